@@ -1,0 +1,670 @@
+// abi.cpp -- the extern "C" surface declared in include/microscopes_hip.h.
+// Host logic only: argument checking, table bookkeeping and kernel launches.
+// There is deliberately no CPU arithmetic path here: every score / update is a
+// kernel in kernels_*.hip, and context creation fails without a gfx950 device.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <new>
+
+#include "launchers.hpp"
+
+namespace msc {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+size_t primitive_size(int t) {
+  static const size_t sz[MSC_TYPE_NELEMS] = {1, 1, 1, 2, 2, 4, 4, 8, 8, 4, 8};
+  return (t >= 0 && t < MSC_TYPE_NELEMS) ? sz[t] : 0;
+}
+
+static bool family_ok(int f) { return f >= MSC_BB && f <= MSC_NOOP; }
+
+template <typename T>
+static int dev_alloc(std::vector<void *> &owned, T **out, size_t count) {
+  void *p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  MSC_HIP(hipMalloc(&p, bytes));
+  MSC_HIP(hipMemset(p, 0, bytes));
+  owned.push_back(p);
+  *out = static_cast<T *>(p);
+  return MSC_OK;
+}
+
+}  // namespace msc
+
+using namespace msc;
+
+// ---------------------------------------------------------------------------
+// library / context
+// ---------------------------------------------------------------------------
+extern "C" int msc_abi_version(void) { return MSC_ABI_VERSION; }
+extern "C" const char *msc_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *msc_build_info(void) {
+  return "microscopes_hip abi " "1" " gfx950 (CDNA4) hipcc " __VERSION__;
+}
+
+extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
+  MSC_REQUIRE(out != nullptr, "msc_context_create: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(MSC_ENODEVICE, "no HIP device visible (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  MSC_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+  hipDeviceProp_t prop;
+  MSC_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MSC_ENODEVICE, "device %d is %s; kernels are built for gfx950 only", device,
+                prop.gcnArchName);
+  MSC_HIP(hipSetDevice(device));
+  std::unique_ptr<msc_context> ctx(new (std::nothrow) msc_context());
+  if (!ctx) return fail(MSC_ENOMEM, "out of host memory");
+  ctx->device = device;
+  ctx->stream = static_cast<hipStream_t>(stream);
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ctx->mailbox_bytes = 64 * 1024;
+  MSC_HIP(hipHostMalloc(&ctx->mailbox_host, ctx->mailbox_bytes, hipHostMallocMapped));
+  MSC_HIP(hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox_host, 0));
+  *out = ctx.release();
+  return MSC_OK;
+}
+
+extern "C" int msc_context_destroy(msc_context *ctx) {
+  if (!ctx) return MSC_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->mailbox_host) (void)hipHostFree(ctx->mailbox_host);
+  delete ctx;
+  return MSC_OK;
+}
+
+extern "C" int msc_context_set_stream(msc_context *ctx, void *stream) {
+  MSC_REQUIRE(ctx, "null context");
+  ctx->stream = static_cast<hipStream_t>(stream);
+  return MSC_OK;
+}
+
+extern "C" int msc_context_synchronize(msc_context *ctx) {
+  MSC_REQUIRE(ctx, "null context");
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  return MSC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dataview
+// ---------------------------------------------------------------------------
+static void free_all(std::vector<void *> &owned) {
+  for (void *p : owned) (void)hipFree(p);
+  owned.clear();
+}
+
+extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_records,
+                                         const uint8_t *host_mask, uint64_t nrows,
+                                         const msc_runtime_type *types, uint32_t ntypes,
+                                         const int32_t *col_types, msc_dataview **out) {
+  MSC_REQUIRE(ctx && out && types, "null argument");
+  MSC_REQUIRE(ntypes > 0, "a dataview needs at least one feature");
+  MSC_REQUIRE(nrows == 0 || host_records, "null records");
+  *out = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  // runtime_type::GetOffsetsAndSize (runtime_type.hpp:123-134)
+  std::vector<UnpackFeat> uf(ntypes);
+  size_t rowsize = 0, maskrowsize = 0;
+  for (uint32_t i = 0; i < ntypes; i++) {
+    MSC_REQUIRE(types[i].type >= 0 && types[i].type < MSC_TYPE_NELEMS, "feature %u: bad type %d", i,
+                types[i].type);
+    MSC_REQUIRE(types[i].count >= 1, "feature %u: count must be >= 1", i);
+    const int dst = col_types ? col_types[i] : types[i].type;
+    MSC_REQUIRE(dst >= 0 && dst < MSC_TYPE_NELEMS, "feature %u: bad column type %d", i, dst);
+    uf[i].offset = (uint32_t)rowsize;
+    uf[i].mask_offset = (uint32_t)maskrowsize;
+    uf[i].src_type = types[i].type;
+    uf[i].dst_type = dst;
+    uf[i].count = types[i].count;
+    rowsize += primitive_size(types[i].type) * types[i].count;
+    maskrowsize += types[i].count;
+  }
+  std::unique_ptr<msc_dataview> v(new (std::nothrow) msc_dataview());
+  if (!v) return fail(MSC_ENOMEM, "out of host memory");
+  v->ctx = ctx;
+  v->nrows = nrows;
+  int rc = MSC_OK;
+  uint8_t *rec_dev = nullptr, *mask_dev = nullptr;
+  UnpackFeat *uf_dev = nullptr;
+  std::vector<void *> scratch;
+  auto cleanup = [&](int code) { free_all(scratch); if (code != MSC_OK) free_all(v->owned); return code; };
+  for (uint32_t i = 0; i < ntypes; i++) {
+    uint8_t *col = nullptr;
+    rc = dev_alloc(v->owned, &col, (size_t)nrows * types[i].count * primitive_size(uf[i].dst_type));
+    if (rc) return cleanup(rc);
+    uf[i].dst = col;
+    uf[i].dst_mask = nullptr;
+    if (host_mask) {
+      rc = dev_alloc(v->owned, &uf[i].dst_mask, (size_t)nrows * types[i].count);
+      if (rc) return cleanup(rc);
+    }
+    v->cols.push_back(col);
+    v->masks.push_back(uf[i].dst_mask);
+    v->types.push_back(msc_runtime_type{uf[i].dst_type, types[i].count});
+  }
+  if (nrows > 0) {
+    if ((rc = dev_alloc(scratch, &rec_dev, (size_t)nrows * rowsize))) return cleanup(rc);
+    if ((rc = dev_alloc(scratch, &uf_dev, ntypes))) return cleanup(rc);
+    if (host_mask && (rc = dev_alloc(scratch, &mask_dev, (size_t)nrows * maskrowsize))) return cleanup(rc);
+    hipError_t e = hipMemcpyAsync(rec_dev, host_records, (size_t)nrows * rowsize, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && host_mask)
+      e = hipMemcpyAsync(mask_dev, host_mask, (size_t)nrows * maskrowsize, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(uf_dev, uf.data(), sizeof(UnpackFeat) * ntypes, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return cleanup(fail(MSC_EHIP, "upload failed: %s", hipGetErrorString(e)));
+    if (launch_unpack(ctx->stream, rec_dev, mask_dev, nrows, (uint32_t)rowsize, (uint32_t)maskrowsize, uf_dev, ntypes))
+      return cleanup(fail(MSC_EHIP, "k_unpack launch failed: %s", hipGetErrorString(hipGetLastError())));
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return cleanup(fail(MSC_EHIP, "k_unpack failed: %s", hipGetErrorString(e)));
+  }
+  cleanup(MSC_OK);
+  *out = v.release();
+  return MSC_OK;
+}
+
+extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows,
+                                                const msc_runtime_type *types, uint32_t ntypes,
+                                                void *const *dev_columns, void *const *dev_masks,
+                                                msc_dataview **out) {
+  MSC_REQUIRE(ctx && out && types && dev_columns, "null argument");
+  MSC_REQUIRE(ntypes > 0, "a dataview needs at least one feature");
+  *out = nullptr;
+  std::unique_ptr<msc_dataview> v(new (std::nothrow) msc_dataview());
+  if (!v) return fail(MSC_ENOMEM, "out of host memory");
+  v->ctx = ctx;
+  v->nrows = nrows;
+  for (uint32_t i = 0; i < ntypes; i++) {
+    MSC_REQUIRE(types[i].type >= 0 && types[i].type < MSC_TYPE_NELEMS, "feature %u: bad type", i);
+    MSC_REQUIRE(types[i].count >= 1, "feature %u: count must be >= 1", i);
+    MSC_REQUIRE(nrows == 0 || dev_columns[i], "feature %u: null column", i);
+    v->types.push_back(types[i]);
+    v->cols.push_back(dev_columns[i]);
+    v->masks.push_back(dev_masks ? dev_masks[i] : nullptr);
+  }
+  *out = v.release();
+  return MSC_OK;
+}
+
+extern "C" int msc_dataview_destroy(msc_dataview *view) {
+  if (!view) return MSC_OK;
+  (void)hipSetDevice(view->ctx->device);
+  free_all(view->owned);
+  delete view;
+  return MSC_OK;
+}
+
+extern "C" int msc_dataview_size(const msc_dataview *view, uint64_t *nrows, uint32_t *nfeatures) {
+  MSC_REQUIRE(view, "null view");
+  if (nrows) *nrows = view->nrows;
+  if (nfeatures) *nfeatures = (uint32_t)view->types.size();
+  return MSC_OK;
+}
+
+extern "C" int msc_dataview_column(const msc_dataview *view, uint32_t feature, void **dev_ptr,
+                                   msc_runtime_type *type) {
+  MSC_REQUIRE(view, "null view");
+  MSC_REQUIRE(feature < view->types.size(), "feature %u out of range", feature);
+  if (dev_ptr) *dev_ptr = view->cols[feature];
+  if (type) *type = view->types[feature];
+  return MSC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------
+extern "C" size_t msc_hp_floats(int family, uint32_t dim) {
+  switch (family) {
+    case MSC_BB: return 2;
+    case MSC_GP: return 2;
+    case MSC_DD: return dim;
+    case MSC_NICH: return 4;
+    case MSC_NIW: return 2 + (size_t)dim + (size_t)dim * dim;
+    default: return 0;
+  }
+}
+
+extern "C" size_t msc_ss_bytes(int family, uint32_t dim) {
+  switch (family) {
+    case MSC_BB: return 8;
+    case MSC_GP: return 12;
+    case MSC_DD: return 4 * (1 + (size_t)dim);
+    case MSC_NICH: return 12;
+    case MSC_NIW: return 4 * (1 + (size_t)dim + (size_t)dim * dim);
+    default: return 4;
+  }
+}
+
+static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
+  // microscopes/models.pyx:189,211,223,238,264-269
+  hp.assign(msc_hp_floats(family, dim), 0.f);
+  switch (family) {
+    case MSC_BB: hp[0] = 1; hp[1] = 1; break;
+    case MSC_GP: hp[0] = 1; hp[1] = 1; break;
+    case MSC_DD: std::fill(hp.begin(), hp.end(), 1.f); break;
+    case MSC_NICH: hp[0] = 0; hp[1] = 1; hp[2] = 1; hp[3] = 1; break;
+    case MSC_NIW:
+      hp[0] = 1; hp[1] = (float)dim;
+      for (uint32_t i = 0; i < dim; i++) hp[2 + dim + (size_t)i * dim + i] = 1.f;
+      break;
+    default: break;
+  }
+}
+
+static int upload_desc(msc_state *st) {
+  MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat,
+                         hipMemcpyHostToDevice, st->ctx->stream));
+  return MSC_OK;
+}
+
+extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *features,
+                                uint32_t nfeatures, uint32_t ngroups, msc_state **out) {
+  MSC_REQUIRE(ctx && features && out, "null argument");
+  MSC_REQUIRE(nfeatures > 0, "a state needs at least one feature");
+  MSC_REQUIRE(ngroups > 0 && ngroups <= (1u << 20), "ngroups %u out of range", ngroups);
+  *out = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  std::unique_ptr<msc_state> st(new (std::nothrow) msc_state());
+  if (!st) return fail(MSC_ENOMEM, "out of host memory");
+  st->ctx = ctx;
+  st->nfeat = nfeatures;
+  st->K = ngroups;
+  st->kpad = round_up(ngroups, kGroupTile);
+  const size_t kpad = st->kpad;
+  st->feats.resize(nfeatures);
+  st->desc_host.resize(nfeatures);
+  size_t n_i64 = kpad, n_f64 = 0;
+  for (uint32_t f = 0; f < nfeatures; f++) {
+    msc_feature_host &h = st->feats[f];
+    h.family = features[f].family;
+    h.dim = features[f].dim;
+    MSC_REQUIRE(family_ok(h.family), "feature %u: unknown family %d", f, h.family);
+    if (h.family == MSC_DD && (h.dim == 0 || h.dim > kMaxDDDim))
+      return fail(MSC_EUNSUPPORTED, "feature %u: dd dim %u outside 1..%u (DirichletDiscrete<128>)", f,
+                  h.dim, kMaxDDDim);
+    if (h.family == MSC_NIW)
+      return fail(MSC_EUNSUPPORTED, "feature %u: niw tables are not built in this revision", f);
+    h.i64_off = n_i64;
+    h.i64_len = acc_i64_rows(h.family, h.dim) * kpad;
+    n_i64 += h.i64_len;
+    h.f64_off = n_f64;
+    h.f64_len = acc_f64_rows(h.family) * kpad;
+    n_f64 += h.f64_len;
+  }
+  st->n_i64 = n_i64;
+  st->n_f64 = n_f64;
+  int rc;
+  auto bail = [&](int code) { free_all(st->owned); return code; };
+  if ((rc = dev_alloc(st->owned, &st->red_i64, n_i64))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->red_f64, n_f64))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->cnt_u32, kpad))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->logpc, 2 * kpad + 4))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
+  for (uint32_t f = 0; f < nfeatures; f++) {
+    msc_feature_host &h = st->feats[f];
+    default_hp(h.family, h.dim, h.hp);
+    if ((rc = dev_alloc(st->owned, &h.hp_dev, h.hp.size()))) return bail(rc);
+    if ((rc = dev_alloc(st->owned, &h.tab, (size_t)tab_rows(h.family, h.dim) * kpad))) return bail(rc);
+    if ((rc = dev_alloc(st->owned, &h.raw_u32, (size_t)raw_u32_rows(h.family, h.dim) * kpad))) return bail(rc);
+    if ((rc = dev_alloc(st->owned, &h.raw_f32, (size_t)raw_f32_rows(h.family) * kpad))) return bail(rc);
+    if (!h.hp.empty()) {
+      hipError_t e = hipMemcpy(h.hp_dev, h.hp.data(), h.hp.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(MSC_EHIP, "hp upload failed: %s", hipGetErrorString(e)));
+    }
+    h.raw_valid = true;
+    h.additive_valid = true;   // both all-zero
+    h.derived_valid = false;
+    FeatDesc &d = st->desc_host[f];
+    std::memset(&d, 0, sizeof d);
+    d.family = h.family;
+    d.dim = h.dim;
+    d.col_type = value_type_of(h.family);
+    d.hp = h.hp_dev;
+    d.tab = h.tab;
+    d.raw_u32 = h.raw_u32;
+    d.raw_f32 = h.raw_f32;
+    d.acc_i64 = st->red_i64 + h.i64_off;
+    d.acc_f64 = st->red_f64 + h.f64_off;
+  }
+  st->cnt_additive_valid = true;
+  if ((rc = upload_desc(st.get()))) return bail(rc);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return bail(fail(MSC_EHIP, "state init failed: %s", hipGetErrorString(e)));
+  *out = st.release();
+  return MSC_OK;
+}
+
+extern "C" int msc_state_destroy(msc_state *st) {
+  if (!st) return MSC_OK;
+  (void)hipSetDevice(st->ctx->device);
+  (void)hipStreamSynchronize(st->ctx->stream);
+  free_all(st->owned);
+  delete st;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_shape(const msc_state *st, uint32_t *nfeatures, uint32_t *ngroups) {
+  MSC_REQUIRE(st, "null state");
+  if (nfeatures) *nfeatures = st->nfeat;
+  if (ngroups) *ngroups = st->K;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_set_hp(msc_state *st, uint32_t feature, const float *host_hp, size_t nfloats) {
+  MSC_REQUIRE(st && host_hp, "null argument");
+  MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
+  msc_feature_host &h = st->feats[feature];
+  MSC_REQUIRE(nfloats == h.hp.size(), "feature %u: hp block has %zu floats, expected %zu", feature,
+              nfloats, h.hp.size());
+  std::copy(host_hp, host_hp + nfloats, h.hp.begin());
+  if (nfloats) {
+    MSC_HIP(hipMemcpyAsync(h.hp_dev, h.hp.data(), nfloats * sizeof(float), hipMemcpyHostToDevice, st->ctx->stream));
+    MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  }
+  h.derived_valid = false;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_get_hp(const msc_state *st, uint32_t feature, float *host_hp, size_t nfloats) {
+  MSC_REQUIRE(st && host_hp, "null argument");
+  MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
+  const msc_feature_host &h = st->feats[feature];
+  MSC_REQUIRE(nfloats == h.hp.size(), "feature %u: hp block has %zu floats, expected %zu", feature,
+              nfloats, h.hp.size());
+  std::copy(h.hp.begin(), h.hp.end(), host_hp);
+  return MSC_OK;
+}
+
+static int ensure_raw(msc_state *st) {
+  bool any = false;
+  for (auto &h : st->feats) any |= !h.raw_valid;
+  if (!any) return MSC_OK;
+  if (launch_commit(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->kpad, st->red_i64, st->cnt_u32))
+    return fail(MSC_EHIP, "k_commit launch failed");
+  for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = false; }
+  st->crp_valid = false;
+  return MSC_OK;
+}
+
+// u32 rows / f32 rows of one family's packed record, in record order
+static void record_layout(int family, uint32_t dim, uint32_t &nu32, uint32_t &nf32) {
+  nu32 = raw_u32_rows(family, dim);
+  nf32 = raw_f32_rows(family);
+}
+
+extern "C" int msc_state_set_ss(msc_state *st, uint32_t feature, uint32_t first_group,
+                                uint32_t ngroups, const void *host_records, size_t nbytes) {
+  MSC_REQUIRE(st && host_records, "null argument");
+  MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
+  msc_feature_host &h = st->feats[feature];
+  MSC_REQUIRE(first_group + ngroups <= st->K && ngroups > 0, "groups [%u,%u) outside [0,%u)",
+              first_group, first_group + ngroups, st->K);
+  const size_t rec = msc_ss_bytes(h.family, h.dim);
+  MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(ensure_raw(st));
+  uint32_t nu32, nf32;
+  record_layout(h.family, h.dim, nu32, nf32);
+  // AoS records -> SoA rows
+  std::vector<uint32_t> su((size_t)nu32 * ngroups);
+  std::vector<float> sf((size_t)nf32 * ngroups);
+  const uint8_t *p = static_cast<const uint8_t *>(host_records);
+  for (uint32_t g = 0; g < ngroups; g++) {
+    const uint8_t *r = p + (size_t)g * rec;
+    for (uint32_t i = 0; i < nu32; i++) std::memcpy(&su[(size_t)i * ngroups + g], r + 4 * i, 4);
+    for (uint32_t i = 0; i < nf32; i++) std::memcpy(&sf[(size_t)i * ngroups + g], r + 4 * (nu32 + i), 4);
+  }
+  for (uint32_t i = 0; i < nu32; i++)
+    MSC_HIP(hipMemcpyAsync(h.raw_u32 + (size_t)i * st->kpad + first_group, &su[(size_t)i * ngroups],
+                           4 * (size_t)ngroups, hipMemcpyHostToDevice, st->ctx->stream));
+  for (uint32_t i = 0; i < nf32; i++)
+    MSC_HIP(hipMemcpyAsync(h.raw_f32 + (size_t)i * st->kpad + first_group, &sf[(size_t)i * ngroups],
+                           4 * (size_t)ngroups, hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  h.additive_valid = false;
+  h.derived_valid = false;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_get_ss(msc_state *st, uint32_t feature, uint32_t first_group,
+                                uint32_t ngroups, void *host_records, size_t nbytes) {
+  MSC_REQUIRE(st && host_records, "null argument");
+  MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
+  msc_feature_host &h = st->feats[feature];
+  MSC_REQUIRE(first_group + ngroups <= st->K && ngroups > 0, "groups [%u,%u) outside [0,%u)",
+              first_group, first_group + ngroups, st->K);
+  const size_t rec = msc_ss_bytes(h.family, h.dim);
+  MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(ensure_raw(st));
+  uint32_t nu32, nf32;
+  record_layout(h.family, h.dim, nu32, nf32);
+  std::vector<uint32_t> su((size_t)nu32 * ngroups);
+  std::vector<float> sf((size_t)nf32 * ngroups);
+  for (uint32_t i = 0; i < nu32; i++)
+    MSC_HIP(hipMemcpyAsync(&su[(size_t)i * ngroups], h.raw_u32 + (size_t)i * st->kpad + first_group,
+                           4 * (size_t)ngroups, hipMemcpyDeviceToHost, st->ctx->stream));
+  for (uint32_t i = 0; i < nf32; i++)
+    MSC_HIP(hipMemcpyAsync(&sf[(size_t)i * ngroups], h.raw_f32 + (size_t)i * st->kpad + first_group,
+                           4 * (size_t)ngroups, hipMemcpyDeviceToHost, st->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  uint8_t *p = static_cast<uint8_t *>(host_records);
+  for (uint32_t g = 0; g < ngroups; g++) {
+    uint8_t *r = p + (size_t)g * rec;
+    for (uint32_t i = 0; i < nu32; i++) std::memcpy(r + 4 * i, &su[(size_t)i * ngroups + g], 4);
+    for (uint32_t i = 0; i < nf32; i++) std::memcpy(r + 4 * (nu32 + i), &sf[(size_t)i * ngroups + g], 4);
+  }
+  return MSC_OK;
+}
+
+extern "C" int msc_state_set_alpha(msc_state *st, float alpha) {
+  MSC_REQUIRE(st, "null state");
+  MSC_REQUIRE(alpha > 0.f, "alpha must be positive (group_manager.hpp:78)");
+  st->alpha = alpha;
+  st->crp_valid = false;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_set_group_counts(msc_state *st, const uint32_t *host_counts, uint32_t ngroups) {
+  MSC_REQUIRE(st && host_counts, "null argument");
+  MSC_REQUIRE(ngroups == st->K, "expected %u counts, got %u", st->K, ngroups);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(ensure_raw(st));
+  MSC_HIP(hipMemcpyAsync(st->cnt_u32, host_counts, 4 * (size_t)ngroups, hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  st->cnt_additive_valid = false;
+  st->crp_valid = false;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, uint32_t ngroups) {
+  MSC_REQUIRE(st && host_counts, "null argument");
+  MSC_REQUIRE(ngroups == st->K, "expected %u counts, got %u", st->K, ngroups);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(ensure_raw(st));
+  MSC_HIP(hipMemcpyAsync(host_counts, st->cnt_u32, 4 * (size_t)ngroups, hipMemcpyDeviceToHost, st->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  return MSC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// binding a dataview to the state's features
+// ---------------------------------------------------------------------------
+static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                     uint64_t nrows) {
+  MSC_REQUIRE(view, "null dataview");
+  MSC_REQUIRE(view->ctx->device == st->ctx->device, "dataview and state live on different devices");
+  MSC_REQUIRE(row0 + nrows <= view->nrows, "rows [%llu,%llu) outside the view (%llu rows)",
+              (unsigned long long)row0, (unsigned long long)(row0 + nrows),
+              (unsigned long long)view->nrows);
+  bool same = st->bound_view == view && st->bound_cols.size() == st->nfeat;
+  for (uint32_t f = 0; f < st->nfeat && same; f++) same = st->bound_cols[f] == (cols ? cols[f] : f);
+  if (same) {
+    for (uint32_t f = 0; f < st->nfeat && same; f++)
+      same = st->desc_host[f].col == view->cols[st->bound_cols[f]];
+  }
+  if (same) return MSC_OK;
+  st->bound_cols.resize(st->nfeat);
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    const uint32_t c = cols ? cols[f] : f;
+    MSC_REQUIRE(c < view->types.size(), "feature %u: column %u outside the view (%zu columns)", f, c,
+                view->types.size());
+    const msc_feature_host &h = st->feats[f];
+    const msc_runtime_type t = view->types[c];
+    if (h.family != MSC_NOOP) {
+      const uint32_t want_n = h.family == MSC_NIW ? h.dim : 1;
+      // model::get_runtime_type() must match the column (distributions.hpp:398-403, _dataview.pyx:27-44)
+      MSC_REQUIRE(t.type == value_type_of(h.family) && t.count == want_n,
+                  "feature %u: column %u has type (%d x %u) but the model wants (%d x %u); convert at upload",
+                  f, c, t.type, t.count, value_type_of(h.family), want_n);
+    }
+    st->bound_cols[f] = c;
+    st->desc_host[f].col = view->cols[c];
+    st->desc_host[f].mask = static_cast<const uint8_t *>(view->masks[c]);
+    st->desc_host[f].col_type = t.type;
+  }
+  st->bound_view = view;
+  return upload_desc(st);
+}
+
+static int ensure_derived(msc_state *st) {
+  MSC_TRY(ensure_raw(st));
+  bool any = false;
+  for (auto &h : st->feats) any |= !h.derived_valid;
+  if (!any) return MSC_OK;
+  if (launch_prepare(st->ctx->stream, st->desc_dev, st->nfeat, st->kpad))
+    return fail(MSC_EHIP, "k_prepare launch failed");
+  for (auto &h : st->feats) h.derived_valid = true;
+  return MSC_OK;
+}
+
+static int ensure_crp(msc_state *st) {
+  MSC_TRY(ensure_raw(st));
+  if (st->crp_valid) return MSC_OK;
+  if (launch_crp_prepare(st->ctx->stream, st->cnt_u32, st->K, st->kpad, st->alpha, st->logpc))
+    return fail(MSC_EHIP, "k_crp_prepare launch failed");
+  st->crp_valid = true;
+  return MSC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------
+extern "C" int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *cols,
+                               uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags,
+                               float *out_dev, uint64_t ld_out) {
+  MSC_REQUIRE(st && out_dev, "null argument");
+  MSC_REQUIRE(ld_out >= st->K, "ld_out %llu < ngroups %u", (unsigned long long)ld_out, st->K);
+  MSC_REQUIRE((flags & ~MSC_SCORE_CRP_PRIOR) == 0, "unknown flags 0x%x", flags);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(bind_view(st, view, cols, row0, nrows));
+  if (nrows == 0) return MSC_OK;
+  MSC_TRY(ensure_derived(st));
+  const bool crp = (flags & MSC_SCORE_CRP_PRIOR) != 0;
+  if (crp) MSC_TRY(ensure_crp(st));
+  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  if (launch_score(st->ctx->stream, st->ctx->num_cus, nich1, st->desc_dev, (int)st->nfeat, st->K, st->kpad,
+                   row0, nrows, z_dev, crp ? st->logpc : nullptr, out_dev, ld_out))
+    return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return MSC_OK;
+}
+
+static int commit(msc_state *st) {
+  if (launch_commit(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->kpad, st->red_i64, st->cnt_u32))
+    return fail(MSC_EHIP, "k_commit launch failed");
+  for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = false; }
+  st->crp_valid = false;
+  return MSC_OK;
+}
+
+extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols,
+                              uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags) {
+  MSC_REQUIRE(st && z_dev, "null argument");
+  MSC_REQUIRE((flags & ~(MSC_ACC_RESET | MSC_ACC_SUBTRACT | MSC_ACC_NO_COMMIT)) == 0, "unknown flags 0x%x", flags);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(bind_view(st, view, cols, row0, nrows));
+  hipStream_t s = st->ctx->stream;
+  if (flags & MSC_ACC_RESET) {
+    MSC_HIP(hipMemsetAsync(st->red_i64, 0, st->n_i64 * sizeof(long long), s));
+    if (st->n_f64) MSC_HIP(hipMemsetAsync(st->red_f64, 0, st->n_f64 * sizeof(double), s));
+  } else {
+    MSC_TRY(ensure_raw(st));
+    for (uint32_t f = 0; f < st->nfeat; f++)
+      if (!st->feats[f].additive_valid)
+        if (launch_lift(s, st->desc_dev + f, 1, st->kpad, st->red_i64, st->cnt_u32, 0))
+          return fail(MSC_EHIP, "k_lift launch failed");
+    if (!st->cnt_additive_valid)
+      if (launch_lift(s, st->desc_dev, 0, st->kpad, st->red_i64, st->cnt_u32, 1))
+        return fail(MSC_EHIP, "k_lift launch failed");
+  }
+  for (auto &h : st->feats) h.additive_valid = true;
+  st->cnt_additive_valid = true;
+  if (nrows > 0) {
+    const int rc = launch_accumulate(s, st->ctx->num_cus, st->desc_dev, st->desc_host.data(), (int)st->nfeat,
+                                     st->K, st->kpad, row0, nrows, z_dev,
+                                     (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->red_i64);
+    if (rc == -2) return fail(MSC_EUNSUPPORTED, "accumulate tables for %u groups exceed LDS", st->K);
+    if (rc) return fail(MSC_EHIP, "k_accumulate launch failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  for (auto &h : st->feats) h.raw_valid = false;
+  if (!(flags & MSC_ACC_NO_COMMIT)) MSC_TRY(commit(st));
+  return MSC_OK;
+}
+
+extern "C" int msc_score_data(msc_state *st, float *out_dev) {
+  MSC_REQUIRE(st && out_dev, "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(ensure_raw(st));
+  if (launch_score_data(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->K, st->kpad, out_dev))
+    return fail(MSC_EHIP, "k_score_data launch failed");
+  return MSC_OK;
+}
+
+extern "C" int msc_sweep_assign(msc_state *, const msc_dataview *, const uint32_t *, uint64_t, uint64_t,
+                                uint64_t, int32_t *, uint64_t, uint64_t) {
+  return fail(MSC_EUNSUPPORTED, "msc_sweep_assign: not built in this revision");
+}
+
+extern "C" int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n_i64, void **dev_f64,
+                                        size_t *n_f64) {
+  MSC_REQUIRE(st, "null state");
+  if (dev_i64) *dev_i64 = st->red_i64;
+  if (n_i64) *n_i64 = st->n_i64;
+  if (dev_f64) *dev_f64 = st->red_f64;
+  if (n_f64) *n_f64 = st->n_f64;
+  return MSC_OK;
+}
+
+extern "C" int msc_state_commit_reduce(msc_state *st) {
+  MSC_REQUIRE(st, "null state");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  return commit(st);
+}
+
+extern "C" int msc_value_op_single(msc_context *, int, uint32_t, int, const float *, void *, const void *,
+                                   float *) {
+  return fail(MSC_EUNSUPPORTED, "msc_value_op_single: not built in this revision");
+}

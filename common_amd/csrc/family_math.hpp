@@ -1,0 +1,219 @@
+// family_math.hpp -- device-side arithmetic of the component models, shared by
+// every kernel (batched score, fused sweep, per-value mailbox).  gfx950 only.
+//
+// Split of labour
+//   * "prepare" functions run once per (feature, group) in double and turn the
+//     reference's suff-stats (distributions.hpp:21-56 field names) into a few
+//     float constants per group, so that the per-evaluation work is a handful of
+//     float instructions (the reference instead rebuilds the posterior on every
+//     score_value call).
+//   * "eval" functions are the per-(row, group) float work.  They are written so
+//     that the result stays within 1e-6 of the double evaluation: differences of
+//     large numbers are taken in the prepare step, log1p is compensated, and the
+//     posterior mean is carried as a hi/lo float pair.
+//   * "loo" functions evaluate one row against its own group with the row
+//     removed (remove_value then score_value) in double; they run
+//     lane-parallel over rows, once per row, so their cost is amortised over K.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "msc_internal.hpp"
+
+namespace msc {
+
+#define MSC_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kLogPi = 1.1447298858494001741;
+constexpr double kHalfLog2Pi = 0.91893853320467274178;
+constexpr float kLn2f = 0.69314718055994530942f;
+
+// v_log_f32 is log2 with ~1 ulp; arguments here are >= 1 so denormals never occur.
+MSC_DEV float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
+MSC_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// log2(1+t) and the first-order compensation term r such that
+//   log(1+t) = ln2 * log2(u) + r,  u = fl(1+t),  r = (t - (u-1)) / u     (t >= 0)
+// (u-1 is exact for u >= 1, t-(u-1) is exact, so only the division rounds.)
+MSC_DEV void log1p_parts(float t, float &l2, float &r) {
+  const float u = 1.0f + t;
+  l2 = hw_log2(u);
+  r = (t - (u - 1.0f)) * hw_rcp(u);
+}
+MSC_DEV float log1p_acc(float t) {
+  float l2, r;
+  log1p_parts(t, l2, r);
+  return fmaf(l2, kLn2f, r);
+}
+
+MSC_DEV void split_hi_lo(double v, float &hi, float &lo) {
+  hi = (float)v;
+  lo = (float)(v - (double)hi);
+}
+
+// ============================ Beta-Bernoulli ================================
+// tab rows: 0 = log p(v = 0), 1 = log p(v = 1)
+MSC_DEV void bb_prepare(const float *hp, uint32_t heads, uint32_t tails, float &s0, float &s1) {
+  const double a = hp[0], b = hp[1], h = heads, t = tails;
+  const double den = a + b + h + t;
+  s0 = (float)log((b + t) / den);
+  s1 = (float)log((a + h) / den);
+}
+MSC_DEV double bb_loo(const float *hp, uint32_t heads, uint32_t tails, bool v) {
+  const double a = hp[0], b = hp[1];
+  const double h = (double)heads - (v ? 1.0 : 0.0), t = (double)tails - (v ? 0.0 : 1.0);
+  return log((v ? a + h : b + t) / (a + b + h + t));
+}
+MSC_DEV double bb_score_data(const float *hp, uint32_t heads, uint32_t tails) {
+  const double a = hp[0], b = hp[1], h = heads, t = tails;
+  return lgamma(a + b) - lgamma(a + b + h + t) + lgamma(a + h) - lgamma(a) + lgamma(b + t) -
+         lgamma(b);
+}
+
+// ============================ Dirichlet-Discrete ============================
+// tab rows: i in [0, dim) -> log p(v = i)
+MSC_DEV float dd_prepare_entry(float alpha_i, uint32_t count_i, double alpha_sum, uint32_t count_sum) {
+  return (float)log(((double)alpha_i + (double)count_i) / (alpha_sum + (double)count_sum));
+}
+MSC_DEV double dd_loo(float alpha_v, uint32_t count_v, double alpha_sum, uint32_t count_sum) {
+  return log(((double)alpha_v + (double)count_v - 1.0) / (alpha_sum + (double)count_sum - 1.0));
+}
+
+// ============================ Gamma-Poisson =================================
+// Posterior a = alpha + sum, b = inv_beta + count.  Negative-binomial predictive
+//   score(v) = lgamma(a+v) - lgamma(a) - lgamma(v+1) + a ln b - (a+v) ln(1+b)
+// evaluated for z = a + v >= 4 through Stirling's series on lgamma(z) only:
+//   score(v) = (a-1/2) log1p(v/a) + v (ln(z/(1+b)) - 1) + S(z) - Sa + C - lgamma(v+1)
+//   Sa = lgamma(a) - [(a-1/2) ln a - a + ln(2pi)/2]   exact residual, taken in double
+//   C  = a ln(b/(1+b))
+// and through four exact per-group constants for v in {0,1,2,3}.
+// tab rows: 0 a, 1 inv_a, 2 a-1/2, 3 inv_1pb, 4 C - Sa, 5..8?  -> see GP_ROWS below
+enum { GP_A = 0, GP_INV_A = 1, GP_AMH = 2, GP_INV1PB = 3, GP_CMS = 4, GP_T0 = 5 /* T0..T3 */, GP_ROWS = 9 };
+
+MSC_DEV double gp_score_exact(double a, double b, double v) {
+  return lgamma(a + v) - lgamma(a) - lgamma(v + 1.0) + a * log(b) - (a + v) * log1p(b);
+}
+MSC_DEV void gp_prepare(const float *hp, uint32_t count, uint32_t sum, float *out /*GP_ROWS*/) {
+  const double a = (double)hp[0] + (double)sum, b = (double)hp[1] + (double)count;
+  const double sa = lgamma(a) - ((a - 0.5) * log(a) - a + kHalfLog2Pi);
+  const double c = a * (log(b) - log1p(b));
+  out[GP_A] = (float)a;
+  out[GP_INV_A] = (float)(1.0 / a);
+  out[GP_AMH] = (float)(a - 0.5);
+  out[GP_INV1PB] = (float)(1.0 / (1.0 + b));
+  out[GP_CMS] = (float)(c - sa);
+  for (int v = 0; v < 4; v++) out[GP_T0 + v] = (float)gp_score_exact(a, b, (double)v);
+}
+MSC_DEV float stirling_tail(float rz) {  // S(z) = 1/(12z) - 1/(360z^3) + 1/(1260z^5) - 1/(1680z^7)
+  const float r2 = rz * rz;
+  float p = fmaf(r2, -1.0f / 1680.0f, 1.0f / 1260.0f);
+  p = fmaf(r2, p, -1.0f / 360.0f);
+  p = fmaf(r2, p, 1.0f / 12.0f);
+  return p * rz;
+}
+// v >= 4 (so z >= 4); vf = (float)v, neg_lgv1 = -lgamma(v+1) (per row)
+MSC_DEV float gp_eval_large(float vf, float neg_lgv1, float a, float inv_a, float amh, float inv1pb,
+                            float cms) {
+  const float l1 = log1p_acc(vf * inv_a);
+  const float z = a + vf;
+  const float lw = hw_log2(z * inv1pb) * kLn2f;
+  const float s = stirling_tail(hw_rcp(z));
+  float acc = cms + neg_lgv1;
+  acc = fmaf(amh, l1, acc);
+  acc = fmaf(vf, lw - 1.0f, acc);
+  return acc + s;
+}
+MSC_DEV double gp_loo(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
+  const double a = (double)hp[0] + (double)sum - (double)v, b = (double)hp[1] + (double)count - 1.0;
+  return gp_score_exact(a, b, (double)v);
+}
+MSC_DEV double gp_score_data(const float *hp, uint32_t count, uint32_t sum, double log_prod) {
+  const double al = hp[0], ib = hp[1];
+  const double a = al + (double)sum, b = ib + (double)count;
+  return lgamma(a) - lgamma(al) + al * log(ib) - a * log(b) - log_prod;
+}
+
+// ============================ Normal-Inverse-Chi^2 ==========================
+// Posterior (kappa', mu', nu', sigmasq') from (count, mean, count_times_variance);
+// Student-t predictive  score(x) = c0 - c1 * log1p(c2 (x - mu')^2)
+//   c0 = lgamma((nu'+1)/2) - lgamma(nu'/2) + ln(lambda/(pi nu'))/2,  c1 = (nu'+1)/2,
+//   c2 = lambda/nu',  lambda = kappa'/((kappa'+1) sigmasq')
+enum { NICH_MU_HI = 0, NICH_MU_LO = 1, NICH_C0 = 2, NICH_C1LN2 = 3, NICH_C1 = 4, NICH_C2 = 5, NICH_ROWS = 6 };
+
+struct NichPost { double mu, kappa, sigmasq, nu; };
+MSC_DEV NichPost nich_posterior(const float *hp, double n, double mean, double ctv) {
+  const double mu = hp[0], kappa = hp[1], sigmasq = hp[2], nu = hp[3];
+  NichPost p;
+  const double d = mu - mean;
+  p.kappa = kappa + n;
+  p.mu = (kappa * mu + mean * n) / p.kappa;
+  p.nu = nu + n;
+  p.sigmasq = (nu * sigmasq + ctv + (n * kappa * d * d) / p.kappa) / p.nu;
+  return p;
+}
+MSC_DEV void nich_coeffs(const NichPost &p, double &c0, double &c1, double &c2) {
+  const double lambda = p.kappa / ((p.kappa + 1.0) * p.sigmasq);
+  c0 = lgamma(0.5 * p.nu + 0.5) - lgamma(0.5 * p.nu) + 0.5 * log(lambda / (kPi * p.nu));
+  c1 = 0.5 * p.nu + 0.5;
+  c2 = lambda / p.nu;
+}
+MSC_DEV void nich_prepare(const float *hp, uint32_t count, float mean, float ctv, float *out /*NICH_ROWS*/) {
+  const NichPost p = nich_posterior(hp, (double)count, (double)mean, (double)ctv);
+  double c0, c1, c2;
+  nich_coeffs(p, c0, c1, c2);
+  split_hi_lo(p.mu, out[NICH_MU_HI], out[NICH_MU_LO]);
+  out[NICH_C0] = (float)c0;
+  out[NICH_C1LN2] = (float)(c1 * 0.69314718055994530942);
+  out[NICH_C1] = (float)c1;
+  out[NICH_C2] = (float)c2;
+}
+MSC_DEV float nich_eval(float x, float mu_hi, float mu_lo, float c0, float c1ln2, float c1, float c2) {
+  const float d = (x - mu_hi) - mu_lo;
+  float l2, r;
+  log1p_parts(c2 * d * d, l2, r);
+  return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
+}
+// remove_value (Welford downdate) then score_value, all in double
+MSC_DEV double nich_loo(const float *hp, uint32_t count, float mean_f, float ctv_f, float xf) {
+  const double x = xf, mean = mean_f, ctv = ctv_f;
+  const double total = mean * (double)count, delta = x - mean;
+  const double n = (double)count - 1.0;
+  const double m2 = (count <= 1) ? 0.0 : (total - x) / n;
+  const double v2 = (n <= 1.0) ? 0.0 : ctv - delta * (x - m2);
+  const NichPost p = nich_posterior(hp, n, m2, v2);
+  double c0, c1, c2;
+  nich_coeffs(p, c0, c1, c2);
+  const double d = x - p.mu;
+  return c0 - c1 * log1p(c2 * d * d);
+}
+MSC_DEV double nich_score_data(const float *hp, uint32_t count, float mean, float ctv) {
+  const NichPost p = nich_posterior(hp, (double)count, (double)mean, (double)ctv);
+  const double kappa = hp[1], sigmasq = hp[2], nu = hp[3];
+  return lgamma(0.5 * p.nu) - lgamma(0.5 * nu) + 0.5 * log(kappa / p.kappa) +
+         0.5 * nu * log(nu * sigmasq) - 0.5 * p.nu * log(p.nu * p.sigmasq) -
+         0.5 * (double)count * kLogPi;
+}
+
+// ============================ typed column loads ============================
+// runtime_cast::cast<T>(px, t) (runtime_type.hpp:145-166): load as the stored C
+// type, convert with the implicit C++ conversion.
+template <typename T>
+MSC_DEV T load_as(const void *base, uint64_t idx, int type) {
+  switch (type) {
+    case MSC_TYPE_B: return (T)(((const uint8_t *)base)[idx] != 0);
+    case MSC_TYPE_I8: return (T)((const int8_t *)base)[idx];
+    case MSC_TYPE_U8: return (T)((const uint8_t *)base)[idx];
+    case MSC_TYPE_I16: return (T)((const int16_t *)base)[idx];
+    case MSC_TYPE_U16: return (T)((const uint16_t *)base)[idx];
+    case MSC_TYPE_I32: return (T)((const int32_t *)base)[idx];
+    case MSC_TYPE_U32: return (T)((const uint32_t *)base)[idx];
+    case MSC_TYPE_I64: return (T)((const long long *)base)[idx];
+    case MSC_TYPE_U64: return (T)((const unsigned long long *)base)[idx];
+    case MSC_TYPE_F32: return (T)((const float *)base)[idx];
+    case MSC_TYPE_F64: return (T)((const double *)base)[idx];
+    default: return T();
+  }
+}
+
+}  // namespace msc

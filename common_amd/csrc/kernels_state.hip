@@ -1,0 +1,368 @@
+// kernels_state.hip -- gfx950 kernels for the state side of the hot path:
+//   k_accumulate   bulk add_value / remove_value keyed by the assignment vector
+//   k_commit       additive sums (all-reduce payload) -> the reference's fields
+//   k_lift         the reference's fields -> additive sums
+//   k_score_data   marginal likelihood of every (feature, group)
+//   k_unpack       packed row-major records -> one typed column per feature
+#include "family_math.hpp"
+#include "launchers.hpp"
+
+namespace msc {
+
+// ---------------------------------------------------------------------------
+// accumulate.  Each workgroup owns a contiguous slice of rows and, feature by
+// feature, histograms it into LDS (ds_add_u32 / ds_add_u64 / ds_add_f64), then
+// flushes the non-zero bins with one global atomic each.  Integer fields are
+// exact whatever the order; float fields are summed in double.
+// LDS layout per pass: f64[K * nf64] | u64[K * nu64] | u32[K * nu32]
+// ---------------------------------------------------------------------------
+struct AccShape { uint32_t nu32, nu64, nf64; };
+__device__ __host__ inline AccShape acc_shape(int family, uint32_t dim_slice) {
+  switch (family) {
+    case MSC_BB: return {2, 0, 0};
+    case MSC_GP: return {1, 1, 1};
+    case MSC_DD: return {dim_slice, 0, 0};
+    case MSC_NICH: return {1, 0, 2};
+    default: return {0, 0, 0};
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict__ feats, int nfeat,
+                                                      uint32_t K, uint32_t kpad, uint64_t row0,
+                                                      uint64_t nrows, const int32_t *__restrict__ z,
+                                                      int sign, long long *__restrict__ cnt_acc,
+                                                      uint32_t dd_slice) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per;
+  const uint64_t hi = lo + per < nrows ? lo + per : nrows;
+  const long long sgn = sign;
+
+  // pass -1: group sizes (group_manager counts)
+  {
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) c32[i] = 0;
+    __syncthreads();
+    for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+      const int g = z[n];
+      if (g >= 0 && (uint32_t)g < K) atomicAdd(&c32[g], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
+      if (c32[i]) atomicAdd(reinterpret_cast<unsigned long long *>(&cnt_acc[i]),
+                            (unsigned long long)(sgn * (long long)c32[i]));
+    __syncthreads();
+  }
+
+  for (int f = 0; f < nfeat; f++) {
+    const FeatDesc fd = feats[f];
+    const uint32_t nslices = fd.family == MSC_DD ? (fd.dim + dd_slice - 1) / dd_slice : 1;
+    for (uint32_t sl = 0; sl < nslices; sl++) {
+      const uint32_t c_lo = sl * dd_slice;
+      const uint32_t c_n = fd.family == MSC_DD ? (fd.dim - c_lo < dd_slice ? fd.dim - c_lo : dd_slice) : 0;
+      const AccShape sh = acc_shape(fd.family, c_n);
+      double *f64 = reinterpret_cast<double *>(smem);
+      unsigned long long *u64 = reinterpret_cast<unsigned long long *>(f64 + (size_t)K * sh.nf64);
+      uint32_t *u32 = reinterpret_cast<uint32_t *>(u64 + (size_t)K * sh.nu64);
+      for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += blockDim.x) f64[i] = 0.0;
+      for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) u64[i] = 0ull;
+      for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += blockDim.x) u32[i] = 0u;
+      __syncthreads();
+      for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+        const int g = z[n];
+        if (g < 0 || (uint32_t)g >= K) continue;
+        const uint64_t row = row0 + n;
+        switch (fd.family) {
+          case MSC_BB: {
+            const bool v = reinterpret_cast<const uint8_t *>(fd.col)[row] != 0;
+            atomicAdd(&u32[(v ? 0 : K) + g], 1u);
+          } break;
+          case MSC_GP: {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+            atomicAdd(&u32[g], 1u);
+            atomicAdd(&u64[g], (unsigned long long)v);
+            atomicAdd(&f64[g], lgamma((double)v + 1.0));
+          } break;
+          case MSC_DD: {
+            const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+            if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + g], 1u);
+          } break;
+          case MSC_NICH: {
+            const double x = reinterpret_cast<const float *>(fd.col)[row];
+            atomicAdd(&u32[g], 1u);
+            atomicAdd(&f64[g], x);
+            atomicAdd(&f64[K + g], x * x);
+          } break;
+          default: break;
+        }
+      }
+      __syncthreads();
+      // flush: row r of the pass maps to a row of the feature's additive tables
+      for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += blockDim.x) {
+        const uint32_t r = i / K, k = i - r * K;
+        if (!u32[i]) continue;
+        uint32_t dst_row = r;
+        if (fd.family == MSC_DD) dst_row = c_lo + r;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
+                  (unsigned long long)(sgn * (long long)u32[i]));
+      }
+      for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) {
+        const uint32_t r = i / K, k = i - r * K;
+        if (!u64[i]) continue;
+        // gp: u64 row 0 is `sum`, additive row 1
+        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)(1 + r) * kpad + k]),
+                  (unsigned long long)(sgn * (long long)u64[i]));
+      }
+      for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += blockDim.x) {
+        const uint32_t r = i / K, k = i - r * K;
+        if (f64[i] != 0.0) atomicAdd(&fd.acc_f64[(size_t)r * kpad + k], (double)sign * f64[i]);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// commit: additive -> raw.  blockIdx.y = feature (nfeat = the group-size table)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_commit(const FeatDesc *__restrict__ feats, int nfeat,
+                                                 uint32_t kpad, const long long *__restrict__ cnt_acc,
+                                                 uint32_t *__restrict__ cnt_u32) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kpad) return;
+  if ((int)blockIdx.y == nfeat) {
+    cnt_u32[k] = (uint32_t)cnt_acc[k];
+    return;
+  }
+  const FeatDesc fd = feats[blockIdx.y];
+  switch (fd.family) {
+    case MSC_BB:
+      fd.raw_u32[k] = (uint32_t)fd.acc_i64[k];
+      fd.raw_u32[kpad + k] = (uint32_t)fd.acc_i64[kpad + k];
+      break;
+    case MSC_GP:
+      fd.raw_u32[k] = (uint32_t)fd.acc_i64[k];
+      fd.raw_u32[kpad + k] = (uint32_t)fd.acc_i64[kpad + k];
+      fd.raw_f32[k] = (float)fd.acc_f64[k];
+      break;
+    case MSC_DD: {
+      long long tot = 0;
+      for (uint32_t i = 0; i < fd.dim; i++) {
+        const long long c = fd.acc_i64[(size_t)i * kpad + k];
+        fd.raw_u32[(size_t)(1 + i) * kpad + k] = (uint32_t)c;
+        tot += c;
+      }
+      fd.raw_u32[k] = (uint32_t)tot;
+    } break;
+    case MSC_NICH: {
+      const long long n = fd.acc_i64[k];
+      const double sx = fd.acc_f64[k], sxx = fd.acc_f64[kpad + k];
+      double mean = 0, ctv = 0;
+      if (n > 0) mean = sx / (double)n;
+      if (n > 1) {
+        ctv = sxx - (double)n * mean * mean;
+        if (ctv < 0) ctv = 0;
+      }
+      fd.raw_u32[k] = (uint32_t)n;
+      fd.raw_f32[k] = (float)mean;
+      fd.raw_f32[kpad + k] = (float)ctv;
+    } break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lift(const FeatDesc *__restrict__ feats, int nfeat,
+                                               uint32_t kpad, long long *__restrict__ cnt_acc,
+                                               const uint32_t *__restrict__ cnt_u32, int lift_cnt) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kpad) return;
+  if ((int)blockIdx.y == nfeat) {
+    if (lift_cnt) cnt_acc[k] = cnt_u32[k];
+    return;
+  }
+  const FeatDesc fd = feats[blockIdx.y];
+  if (fd.acc_i64 == nullptr) return;   // feature already in sync (host passes null to skip)
+  switch (fd.family) {
+    case MSC_BB:
+      fd.acc_i64[k] = fd.raw_u32[k];
+      fd.acc_i64[kpad + k] = fd.raw_u32[kpad + k];
+      break;
+    case MSC_GP:
+      fd.acc_i64[k] = fd.raw_u32[k];
+      fd.acc_i64[kpad + k] = fd.raw_u32[kpad + k];
+      fd.acc_f64[k] = fd.raw_f32[k];
+      break;
+    case MSC_DD:
+      for (uint32_t i = 0; i < fd.dim; i++)
+        fd.acc_i64[(size_t)i * kpad + k] = fd.raw_u32[(size_t)(1 + i) * kpad + k];
+      break;
+    case MSC_NICH: {
+      const double n = fd.raw_u32[k], mean = fd.raw_f32[k], ctv = fd.raw_f32[kpad + k];
+      fd.acc_i64[k] = fd.raw_u32[k];
+      fd.acc_f64[k] = n * mean;
+      fd.acc_f64[kpad + k] = ctv + n * mean * mean;
+    } break;
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// score_data for every (feature, group): out[f * K + k]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score_data(const FeatDesc *__restrict__ feats, uint32_t K,
+                                                     uint32_t kpad, float *__restrict__ out) {
+  const FeatDesc fd = feats[blockIdx.y];
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double s = 0;
+  switch (fd.family) {
+    case MSC_BB: s = bb_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k]); break;
+    case MSC_GP: s = gp_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], (double)fd.raw_f32[k]); break;
+    case MSC_DD: {
+      double asum = 0;
+      for (uint32_t i = 0; i < fd.dim; i++) {
+        const double a = fd.hp[i];
+        asum += a;
+        s += lgamma(a + (double)fd.raw_u32[(size_t)(1 + i) * kpad + k]) - lgamma(a);
+      }
+      s += lgamma(asum) - lgamma(asum + (double)fd.raw_u32[k]);
+    } break;
+    case MSC_NICH: s = nich_score_data(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k]); break;
+    default: break;
+  }
+  out[(size_t)blockIdx.y * K + k] = (float)s;
+}
+
+// ---------------------------------------------------------------------------
+// unpack: one thread per (row, feature element).  src are packed records;
+// element e of feature f lands at dst[f][row * count + e] converted src->dst type.
+// ---------------------------------------------------------------------------
+
+template <typename D>
+MSC_DEV void store_as(void *dst, uint64_t idx, int src_type, const uint8_t *px) {
+  // px may be unaligned inside a packed record: assemble the value bytewise
+  unsigned long long raw = 0;
+  const int n = src_type == MSC_TYPE_B || src_type == MSC_TYPE_I8 || src_type == MSC_TYPE_U8 ? 1
+              : src_type == MSC_TYPE_I16 || src_type == MSC_TYPE_U16 ? 2
+              : src_type == MSC_TYPE_I32 || src_type == MSC_TYPE_U32 || src_type == MSC_TYPE_F32 ? 4 : 8;
+  for (int i = 0; i < n; i++) raw |= (unsigned long long)px[i] << (8 * i);
+  D out;
+  switch (src_type) {
+    case MSC_TYPE_B: out = (D)(raw != 0); break;
+    case MSC_TYPE_I8: out = (D)(int8_t)raw; break;
+    case MSC_TYPE_U8: out = (D)(uint8_t)raw; break;
+    case MSC_TYPE_I16: out = (D)(int16_t)raw; break;
+    case MSC_TYPE_U16: out = (D)(uint16_t)raw; break;
+    case MSC_TYPE_I32: out = (D)(int32_t)raw; break;
+    case MSC_TYPE_U32: out = (D)(uint32_t)raw; break;
+    case MSC_TYPE_I64: out = (D)(long long)raw; break;
+    case MSC_TYPE_U64: out = (D)raw; break;
+    case MSC_TYPE_F32: out = (D)__uint_as_float((uint32_t)raw); break;
+    default: out = (D)__longlong_as_double((long long)raw); break;
+  }
+  reinterpret_cast<D *>(dst)[idx] = out;
+}
+
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ records,
+                                                 const uint8_t *__restrict__ mask, uint64_t nrows,
+                                                 uint32_t rowsize, uint32_t maskrowsize,
+                                                 const UnpackFeat *__restrict__ feats, uint32_t nfeat) {
+  const uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= nrows) return;
+  const uint8_t *rec = records + row * rowsize;
+  for (uint32_t f = 0; f < nfeat; f++) {
+    const UnpackFeat uf = feats[f];
+    const uint32_t psz = uf.src_type <= MSC_TYPE_U8 ? 1 : uf.src_type <= MSC_TYPE_U16 ? 2
+                       : (uf.src_type <= MSC_TYPE_U32 || uf.src_type == MSC_TYPE_F32) ? 4 : 8;
+    for (uint32_t e = 0; e < uf.count; e++) {
+      const uint8_t *px = rec + uf.offset + e * psz;
+      const uint64_t idx = row * uf.count + e;
+      switch (uf.dst_type) {
+        case MSC_TYPE_B: {
+          double tmp;
+          store_as<double>(&tmp, 0, uf.src_type, px);
+          reinterpret_cast<uint8_t *>(uf.dst)[idx] = tmp != 0.0;
+        } break;
+        case MSC_TYPE_I8: store_as<int8_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_U8: store_as<uint8_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_I16: store_as<int16_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_U16: store_as<uint16_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_I32: store_as<int32_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_U32: store_as<uint32_t>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_I64: store_as<long long>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_U64: store_as<unsigned long long>(uf.dst, idx, uf.src_type, px); break;
+        case MSC_TYPE_F32: store_as<float>(uf.dst, idx, uf.src_type, px); break;
+        default: store_as<double>(uf.dst, idx, uf.src_type, px); break;
+      }
+      if (uf.dst_mask) uf.dst_mask[idx] = mask ? mask[row * maskrowsize + uf.mask_offset + e] : 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+size_t accumulate_lds_bytes(const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t dd_slice) {
+  size_t need = (size_t)K * 4;
+  for (int f = 0; f < nfeat; f++) {
+    const uint32_t sl = feats_host[f].family == MSC_DD
+                            ? (feats_host[f].dim < dd_slice ? feats_host[f].dim : dd_slice) : 0;
+    const AccShape sh = acc_shape(feats_host[f].family, sl);
+    const size_t b = (size_t)K * (8u * sh.nf64 + 8u * sh.nu64 + 4u * sh.nu32);
+    if (b > need) need = b;
+  }
+  return need;
+}
+
+int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, const FeatDesc *feats_host,
+                      int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                      const int32_t *z, int sign, long long *cnt_acc) {
+  // pick the dd category slice so one pass fits 64 KiB of LDS
+  uint32_t dd_slice = kMaxDDDim;
+  while (dd_slice > 1 && (size_t)K * 4u * dd_slice > 64u * 1024u) dd_slice /= 2;
+  const size_t lds = accumulate_lds_bytes(feats_host, nfeat, K, dd_slice);
+  if (lds > 160u * 1024u) return -2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  uint64_t blocks = (nrows + 4095) / 4096;          // >= 4 rows per thread
+  const uint64_t cap = (uint64_t)num_cus * 2;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)blocks), dim3(1024), lds, stream, feats_dev, nfeat, K,
+                     kpad, row0, nrows, z, sign, cnt_acc, dd_slice);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_commit(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
+                  const long long *cnt_acc, uint32_t *cnt_u32) {
+  hipLaunchKernelGGL(k_commit, dim3((kpad + 255) / 256, nfeat + 1), dim3(256), 0, stream, feats_dev,
+                     nfeat, kpad, cnt_acc, cnt_u32);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
+                long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt) {
+  hipLaunchKernelGGL(k_lift, dim3((kpad + 255) / 256, nfeat + 1), dim3(256), 0, stream, feats_dev, nfeat,
+                     kpad, cnt_acc, cnt_u32, lift_cnt);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                      uint32_t kpad, float *out) {
+  hipLaunchKernelGGL(k_score_data, dim3((K + 255) / 256, nfeat), dim3(256), 0, stream, feats_dev, K,
+                     kpad, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
+                  uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat) {
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, records, mask,
+                     nrows, rowsize, maskrowsize, reinterpret_cast<const UnpackFeat *>(feats_dev), nfeat);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace msc

@@ -1,0 +1,38 @@
+// launchers.hpp -- host entry points of the kernel translation units.
+#pragma once
+#include "msc_internal.hpp"
+
+namespace msc {
+
+struct UnpackFeat {
+  void *dst;
+  uint8_t *dst_mask;     // may be null
+  uint32_t offset;       // byte offset of the feature in the packed record
+  uint32_t mask_offset;  // element offset of the feature in the mask record
+  int32_t src_type, dst_type;
+  uint32_t count;
+  uint32_t pad;
+};
+
+// kernels_score.hip
+int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad);
+int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
+                       float *crp);
+int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev, int nfeat,
+                 uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
+                 const float *crp, float *out, uint64_t ld);
+
+// kernels_state.hip
+int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
+                      const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
+                      uint64_t nrows, const int32_t *z, int sign, long long *cnt_acc);
+int launch_commit(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
+                  const long long *cnt_acc, uint32_t *cnt_u32);
+int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
+                long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt);
+int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                      uint32_t kpad, float *out);
+int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
+                  uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);
+
+}  // namespace msc

@@ -1,0 +1,201 @@
+// msc_internal.hpp -- host-side objects behind include/microscopes_hip.h and the
+// plain-old-data descriptors shared with the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/microscopes_hip.h"
+
+namespace msc {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kGroupTile = 256;    // groups per k-tile: lane <-> 4 consecutive groups
+constexpr unsigned kMaxDDDim = 128;
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define MSC_HIP(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return ::msc::fail(MSC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                            \
+  } while (0)
+
+#define MSC_REQUIRE(cond, ...)                                    \
+  do {                                                            \
+    if (!(cond)) return ::msc::fail(MSC_EINVAL, __VA_ARGS__);     \
+  } while (0)
+
+#define MSC_TRY(expr)                \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != MSC_OK) return _s;     \
+  } while (0)
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- device-visible feature descriptor -------------------------------------
+// One per state feature; lives in a small device array rebuilt when the (view,
+// cols) binding changes.  All tables are struct-of-arrays with row stride kpad
+// (ngroups rounded up to kGroupTile) so that lane l of a wave reads groups
+// 4l..4l+3 of a k-tile with one 16-byte load.
+//
+// Derived score tables (float, filled by the prepare kernels from the raw tables):
+//   bb   rows {s0, s1}                       log p(v=0), log p(v=1)
+//   gp   rows {a, inv_a, c, inv_1pb, s_a}    see family_math.hpp
+//   dd   rows {table[0..dim)}                log p(v = i)
+//   nich rows {mu_hi, mu_lo, c0, c1ln2, c1, c2, g_loo}
+//   niw  tab = {c0, c1, inv_dof, kappa_n, logdet_extra...}[kpad]; wmat = L^-1 [K][d][d]; bvec = [K][d]
+// Raw tables (the reference's own fields, u32 / f32):
+//   bb   u32 {heads, tails}
+//   gp   u32 {count, sum}            f32 {log_prod}
+//   dd   u32 {count_sum, counts[dim]}
+//   nich u32 {count}                 f32 {mean, count_times_variance}
+//   niw  u32 {count}                 f32 group-major {sum_x[d]} then {sum_xxT[d*d]} (see niw_* offsets)
+// Additive tables (the all-reduce payload):
+//   bb   i64 {heads, tails}
+//   gp   i64 {count, sum}            f64 {log_prod}
+//   dd   i64 {counts[dim]}
+//   nich i64 {count}                 f64 {sum_x, sum_xx}
+//   niw  i64 {count}                 f64 group-major {sum_x[d]}, {sum_xxT[d*d]}
+struct FeatDesc {
+  int32_t family;
+  uint32_t dim;
+  int32_t col_type;        // msc_primitive_type of the bound column (value type of the family)
+  uint32_t pad0;
+  const void *col;         // bound dataview column (device), null until bound
+  const uint8_t *mask;     // optional per-element mask column
+  const float *hp;         // device copy of the hp block
+  float *tab;              // derived score table rows
+  uint32_t *raw_u32;
+  float *raw_f32;
+  long long *acc_i64;
+  double *acc_f64;
+  float *niw_w;            // niw only: [K][d][d] whitening matrix (row-major), scaled
+  float *niw_b;            // niw only: [K][d] posterior mean
+};
+
+inline uint32_t tab_rows(int family, uint32_t dim) {
+  switch (family) {
+    case MSC_BB: return 2;
+    case MSC_GP: return 9;   // GP_ROWS in family_math.hpp
+    case MSC_DD: return dim;
+    case MSC_NICH: return 6; // NICH_ROWS
+    case MSC_NIW: return 4;  // NIW_ROWS
+    default: return 0;
+  }
+}
+inline uint32_t raw_u32_rows(int family, uint32_t dim) {
+  switch (family) {
+    case MSC_BB: return 2;
+    case MSC_GP: return 2;
+    case MSC_DD: return 1 + dim;
+    case MSC_NICH: return 1;
+    case MSC_NIW: return 1;
+    default: return 0;
+  }
+}
+// float raw rows with stride kpad (niw's vector fields are handled separately)
+inline uint32_t raw_f32_rows(int family) {
+  switch (family) {
+    case MSC_GP: return 1;
+    case MSC_NICH: return 2;
+    default: return 0;
+  }
+}
+inline uint32_t acc_i64_rows(int family, uint32_t dim) {
+  switch (family) {
+    case MSC_BB: return 2;
+    case MSC_GP: return 2;
+    case MSC_DD: return dim;
+    case MSC_NICH: return 1;
+    case MSC_NIW: return 1;
+    default: return 0;
+  }
+}
+inline uint32_t acc_f64_rows(int family) {
+  switch (family) {
+    case MSC_GP: return 1;
+    case MSC_NICH: return 2;
+    default: return 0;
+  }
+}
+inline int value_type_of(int family) {
+  switch (family) {
+    case MSC_BB: return MSC_TYPE_B;
+    case MSC_GP: return MSC_TYPE_U32;
+    case MSC_DD: return MSC_TYPE_I32;
+    case MSC_NICH: return MSC_TYPE_F32;
+    case MSC_NIW: return MSC_TYPE_F32;
+    default: return MSC_TYPE_B;
+  }
+}
+size_t primitive_size(int t);
+
+}  // namespace msc
+
+// ---- opaque objects ---------------------------------------------------------
+struct msc_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+  // pinned, device-mapped mailbox for msc_value_op_single
+  void *mailbox_host = nullptr;
+  void *mailbox_dev = nullptr;
+  size_t mailbox_bytes = 0;
+};
+
+struct msc_dataview {
+  msc_context *ctx = nullptr;
+  uint64_t nrows = 0;
+  std::vector<msc_runtime_type> types;   // per feature, after conversion
+  std::vector<void *> cols;              // device columns
+  std::vector<void *> masks;             // device mask columns or null
+  std::vector<void *> owned;             // allocations to free
+};
+
+struct msc_feature_host {
+  int family = 0;
+  uint32_t dim = 0;
+  std::vector<float> hp;
+  float *hp_dev = nullptr;
+  float *tab = nullptr;
+  uint32_t *raw_u32 = nullptr;
+  float *raw_f32 = nullptr;
+  float *niw_raw = nullptr;     // [K][d + d*d] float
+  float *niw_w = nullptr, *niw_b = nullptr;
+  size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
+  size_t f64_off = 0, f64_len = 0;
+  bool raw_valid = true;        // raw tables hold the truth
+  bool additive_valid = false;  // additive tables are in sync with raw
+  bool derived_valid = false;   // score tables are in sync with raw
+};
+
+struct msc_state {
+  msc_context *ctx = nullptr;
+  uint32_t nfeat = 0, K = 0, kpad = 0;
+  float alpha = 1.f;
+  std::vector<msc_feature_host> feats;
+  long long *red_i64 = nullptr;   // [cnt[kpad] | feature slices]
+  double *red_f64 = nullptr;
+  size_t n_i64 = 0, n_f64 = 0;
+  uint32_t *cnt_u32 = nullptr;    // group sizes (group_manager counts), [kpad]
+  float *logpc = nullptr;         // log pseudocount per group, [kpad] (+ loo variants, see prepare)
+  bool cnt_additive_valid = false;
+  bool crp_valid = false;
+  msc::FeatDesc *desc_dev = nullptr;
+  std::vector<msc::FeatDesc> desc_host;
+  const msc_dataview *bound_view = nullptr;
+  std::vector<uint32_t> bound_cols;
+  std::vector<void *> owned;
+};

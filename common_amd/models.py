@@ -1,0 +1,141 @@
+"""Model descriptors: the Python surface of microscopes/models.pyx:96-290.
+
+Same names (`bb`, `bnb`, `gp`, `nich`, `dd(n)`, `niw(d)`, ...), same accessor
+methods and the same default hyper-parameters; `c_desc()` returns the handle the
+HIP state consumes (family tag + dimension) instead of a `shared_ptr[model]`.
+Descriptors the HIP path does not build yet (`bnb`, `bbnc`, `dm`)
+exist for name/pickle compatibility and raise when asked for a c_desc.
+"""
+import itertools as it
+
+import numpy as np
+
+from . import _lib as L
+
+
+class c_model(object):
+    """What `_base.get()` hands to a state object (microscopes/_models.pyx:16-20)."""
+
+    def __init__(self, family, dim=0):
+        self.family, self.dim = int(family), int(dim)
+
+    def get_runtime_type(self):
+        """(primitive type, count): model::get_runtime_type, distributions.hpp:398-403,497-505."""
+        from .runtime import VALUE_TYPE
+        return VALUE_TYPE[self.family], (self.dim if self.family == L.NIW else 1)
+
+    def __repr__(self):
+        return "c_model(family=%d, dim=%d)" % (self.family, self.dim)
+
+
+class py_model(object):
+    """dtype carrier (microscopes/models.pyx:53-66); the protobuf converters are out of scope."""
+
+    def __init__(self, dtype):
+        self._dtype = np.dtype(dtype)
+
+    def get_np_dtype(self):
+        return self._dtype
+
+
+class model_descriptor(object):
+    def __init__(self, name, py_descriptor, c_descriptor, default_hyperparams, default_hyperpriors,
+                 default_partial_hypergrid):
+        self._name = name
+        self._py_descriptor = py_descriptor
+        self._c_descriptor = c_descriptor
+        self._default_hyperparams = default_hyperparams
+        self._default_hyperpriors = default_hyperpriors
+        self._default_partial_hypergrid = default_partial_hypergrid
+
+    def name(self):
+        return self._name
+
+    def py_desc(self):
+        return self._py_descriptor
+
+    def c_desc(self):
+        if self._c_descriptor is None:
+            raise NotImplementedError("model '%s' has no HIP kernel family yet" % self._name)
+        return self._c_descriptor
+
+    def default_hyperparams(self):
+        return self._default_hyperparams
+
+    def default_hyperpriors(self):
+        return self._default_hyperpriors
+
+    def default_partial_hypergrid(self):
+        return self._default_partial_hypergrid
+
+    # convenience for State(...)
+    @property
+    def family(self):
+        return self.c_desc().family
+
+    @property
+    def dim(self):
+        return self.c_desc().dim
+
+    def _param(self):
+        name = self.name()
+        if name in ("dd", "dm"):
+            return len(self._default_hyperparams["alphas"])
+        if name == "niw":
+            return len(self._default_hyperparams["mu"])
+        return None
+
+    def __reduce__(self):
+        return (_reconstruct_model_descriptor, (self._name, self._param()))
+
+    def __call__(self):
+        return self  # nich() == nich
+
+
+def _reconstruct_model_descriptor(name, param):
+    desc = globals()[name]
+    return desc if param is None else desc(param)
+
+
+def _grid2(k0, k1):
+    pts = np.logspace(-1, 1, num=100)
+    return [{k0: a, k1: b} for a, b in it.product(pts, pts)]
+
+
+def _nich_grid():
+    return [{"mu": m, "sigmasq": s}
+            for m, s in it.product(np.linspace(-2., 2., num=100), np.logspace(-1, 1, num=100))]
+
+
+bb = model_descriptor("bb", py_model(np.bool_), c_model(L.BB), {"alpha": 1., "beta": 1.}, {},
+                      _grid2("alpha", "beta"))
+bnb = model_descriptor("bnb", py_model(np.uint32), None, {"alpha": 1., "beta": 1., "r": 1}, {},
+                       bb._default_partial_hypergrid)
+gp = model_descriptor("gp", py_model(np.uint32), c_model(L.GP), {"alpha": 1., "inv_beta": 1.}, {},
+                      _grid2("alpha", "inv_beta"))
+nich = model_descriptor("nich", py_model(np.float32), c_model(L.NICH),
+                        {"mu": 0., "kappa": 1., "sigmasq": 1., "nu": 1.}, {}, _nich_grid())
+bbnc = model_descriptor("bbnc", py_model(np.bool_), None, bb._default_hyperparams, {},
+                        bb._default_partial_hypergrid)
+noop = model_descriptor("noop", py_model(np.bool_), c_model(L.NOOP), {}, {}, [])
+
+
+def dd(size):
+    if size <= 0:
+        raise ValueError("size must be positive")
+    return model_descriptor("dd", py_model(np.int32), c_model(L.DD, size), {"alphas": [1.] * size}, {}, [])
+
+
+def niw(dim):
+    if dim <= 0:
+        raise ValueError("dim must be positive")
+    return model_descriptor("niw", py_model(np.dtype((np.float32, (dim,)))), c_model(L.NIW, dim),
+                            {"mu": np.array([0.] * dim), "kappa": 1.0, "psi": np.eye(dim),
+                             "nu": float(dim)}, {}, [])
+
+
+def dm(categories):
+    if categories <= 0:
+        raise ValueError("categories must be positive")
+    return model_descriptor("dm", py_model(np.dtype((np.int32, (categories,)))), None,
+                            {"alphas": [1.] * categories}, {}, [])

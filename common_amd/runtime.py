@@ -1,0 +1,367 @@
+"""Host-side objects over the C-ABI: Context, DataView, State.
+
+PyTorch is used here only as the owner of device memory (tensors hold the
+columns, assignment vectors and score matrices) and of the HIP stream; every
+computation is a call into libmicroscopes_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_NP_OF_TYPE = {L.TYPE_B: np.bool_, L.TYPE_I8: np.int8, L.TYPE_U8: np.uint8, L.TYPE_I16: np.int16,
+               L.TYPE_U16: np.uint16, L.TYPE_I32: np.int32, L.TYPE_U32: np.uint32,
+               L.TYPE_I64: np.int64, L.TYPE_U64: np.uint64, L.TYPE_F32: np.float32,
+               L.TYPE_F64: np.float64}
+_TORCH_OF_TYPE = {L.TYPE_B: torch.bool, L.TYPE_I8: torch.int8, L.TYPE_U8: torch.uint8,
+                  L.TYPE_I16: torch.int16, L.TYPE_I32: torch.int32, L.TYPE_I64: torch.int64,
+                  L.TYPE_F32: torch.float32, L.TYPE_F64: torch.float64}
+_TYPE_OF_TORCH = {torch.bool: L.TYPE_B, torch.int8: L.TYPE_I8, torch.uint8: L.TYPE_U8,
+                  torch.int16: L.TYPE_I16, torch.int32: L.TYPE_I32, torch.int64: L.TYPE_I64,
+                  torch.float32: L.TYPE_F32, torch.float64: L.TYPE_F64}
+for _n, _t in (("uint16", L.TYPE_U16), ("uint32", L.TYPE_U32), ("uint64", L.TYPE_U64)):
+    if hasattr(torch, _n):
+        _TYPE_OF_TORCH[getattr(torch, _n)] = _t
+        _TORCH_OF_TYPE[_t] = getattr(torch, _n)
+
+VALUE_TYPE = {L.BB: L.TYPE_B, L.GP: L.TYPE_U32, L.DD: L.TYPE_I32, L.NICH: L.TYPE_F32,
+              L.NIW: L.TYPE_F32, L.NOOP: L.TYPE_B}
+
+
+def type_of_numpy(dt):
+    """numpy scalar dtype -> primitive type (microscopes/common/_dataview.pyx:6-36)."""
+    dt = np.dtype(dt)
+    for t, npt in _NP_OF_TYPE.items():
+        if np.dtype(npt) == dt:
+            return t
+    raise ValueError("Unknown type: %s" % dt)
+
+
+def runtime_types_of(dtype):
+    """structured dtype -> [(primitive type, count)] (_dataview.pyx:27-44)."""
+    dtype = np.dtype(dtype)
+    if len(dtype) == 0:
+        raise ValueError("structural arrays only")
+    out = []
+    for i in range(len(dtype)):
+        ft = dtype[i]
+        if ft.subdtype is None:
+            out.append((type_of_numpy(ft), 1))
+        else:
+            sub, shape = ft.subdtype
+            if len(shape) != 1:
+                raise ValueError("unsupported shape: %s" % (shape,))
+            out.append((type_of_numpy(sub), int(shape[0])))
+    return out
+
+
+class Context(object):
+    """One per process and GPU.  Kernels are enqueued on torch's current stream."""
+
+    def __init__(self, device=0, stream=None):
+        if not torch.cuda.is_available():
+            raise L.MicroscopesHipError(-3, "no GPU visible to torch; common_amd has no CPU path")
+        self.lib = L.load()
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        torch.cuda.init()
+        self.torch_device = torch.device("cuda", self.device)
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._stream = s
+        h = C.c_void_p()
+        L.check(self.lib.msc_context_create(self.device, C.c_void_p(s.cuda_stream), C.byref(h)))
+        self._h = h
+
+    def set_stream(self, stream):
+        self._stream = stream
+        L.check(self.lib.msc_context_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+
+    def synchronize(self):
+        L.check(self.lib.msc_context_synchronize(self._h))
+
+    def build_info(self):
+        return self.lib.msc_build_info().decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.msc_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DataView(object):
+    """Columnar device copy of a packed recarray (replaces recarray numpy_dataview)."""
+
+    def __init__(self, ctx, handle, keepalive=None):
+        self.ctx, self._h, self._keep = ctx, handle, keepalive
+        n, f = C.c_uint64(), C.c_uint32()
+        L.check(ctx.lib.msc_dataview_size(handle, C.byref(n), C.byref(f)))
+        self.nrows, self.nfeatures = n.value, f.value
+
+    @classmethod
+    def from_recarray(cls, ctx, npd, col_types=None):
+        """numpy structured (optionally masked) 1-D array, as recarray/_dataview.pyx:61-92."""
+        if npd is None:
+            raise ValueError("npd is None")
+        if len(npd.shape) != 1:
+            raise ValueError("1D (structural) arrays only")
+        types = runtime_types_of(npd.dtype)
+        if hasattr(npd, "mask"):
+            data = np.ascontiguousarray(npd.data)
+            mask = np.ascontiguousarray(np.ma.getmaskarray(npd))
+            mask = mask.view(np.uint8).reshape(-1)
+        else:
+            data, mask = np.ascontiguousarray(npd), None
+        if data.dtype.itemsize != sum(np.dtype(_NP_OF_TYPE[t]).itemsize * c for t, c in types):
+            data = np.ascontiguousarray(data.astype(np.dtype([("f%d" % i, _NP_OF_TYPE[t], (c,)) if c > 1
+                                                              else ("f%d" % i, _NP_OF_TYPE[t])
+                                                              for i, (t, c) in enumerate(types)])))
+        rt = (L.RuntimeType * len(types))(*[L.RuntimeType(t, c) for t, c in types])
+        ct = None
+        if col_types is not None:
+            ct = (C.c_int32 * len(types))(*[int(t) for t in col_types])
+        h = C.c_void_p()
+        L.check(ctx.lib.msc_dataview_from_records(
+            ctx._h, data.ctypes.data_as(C.c_void_p),
+            mask.ctypes.data_as(C.c_void_p) if mask is not None else None,
+            data.shape[0], rt, len(types), ct, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_tensors(cls, ctx, columns, masks=None):
+        """Adopt device tensors as columns (no copy).  [N] scalars or [N, d] vector features."""
+        cols = []
+        for c in columns:
+            if c.device != ctx.torch_device or not c.is_contiguous():
+                raise ValueError("columns must be contiguous tensors on %s" % ctx.torch_device)
+            cols.append(c)
+        n = cols[0].shape[0]
+        types = []
+        for c in cols:
+            if c.shape[0] != n or c.dim() > 2:
+                raise ValueError("column shapes must be [N] or [N, d] with one N")
+            types.append((_TYPE_OF_TORCH[c.dtype], 1 if c.dim() == 1 else int(c.shape[1])))
+        rt = (L.RuntimeType * len(types))(*[L.RuntimeType(t, k) for t, k in types])
+        ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+        mptr = None
+        if masks is not None:
+            mptr = (C.c_void_p * len(cols))(*[(m.data_ptr() if m is not None else None) for m in masks])
+        h = C.c_void_p()
+        L.check(ctx.lib.msc_dataview_from_device_columns(ctx._h, n, rt, len(types), ptrs, mptr, C.byref(h)))
+        return cls(ctx, h, keepalive=(cols, masks))
+
+    def column_type(self, f):
+        p, t = C.c_void_p(), L.RuntimeType()
+        L.check(self.ctx.lib.msc_dataview_column(self._h, f, C.byref(p), C.byref(t)))
+        return t.type, t.count, p.value
+
+    def column_to_numpy(self, f):
+        """Device column -> numpy (tests / debugging)."""
+        t, cnt, ptr = self.column_type(f)
+        npt = np.dtype(_NP_OF_TYPE[t])
+        nbytes = self.nrows * cnt * npt.itemsize
+        self.ctx.synchronize()
+        if nbytes == 0:
+            return np.zeros((0, cnt) if cnt > 1 else (0,), dtype=npt)
+        buf = _alias_tensor(ptr, nbytes, torch.uint8, self.ctx.torch_device)
+        out = buf.cpu().numpy().view(npt)
+        return out.reshape(self.nrows, cnt) if cnt > 1 else out
+
+    def __len__(self):
+        return self.nrows
+
+    def size(self):
+        return self.nrows
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.msc_dataview_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ss_dtype(family, dim=0):
+    """numpy record of one group's suff-stats as msc_state_set_ss / get_ss exchange it."""
+    if family == L.BB:
+        return np.dtype([("heads", np.uint32), ("tails", np.uint32)])
+    if family == L.GP:
+        return np.dtype([("count", np.uint32), ("sum", np.uint32), ("log_prod", np.float32)])
+    if family == L.DD:
+        return np.dtype([("count_sum", np.uint32), ("counts", np.uint32, (dim,))])
+    if family == L.NICH:
+        return np.dtype([("count", np.uint32), ("mean", np.float32), ("count_times_variance", np.float32)])
+    if family == L.NIW:
+        return np.dtype([("count", np.uint32), ("sum_x", np.float32, (dim,)),
+                         ("sum_xxT", np.float32, (dim, dim))])
+    return np.dtype([("unused", np.uint32)])
+
+
+def pack_hp(family, hp, dim=0):
+    """dict keyed as microscopes/models.pyx:185-290 -> the flat float block of the ABI."""
+    if isinstance(hp, np.ndarray):
+        return np.ascontiguousarray(hp, dtype=np.float32)
+    if family == L.BB:
+        v = [hp["alpha"], hp["beta"]]
+    elif family == L.GP:
+        v = [hp["alpha"], hp["inv_beta"]]
+    elif family == L.DD:
+        v = list(hp["alphas"])
+    elif family == L.NICH:
+        v = [hp["mu"], hp["kappa"], hp["sigmasq"], hp["nu"]]
+    elif family == L.NIW:
+        v = [hp["kappa"], hp["nu"]] + list(np.asarray(hp["mu"]).ravel()) + list(np.asarray(hp["psi"]).ravel())
+    else:
+        v = []
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+
+
+class State(object):
+    """hypers + K groups of suff-stats per feature + CRP counts, resident in HBM."""
+
+    def __init__(self, ctx, features, ngroups):
+        """features: list of (family, dim) or model descriptors with .family/.dim."""
+        self.ctx = ctx
+        feats = []
+        for f in features:
+            if isinstance(f, tuple):
+                feats.append((int(f[0]), int(f[1])))
+            else:
+                feats.append((int(f.family), int(f.dim)))
+        self.features, self.K = feats, int(ngroups)
+        spec = (L.FeatureSpec * len(feats))(*[L.FeatureSpec(a, b) for a, b in feats])
+        h = C.c_void_p()
+        L.check(ctx.lib.msc_state_create(ctx._h, spec, len(feats), self.K, C.byref(h)))
+        self._h = h
+
+    # hypers -----------------------------------------------------------------
+    def set_hp(self, f, hp):
+        fam, dim = self.features[f]
+        a = pack_hp(fam, hp, dim)
+        L.check(self.ctx.lib.msc_state_set_hp(self._h, f, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_hp(self, f):
+        fam, dim = self.features[f]
+        a = np.empty(self.ctx.lib.msc_hp_floats(fam, dim), dtype=np.float32)
+        L.check(self.ctx.lib.msc_state_get_hp(self._h, f, a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    # suff-stats -------------------------------------------------------------
+    def set_ss(self, f, records, first_group=0):
+        fam, dim = self.features[f]
+        r = np.ascontiguousarray(records, dtype=ss_dtype(fam, dim))
+        L.check(self.ctx.lib.msc_state_set_ss(self._h, f, first_group, r.shape[0],
+                                              r.ctypes.data_as(C.c_void_p), r.nbytes))
+
+    def get_ss(self, f, first_group=0, ngroups=None):
+        fam, dim = self.features[f]
+        n = self.K - first_group if ngroups is None else ngroups
+        r = np.zeros(n, dtype=ss_dtype(fam, dim))
+        L.check(self.ctx.lib.msc_state_get_ss(self._h, f, first_group, n, r.ctypes.data_as(C.c_void_p), r.nbytes))
+        return r
+
+    def set_alpha(self, alpha):
+        L.check(self.ctx.lib.msc_state_set_alpha(self._h, float(alpha)))
+
+    def set_group_counts(self, counts):
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        L.check(self.ctx.lib.msc_state_set_group_counts(self._h, c.ctypes.data_as(C.c_void_p), c.size))
+
+    def get_group_counts(self):
+        c = np.zeros(self.K, dtype=np.uint32)
+        L.check(self.ctx.lib.msc_state_get_group_counts(self._h, c.ctypes.data_as(C.c_void_p), c.size))
+        return c
+
+    # hot path ---------------------------------------------------------------
+    def _cols(self, cols):
+        if cols is None:
+            return None
+        return (C.c_uint32 * len(cols))(*[int(c) for c in cols])
+
+    def score_value(self, view, out=None, row0=0, nrows=None, z=None, crp_prior=False, cols=None):
+        """[nrows, K] float32 device tensor of summed score_value (see msc_score_value)."""
+        n = view.nrows - row0 if nrows is None else nrows
+        if out is None:
+            out = torch.empty((n, self.K), dtype=torch.float32, device=self.ctx.torch_device)
+        if out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[0] < n:
+            raise ValueError("out must be a row-major float32 [nrows, >=K] tensor")
+        ld = out.stride(0) if out.dim() == 2 else self.K
+        zp = None
+        if z is not None:
+            if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
+                raise ValueError("z must be a contiguous int32 tensor of nrows entries")
+            zp = C.c_void_p(z.data_ptr())
+        L.check(self.ctx.lib.msc_score_value(self._h, view._h, self._cols(cols), row0, n, zp,
+                                             L.SCORE_CRP_PRIOR if crp_prior else 0,
+                                             C.c_void_p(out.data_ptr()), ld))
+        return out
+
+    def accumulate(self, view, z, row0=0, nrows=None, reset=True, subtract=False, commit=True, cols=None):
+        n = view.nrows - row0 if nrows is None else nrows
+        if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
+            raise ValueError("z must be a contiguous int32 tensor of nrows entries")
+        flags = (L.ACC_RESET if reset else 0) | (L.ACC_SUBTRACT if subtract else 0) | \
+                (0 if commit else L.ACC_NO_COMMIT)
+        L.check(self.ctx.lib.msc_accumulate(self._h, view._h, self._cols(cols), row0, n,
+                                            C.c_void_p(z.data_ptr()), flags))
+
+    def score_data(self, out=None):
+        if out is None:
+            out = torch.empty((len(self.features), self.K), dtype=torch.float32, device=self.ctx.torch_device)
+        L.check(self.ctx.lib.msc_score_data(self._h, C.c_void_p(out.data_ptr())))
+        return out
+
+    def sweep_assign(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
+        n = view.nrows - row0 if nrows is None else nrows
+        if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
+            raise ValueError("z must be a contiguous int32 tensor of nrows entries")
+        L.check(self.ctx.lib.msc_sweep_assign(self._h, view._h, self._cols(cols), row0, n,
+                                              row0 if row_id0 is None else row_id0,
+                                              C.c_void_p(z.data_ptr()), int(seed), int(sweep)))
+
+    # multi-GPU hook ---------------------------------------------------------
+    def reduce_buffers(self):
+        """(int64 tensor, float64 tensor) aliasing the additive tables, for all_reduce(SUM)."""
+        pi, ni, pf, nf = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        L.check(self.ctx.lib.msc_state_reduce_buffers(self._h, C.byref(pi), C.byref(ni), C.byref(pf), C.byref(nf)))
+        return (_alias_tensor(pi.value, ni.value, torch.int64, self.ctx.torch_device),
+                _alias_tensor(pf.value, nf.value, torch.float64, self.ctx.torch_device))
+
+    def commit_reduce(self):
+        L.check(self.ctx.lib.msc_state_commit_reduce(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.msc_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _CudaArrayView(object):
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def _alias_tensor(ptr, n, dtype, device):
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4",
+               torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_CudaArrayView(ptr, n, typestr), device=device)

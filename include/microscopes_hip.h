@@ -1,0 +1,238 @@
+/*
+ * microscopes_hip.h -- C ABI of the MI355X (gfx950) implementation of the
+ * component-model scoring hot path of datamicroscopes/common.
+ *
+ * The reference has no FFI for this path: downstream C++ drives the virtual
+ * microscopes::models::group API one value at a time
+ * (include/microscopes/models/base.hpp:21-37) and Cython only wraps object
+ * lifetimes (microscopes/_models.pyx:16-52).  This header is the boundary a
+ * maintainer binds instead (cgo-free: plain C, pointers and sizes only, no torch
+ * or C++ types); include/microscopes/ holds the C++ plugin surface that sits on
+ * top of it and INTEGRATION.md shows the binding stubs.  Each entry point names
+ * the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns MSC_OK (0) or a negative msc_status; the message of
+ *     the last failure on the calling thread is msc_last_error().  Nothing throws
+ *     across this boundary (reference convention: C++ exceptions,
+ *     distributions.hpp:140,152,178,198 -- the C++ layer above re-throws).
+ *   - "dev" pointers are device (HBM) addresses valid on the context's device;
+ *     "host" pointers are ordinary host memory.  Work is enqueued on the
+ *     context's HIP stream and is asynchronous unless stated otherwise.
+ *   - there is no CPU fallback: without a usable gfx950 device context creation
+ *     fails and nothing else can be called.
+ */
+#ifndef MICROSCOPES_HIP_H
+#define MICROSCOPES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSC_ABI_VERSION 1
+
+typedef enum msc_status {
+  MSC_OK = 0,
+  MSC_EINVAL = -1,       /* bad argument (shape, family, null pointer, ...) */
+  MSC_EHIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
+  MSC_ENODEVICE = -3,    /* no gfx950 device / extension not usable */
+  MSC_EUNSUPPORTED = -4, /* valid request outside what is built (e.g. dd dim > 128) */
+  MSC_ENOMEM = -5
+} msc_status;
+
+/* likelihood families; one kernel family each (distributions.hpp:58-64) */
+typedef enum msc_family {
+  MSC_BB = 0,   /* BetaBernoulli            value bool   (uint8)          */
+  MSC_GP = 1,   /* GammaPoisson             value uint32                  */
+  MSC_DD = 2,   /* DirichletDiscrete<128>   value int32 in [0, dim)       */
+  MSC_NICH = 3, /* NormalInverseChiSq       value float                   */
+  MSC_NIW = 4,  /* NormalInverseWishart<-1> value float[dim]              */
+  MSC_NOOP = 5  /* noop model, models/noop.hpp:13-53 (API-overhead control) */
+} msc_family;
+
+/* primitive types, include/microscopes/common/type_info.h:10-44 (same order) */
+typedef enum msc_primitive_type {
+  MSC_TYPE_B = 0, MSC_TYPE_I8, MSC_TYPE_U8, MSC_TYPE_I16, MSC_TYPE_U16, MSC_TYPE_I32,
+  MSC_TYPE_U32, MSC_TYPE_I64, MSC_TYPE_U64, MSC_TYPE_F32, MSC_TYPE_F64, MSC_TYPE_NELEMS
+} msc_primitive_type;
+
+/* runtime_type{t, n, vec} (runtime_type.hpp:65-141); count == n() */
+typedef struct msc_runtime_type {
+  int32_t type;   /* msc_primitive_type */
+  uint32_t count; /* elements per value: 1 for scalars, n for vector fields */
+} msc_runtime_type;
+
+typedef struct msc_feature_spec {
+  int32_t family; /* msc_family */
+  uint32_t dim;   /* dd: number of categories (<=128); niw: dimension; else 0 */
+} msc_feature_spec;
+
+typedef struct msc_context msc_context;
+typedef struct msc_dataview msc_dataview;
+typedef struct msc_state msc_state;
+
+/* ---- library / context ------------------------------------------------- */
+int msc_abi_version(void);
+const char *msc_last_error(void);
+const char *msc_build_info(void); /* "gfx950 hipcc <ver> ..." */
+
+/* stream: a hipStream_t (may be NULL = the device's null stream). */
+int msc_context_create(int device, void *stream, msc_context **out);
+int msc_context_destroy(msc_context *ctx);
+int msc_context_set_stream(msc_context *ctx, void *stream);
+int msc_context_synchronize(msc_context *ctx);
+
+/* ---- columnar dataview (replaces recarray/dataview.hpp:194-217) -------- */
+/*
+ * Packed row-major records exactly as numpy_dataview hands them over
+ * (microscopes/common/recarray/_dataview.pyx:61-92): n records of
+ * sum(size(types[i])) bytes, no padding, optional mask with one bool per
+ * element (runtime_type.hpp:123-134).  The records are copied to the device
+ * once and transposed there into one contiguous column per feature, converted
+ * with runtime_cast::cast semantics (runtime_type.hpp:145-166) to col_types[i]
+ * (NULL: keep each feature's own primitive type).  Synchronous w.r.t. the host
+ * buffers: they may be freed on return.
+ */
+int msc_dataview_from_records(msc_context *ctx, const void *host_records, const uint8_t *host_mask,
+                              uint64_t nrows, const msc_runtime_type *types, uint32_t ntypes,
+                              const int32_t *col_types, msc_dataview **out);
+/*
+ * Adopt columns that already live in HBM (generated on the device, or a torch
+ * tensor): dev_columns[i] has nrows * types[i].count elements of types[i].type,
+ * row-major for vector features.  dev_masks may be NULL or hold NULL entries;
+ * a non-NULL entry has nrows * count bytes (nonzero = masked).  Borrowed, not
+ * owned: the caller keeps them alive for the life of the view.
+ */
+int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows,
+                                     const msc_runtime_type *types, uint32_t ntypes,
+                                     void *const *dev_columns, void *const *dev_masks,
+                                     msc_dataview **out);
+int msc_dataview_destroy(msc_dataview *view);
+int msc_dataview_size(const msc_dataview *view, uint64_t *nrows, uint32_t *nfeatures);
+int msc_dataview_column(const msc_dataview *view, uint32_t feature, void **dev_ptr,
+                        msc_runtime_type *type);
+
+/* ---- group tables: hypers + K groups of suff-stats per feature --------- */
+/*
+ * One state = the (hypers[f], groups[f][gid]) tables a mixture state object
+ * keeps (entity_state.hpp:25-90): nfeatures component models, ngroups group
+ * slots each, plus the CRP bookkeeping of group_manager (group_manager.hpp:
+ * 218-283: per-group entity counts and alpha).  Group ids are the dense slot
+ * numbers 0..ngroups-1.
+ */
+int msc_state_create(msc_context *ctx, const msc_feature_spec *features, uint32_t nfeatures,
+                     uint32_t ngroups, msc_state **out);
+int msc_state_destroy(msc_state *st);
+int msc_state_shape(const msc_state *st, uint32_t *nfeatures, uint32_t *ngroups);
+
+/*
+ * hypers::set_hp / get_hp / get_hp_mutator (base.hpp:44-47) as flat float
+ * blocks, field order as the reference names them (distributions.hpp:21-56):
+ *   bb {alpha, beta}  gp {alpha, inv_beta}  dd {alphas[dim]}
+ *   nich {mu, kappa, sigmasq, nu}  niw {kappa, nu, mu[dim], psi[dim*dim]}
+ */
+size_t msc_hp_floats(int family, uint32_t dim);
+int msc_state_set_hp(msc_state *st, uint32_t feature, const float *host_hp, size_t nfloats);
+int msc_state_get_hp(const msc_state *st, uint32_t feature, float *host_hp, size_t nfloats);
+
+/*
+ * group::set_ss / get_ss / get_ss_mutator (base.hpp:31-34) as packed host
+ * records, one per group, float fields in float exactly as the reference keeps
+ * them (distributions.hpp:21-56,79-91):
+ *   bb   {u32 heads, u32 tails}
+ *   gp   {u32 count, u32 sum, f32 log_prod}
+ *   dd   {u32 count_sum, u32 counts[dim]}
+ *   nich {u32 count, f32 mean, f32 count_times_variance}
+ *   niw  {u32 count, f32 sum_x[dim], f32 sum_xxT[dim*dim]}
+ * Synchronous.
+ */
+size_t msc_ss_bytes(int family, uint32_t dim);
+int msc_state_set_ss(msc_state *st, uint32_t feature, uint32_t first_group, uint32_t ngroups,
+                     const void *host_records, size_t nbytes);
+int msc_state_get_ss(msc_state *st, uint32_t feature, uint32_t first_group, uint32_t ngroups,
+                     void *host_records, size_t nbytes);
+
+/* group_manager: alpha (get_hp_mutator("alpha"), group_manager.hpp:124-130) and counts */
+int msc_state_set_alpha(msc_state *st, float alpha);
+int msc_state_set_group_counts(msc_state *st, const uint32_t *host_counts, uint32_t ngroups);
+int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, uint32_t ngroups);
+
+/* ---- the hot path ------------------------------------------------------ */
+#define MSC_SCORE_CRP_PRIOR 0x1u /* add log(pseudocount(gid)), group_manager.hpp:274-283 */
+
+/*
+ * score_value for nrows rows x all groups x all features of the state:
+ *   out[(r) * ld_out + k] = sum_f groups[f][k].score_value(hypers[f], row(row0+r)[cols[f]])
+ * i.e. the K x D inner loop of entity_based_state_object::inplace_score_value
+ * (entity_state.hpp:69-72) for a block of rows at once.
+ * cols[f] = dataview column feeding state feature f (NULL: identity).
+ * z_dev (nullable, int32[nrows] indexed from row0): leave-one-out -- row r is
+ * scored against group z[r] with itself removed (remove_value before
+ * score_value); z < 0 means unassigned.
+ * out_dev: float[nrows * ld_out], ld_out >= ngroups.
+ */
+int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                    uint64_t nrows, const int32_t *z_dev, uint32_t flags, float *out_dev,
+                    uint64_t ld_out);
+
+#define MSC_ACC_RESET 0x1u    /* zero the tables first (then: suff-stats := f(z)) */
+#define MSC_ACC_SUBTRACT 0x2u /* remove_value instead of add_value */
+#define MSC_ACC_NO_COMMIT 0x4u /* leave the sums in the reduce buffer (all-reduce follows) */
+
+/*
+ * Bulk add_value / remove_value (base.hpp:25-26 + group_manager.hpp:218-248):
+ * every row r in [row0, row0+nrows) with z[r] >= 0 is added to (removed from)
+ * group z[r] of every feature, and the group counts follow.  Integer fields are
+ * exact; float fields are accumulated in double in additive form and converted
+ * to the reference's fields on commit.
+ */
+int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                   uint64_t nrows, const int32_t *z_dev, uint32_t flags);
+
+/* score_data (base.hpp:28) for every (feature, group): out_dev[f * ngroups + k] */
+int msc_score_data(msc_state *st, float *out_dev);
+
+/*
+ * One synchronous Gibbs assignment sweep over rows [row0, row0+nrows)
+ * (SURVEY 3.2 as a data-parallel schedule): every row is scored leave-one-out
+ * against the tables as they stand, plus the CRP term, and re-drawn with
+ * util::sample_discrete_log (util.hpp:125-156) using the counter-based uniform
+ * Philox4x32-10(key = seed, counter = (global row id, sweep)).  row_id0 is the
+ * global id of row0 (rank offset when rows are sharded).  z_dev is updated in
+ * place; tables are NOT updated (call msc_accumulate with MSC_ACC_RESET next,
+ * then all-reduce).
+ */
+int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                     uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed,
+                     uint64_t sweep);
+
+/* ---- multi-GPU hook ---------------------------------------------------- */
+/*
+ * The additive form of every table, ready for a sum all-reduce across row
+ * shards: *dev_i64 = int64[n_i64] (counts), *dev_f64 = double[n_f64] (float
+ * sums).  After reducing both in place call msc_state_commit_reduce.
+ */
+int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n_i64, void **dev_f64,
+                             size_t *n_f64);
+int msc_state_commit_reduce(msc_state *st);
+
+/* ---- per-value entry (the virtual group API, base.hpp:25-28) ----------- */
+typedef enum msc_value_op {
+  MSC_OP_ADD = 0, MSC_OP_REMOVE = 1, MSC_OP_SCORE_VALUE = 2, MSC_OP_SCORE_DATA = 3
+} msc_value_op;
+/*
+ * One group, one value, evaluated on the device (a batch of one): host_hp and
+ * host_ss as in msc_state_set_hp / set_ss, host_value one value of the family's
+ * type.  ADD/REMOVE rewrite host_ss in place; SCORE_* write *score.  Synchronous;
+ * latency-bound (one launch per call) -- the batched calls above are the fast path.
+ */
+int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, int op, const float *host_hp,
+                        void *host_ss, const void *host_value, float *score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICROSCOPES_HIP_H */

@@ -1,0 +1,148 @@
+"""GPU parity: msc_score_value through the C-ABI against the double twin of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import (TOL, crp_prior_matrix, load_state, make_feature, oracle_scores,
+                               recarray_of, rel_err, state_from_assignment)
+
+pytestmark = pytest.mark.gpu
+
+SINGLE = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0)]
+
+
+def _setup(gpu_ctx, specs, N, K, seed, empty_groups=0):
+    import common_amd
+    rng = np.random.default_rng(seed)
+    feats = [make_feature(fam, N, K, rng, dim) for fam, dim in specs]
+    z = rng.integers(0, K - empty_groups, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    counts = np.bincount(z, minlength=K).astype(np.uint32)
+    st.set_group_counts(counts)
+    return feats, z, fs, view, st, counts
+
+
+@pytest.mark.parametrize("fam,dim", SINGLE)
+@pytest.mark.parametrize("K", [1, 5, 256, 300])
+def test_score_value_single_feature(gpu_ctx, fam, dim, K):
+    N = 777
+    feats, z, fs, view, st, _ = _setup(gpu_ctx, [(fam, dim)], N, K, seed=100 + K + fam)
+    got = st.score_value(view).cpu().numpy()
+    want = oracle_scores(feats, fs)
+    assert got.shape == (N, K)
+    assert rel_err(got, want).max() <= TOL
+
+
+@pytest.mark.parametrize("fam,dim", SINGLE)
+def test_score_value_leave_one_out(gpu_ctx, fam, dim):
+    N, K = 500, 37
+    feats, z, fs, view, st, _ = _setup(gpu_ctx, [(fam, dim)], N, K, seed=7 + fam)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt).cpu().numpy()
+    want = oracle_scores(feats, fs, z=z)
+    assert rel_err(got, want).max() <= TOL
+    # unassigned rows (z = -1) are scored against the untouched groups
+    z2 = z.copy()
+    z2[::3] = -1
+    got2 = st.score_value(view, z=torch.from_numpy(z2).to(gpu_ctx.torch_device)).cpu().numpy()
+    plain = oracle_scores(feats, fs)
+    assert rel_err(got2[::3], plain[::3]).max() <= TOL
+    assert rel_err(got2[1::3], want[1::3]).max() <= TOL
+
+
+def test_score_value_mixed_features_sum_over_columns(gpu_ctx):
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 32), (orc.NICH, 0)] * 3
+    N, K = 600, 300
+    feats, z, fs, view, st, _ = _setup(gpu_ctx, specs, N, K, seed=3)
+    got = st.score_value(view).cpu().numpy()
+    want = oracle_scores(feats, fs)
+    assert rel_err(got, want).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
+@pytest.mark.parametrize("specs", [[(orc.NICH, 0)], [(orc.BB, 0), (orc.NICH, 0), (orc.DD, 7)]])
+def test_crp_prior_and_empty_groups(gpu_ctx, specs):
+    N, K, alpha = 400, 19, 2.5
+    feats, z, fs, view, st, counts = _setup(gpu_ctx, specs, N, K, seed=21, empty_groups=3)
+    # make one group a singleton so that removing its row empties it
+    st.set_alpha(alpha)
+    got = st.score_value(view, crp_prior=True).cpu().numpy()
+    want = oracle_scores(feats, fs) + crp_prior_matrix(counts, alpha)
+    assert rel_err(got, want).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    want = oracle_scores(feats, fs, z=z) + crp_prior_matrix(counts, alpha, z)
+    assert rel_err(got, want).max() <= TOL
+
+
+def test_singleton_group_becomes_empty_under_leave_one_out(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(5)
+    N, K, alpha = 64, 6, 1.5
+    feats = [make_feature(orc.NICH, N, K, rng)]
+    z = rng.integers(0, 3, N).astype(np.int32)
+    z[10] = 4                      # group 4 holds exactly one row; group 3 and 5 are empty
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    load_state(st, fs)
+    counts = np.bincount(z, minlength=K).astype(np.uint32)
+    st.set_group_counts(counts)
+    st.set_alpha(alpha)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    want = oracle_scores(feats, fs, z=z) + crp_prior_matrix(counts, alpha, z)
+    assert rel_err(got, want).max() <= TOL
+    # row 10 sees three empty groups (3, 4, 5), every other row two
+    assert abs((got[10, 3] - oracle_scores(feats, fs, z=z)[10, 3]) - np.log(alpha / 3)) < 1e-5
+
+
+def test_rows_subrange_and_leading_dimension(gpu_ctx):
+    N, K = 1000, 20
+    feats, z, fs, view, st, _ = _setup(gpu_ctx, [(orc.NICH, 0), (orc.BB, 0)], N, K, seed=9)
+    out = torch.full((300, 32), -7.0, dtype=torch.float32, device=gpu_ctx.torch_device)
+    st.score_value(view, out=out, row0=123, nrows=300)
+    got = out.cpu().numpy()
+    want = oracle_scores(feats, fs, rows=slice(123, 423))
+    assert rel_err(got[:, :K], want).max() <= TOL
+    assert np.all(got[:, K:] == -7.0)  # padding of the leading dimension is left alone
+
+
+def test_golden_vectors_through_the_device(gpu_ctx):
+    """the scipy known answers (tests/golden) reproduced by the HIP path itself"""
+    import common_amd
+    from tests.conftest import load_golden
+    for name, fam in (("bb", orc.BB), ("gp", orc.GP), ("dd", orc.DD), ("nich", orc.NICH)):
+        for case in load_golden(name):
+            dim = case.get("dim", 0)
+            st = common_amd.State(gpu_ctx, [(fam, dim)], 1)
+            st.set_hp(0, case["hp"])
+            rec = np.zeros(1, dtype=common_amd.ss_dtype(fam, dim))
+            for k, v in case["ss"].items():
+                rec[k][0] = np.asarray(v)
+            st.set_ss(0, rec)
+            probe = np.asarray(case["probe"]).astype(orc.value_dtype(fam, dim).base)
+            if fam == orc.BB:
+                probe = probe.astype(np.bool_)
+            arr = np.zeros(len(probe), dtype=[("f0", probe.dtype)])
+            arr["f0"] = probe
+            view = common_amd.DataView.from_recarray(gpu_ctx, arr)
+            got = st.score_value(view).cpu().numpy()[:, 0]
+            # the device holds the suff-stats in float (as the reference does): compare with the
+            # twin fed the same float state, and loosely with scipy on the unrounded state
+            F = orc.Family(fam, case["hp"], dim, "f64")
+            ss64 = np.zeros(1, dtype=orc.ss_dtype(fam, dim, "f64"))
+            for k in rec.dtype.names:
+                ss64[k] = rec[k]
+            want = F.score_matrix(ss64, probe.astype(orc.value_dtype(fam, dim).base))[:, 0]
+            assert rel_err(got, want).max() <= TOL, (name, got, want)
+            if not (name == "nich" and abs(case["ss"]["mean"]) > 100):
+                assert rel_err(got, case["score_value"]).max() <= 5e-5, name
+            sd = st.score_data().cpu().numpy()[0, 0]
+            assert rel_err(sd, F.score_data(ss64, 0)) <= TOL

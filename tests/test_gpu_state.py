@@ -1,0 +1,172 @@
+"""GPU parity: bulk add/remove_value (msc_accumulate), score_data, the columnar dataview."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import (TOL, load_state, make_feature, recarray_of, rel_err,
+                               state_from_assignment)
+
+pytestmark = pytest.mark.gpu
+
+SPECS = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0)]
+
+
+def _check_ss(st, fs, int_exact=True):
+    for i, (F, ss64, _) in enumerate(fs):
+        rec = st.get_ss(i)
+        for name in rec.dtype.names:
+            got = rec[name].astype(np.float64)
+            want = np.asarray(ss64[name], dtype=np.float64)
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(got, want), (F.family, name)   # bit-exact integer counts
+            else:
+                assert rel_err(got, want).max() <= TOL, (F.family, name, rel_err(got, want).max())
+
+
+@pytest.mark.parametrize("K", [3, 256, 1000])
+def test_accumulate_matches_sequential_add_value(gpu_ctx, K):
+    import common_amd
+    rng = np.random.default_rng(K)
+    N = 20000
+    feats = [make_feature(f, N, K, rng, d) for f, d in SPECS]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[::17] = -1   # unassigned rows are skipped (group_manager.hpp:218-233 never sees them)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, SPECS, K)
+    for i, f in enumerate(feats):
+        st.set_hp(i, f["hp"])
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    fs = []
+    for f in feats:
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        fs.append((F, F.accumulate(K, f["values"], z), None))   # sequential Welford etc. in double
+    _check_ss(st, fs)
+    want_cnt = np.bincount(z[z >= 0], minlength=K)
+    assert np.array_equal(st.get_group_counts(), want_cnt)
+
+
+def test_incremental_add_then_remove_rows(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(4)
+    N, K = 6000, 50
+    feats = [make_feature(f, N, K, rng, d) for f, d in SPECS]
+    z = rng.integers(0, K, N).astype(np.int32)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, SPECS, K)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    # first half, then second half added on top, then second half removed again
+    st.accumulate(view, zt, row0=0, nrows=N // 2, reset=True)
+    st.accumulate(view, zt[N // 2:].contiguous(), row0=N // 2, nrows=N - N // 2, reset=False)
+    full = [(orc.Family(f["family"], f["hp"], f["dim"], "f64"), None, None) for f in feats]
+    fs = [(F, F.accumulate(K, f["values"], z), None) for (F, _, _), f in zip(full, feats)]
+    _check_ss(st, fs)
+    st.accumulate(view, zt[N // 2:].contiguous(), row0=N // 2, nrows=N - N // 2, reset=False, subtract=True)
+    half = [(F, F.accumulate(K, f["values"][:N // 2], z[:N // 2]), None) for (F, _, _), f in zip(full, feats)]
+    _check_ss(st, half)
+    assert np.array_equal(st.get_group_counts(), np.bincount(z[:N // 2], minlength=K))
+
+
+def test_set_ss_then_add_rows_continues_from_host_state(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(12)
+    N, K = 3000, 9
+    feats = [make_feature(orc.NICH, N, K, rng), make_feature(orc.GP, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs_half = state_from_assignment([dict(f, values=f["values"][:N // 2]) for f in feats], K, z[:N // 2])
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.GP, 0)], K)
+    load_state(st, fs_half)
+    st.set_group_counts(np.bincount(z[:N // 2], minlength=K).astype(np.uint32))
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt[N // 2:].contiguous(), row0=N // 2, nrows=N - N // 2, reset=False)
+    for i, f in enumerate(feats):
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        ss = fs_half[i][1].copy()               # the float state the device started from, widened
+        for n in range(N // 2, N):
+            F.add_value(ss, int(z[n]), f["values"][n])
+        rec = st.get_ss(i)
+        for name in rec.dtype.names:
+            got, want = rec[name].astype(np.float64), np.asarray(ss[name], np.float64)
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(got, want)
+            else:
+                assert rel_err(got, want).max() <= 2 * TOL, (name, rel_err(got, want).max())
+    assert np.array_equal(st.get_group_counts(), np.bincount(z, minlength=K))
+
+
+@pytest.mark.parametrize("K", [4, 300])
+def test_score_data_matches_twin(gpu_ctx, K):
+    import common_amd
+    rng = np.random.default_rng(31 + K)
+    N = 5000
+    feats = [make_feature(f, N, K, rng, d) for f, d in SPECS]
+    z = rng.integers(0, max(1, K - 1), N).astype(np.int32)   # last group stays empty
+    fs = state_from_assignment(feats, K, z)
+    st = common_amd.State(gpu_ctx, SPECS, K)
+    load_state(st, fs)
+    got = st.score_data().cpu().numpy()
+    for i, (F, ss64, _) in enumerate(fs):
+        want = F.score_data_all(ss64)
+        assert rel_err(got[i], want).max() <= TOL, (F.family, rel_err(got[i], want).max())
+    assert np.all(got[:, K - 1] == 0.0)   # empty group: marginal likelihood of no data
+
+
+def test_dataview_unpack_is_bit_exact_with_runtime_cast(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(8)
+    N = 1237
+    dt = np.dtype([("b", np.bool_), ("i8", np.int8), ("u16", np.uint16), ("i32", np.int32),
+                   ("u64", np.uint64), ("f32", np.float32), ("f64", np.float64), ("v", np.float32, (3,)),
+                   ("w", np.int16, (2,))])
+    arr = np.zeros(N, dtype=dt)
+    arr["b"] = rng.random(N) < 0.5
+    arr["i8"] = rng.integers(-128, 128, N)
+    arr["u16"] = rng.integers(0, 65536, N)
+    arr["i32"] = rng.integers(-2**31, 2**31, N)
+    arr["u64"] = rng.integers(0, 2**63, N).astype(np.uint64)
+    arr["f32"] = rng.normal(0, 100, N)
+    arr["f64"] = rng.normal(0, 1e6, N)
+    arr["v"] = rng.normal(0, 1, (N, 3))
+    arr["w"] = rng.integers(-3000, 3000, (N, 2))
+    assert arr.dtype.itemsize == 1 + 1 + 2 + 4 + 8 + 4 + 8 + 12 + 4   # packed, no padding
+    view = common_amd.DataView.from_recarray(gpu_ctx, arr)
+    assert view.size() == N and len(view) == N
+    for f, name in enumerate(dt.names):
+        got = view.column_to_numpy(f)
+        np.testing.assert_array_equal(got, arr[name])
+    # conversion at upload: every feature to float32 / int32 with the implicit C++ conversion
+    types = common_amd.runtime_types_of(dt)
+    off, row, _ = orc.offsets_and_size([t for t, _ in types], [c for _, c in types])
+    for target, ttype in ((np.float32, orc.TYPE_F32), (np.int32, orc.TYPE_I32)):
+        v2 = common_amd.DataView.from_recarray(gpu_ctx, arr, col_types=[ttype] * len(types))
+        for f, (t, c) in enumerate(types):
+            if ttype == orc.TYPE_I32 and t in (orc.TYPE_F32, orc.TYPE_F64, orc.TYPE_U64):
+                continue   # out-of-range float->int conversions are undefined in C++ too
+            got = v2.column_to_numpy(f).reshape(N, c)
+            for e in range(c):
+                want = orc.unpack_column(arr, row, int(off[f]), e, t, ttype, N)
+                np.testing.assert_array_equal(got[:, e], want)
+
+
+def test_masked_recarray_keeps_mask_columns(gpu_ctx):
+    import common_amd
+    from tests.conftest import load_golden
+    case = load_golden("reference_fixtures")["recarray_masked"]
+    x = np.ma.masked_array(np.array([tuple(case["rows"][0])], dtype=[("f%d" % i, np.bool_) for i in range(5)]),
+                           mask=[tuple(case["mask"][0])])
+    view = common_amd.DataView.from_recarray(gpu_ctx, x)
+    for f in range(5):
+        assert bool(view.column_to_numpy(f)[0]) == case["rows"][0][f]
+
+
+def test_wrong_column_type_is_refused(gpu_ctx):
+    import common_amd
+    arr = np.zeros(10, dtype=[("f0", np.float64)])
+    view = common_amd.DataView.from_recarray(gpu_ctx, arr)
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], 4)
+    with pytest.raises(common_amd.MicroscopesHipError):
+        st.score_value(view)
+    view32 = common_amd.DataView.from_recarray(gpu_ctx, arr, col_types=[orc.TYPE_F32])
+    assert st.score_value(view32).shape == (10, 4)
