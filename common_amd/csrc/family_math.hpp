@@ -81,48 +81,48 @@ MSC_DEV double dd_loo(float alpha_v, uint32_t count_v, double alpha_sum, uint32_
 }
 
 // ============================ Gamma-Poisson =================================
-// Posterior a = alpha + sum, b = inv_beta + count.  Negative-binomial predictive
-//   score(v) = lgamma(a+v) - lgamma(a) - lgamma(v+1) + a ln b - (a+v) ln(1+b)
-// evaluated for z = a + v >= 4 through Stirling's series on lgamma(z) only:
-//   score(v) = (a-1/2) log1p(v/a) + v (ln(z/(1+b)) - 1) + S(z) - Sa + C - lgamma(v+1)
-//   Sa = lgamma(a) - [(a-1/2) ln a - a + ln(2pi)/2]   exact residual, taken in double
-//   C  = a ln(b/(1+b))
-// and through four exact per-group constants for v in {0,1,2,3}.
-// tab rows: 0 a, 1 inv_a, 2 a-1/2, 3 inv_1pb, 4 C - Sa, 5..8?  -> see GP_ROWS below
-enum { GP_A = 0, GP_INV_A = 1, GP_AMH = 2, GP_INV1PB = 3, GP_CMS = 4, GP_T0 = 5 /* T0..T3 */, GP_ROWS = 9 };
+// Posterior a = alpha + sum, b = inv_beta + count; negative-binomial predictive
+//   score(v) = lgamma(a+v) - lgamma(a) - lgamma(v+1) + a ln b - (a+v) ln(1+b).
+// The terms are ~v ln a each while the result is O(1..v): float cannot subtract
+// them to 1e-6.  So:
+//  * v < GP_TABLE: an exact per-group table built in double by the prepare step
+//    (rows GP_T0 + v) -- one 16-byte load per (row, 4 groups), no arithmetic.
+//  * v >= GP_TABLE (rare for count data): Loader's saddle-point form (C. Loader
+//    2000, the form R's dnbinom uses), in which every term is of the size of the
+//    result, evaluated in double:
+//      score = -log1p(v/a)/2 - ln(2 pi v)/2 - e(v) + S(a+v) - e(a) - a g(-d/a) - v g(d/v)
+//      d = (a - v b)/(1+b),  g(y) = y - log1p(y),  e(y) = stirlerr(y) = lgamma(y+1) - Stirling(y)
+//    e(a) comes from the prepare step (hi/lo floats), e(v) and ln(2 pi v) once per row.
+enum { GP_NSE_HI = 0, GP_NSE_LO = 1, GP_T0 = 2, GP_TABLE = 32, GP_ROWS = GP_T0 + GP_TABLE };
 
 MSC_DEV double gp_score_exact(double a, double b, double v) {
   return lgamma(a + v) - lgamma(a) - lgamma(v + 1.0) + a * log(b) - (a + v) * log1p(b);
 }
-MSC_DEV void gp_prepare(const float *hp, uint32_t count, uint32_t sum, float *out /*GP_ROWS*/) {
-  const double a = (double)hp[0] + (double)sum, b = (double)hp[1] + (double)count;
-  const double sa = lgamma(a) - ((a - 0.5) * log(a) - a + kHalfLog2Pi);
-  const double c = a * (log(b) - log1p(b));
-  out[GP_A] = (float)a;
-  out[GP_INV_A] = (float)(1.0 / a);
-  out[GP_AMH] = (float)(a - 0.5);
-  out[GP_INV1PB] = (float)(1.0 / (1.0 + b));
-  out[GP_CMS] = (float)(c - sa);
-  for (int v = 0; v < 4; v++) out[GP_T0 + v] = (float)gp_score_exact(a, b, (double)v);
+MSC_DEV void gp_prepare_consts(const float *hp, uint32_t count, uint32_t sum, float &nse_hi, float &nse_lo) {
+  const double a = (double)hp[0] + (double)sum;
+  (void)count;
+  const double stirlerr_a = lgamma(a + 1.0) - ((a + 0.5) * log(a) - a + kHalfLog2Pi);
+  split_hi_lo(-stirlerr_a, nse_hi, nse_lo);
 }
-MSC_DEV float stirling_tail(float rz) {  // S(z) = 1/(12z) - 1/(360z^3) + 1/(1260z^5) - 1/(1680z^7)
-  const float r2 = rz * rz;
-  float p = fmaf(r2, -1.0f / 1680.0f, 1.0f / 1260.0f);
-  p = fmaf(r2, p, -1.0f / 360.0f);
-  p = fmaf(r2, p, 1.0f / 12.0f);
-  return p * rz;
+MSC_DEV float gp_prepare_table(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
+  return (float)gp_score_exact((double)hp[0] + (double)sum, (double)hp[1] + (double)count, (double)v);
 }
-// v >= 4 (so z >= 4); vf = (float)v, neg_lgv1 = -lgamma(v+1) (per row)
-MSC_DEV float gp_eval_large(float vf, float neg_lgv1, float a, float inv_a, float amh, float inv1pb,
-                            float cms) {
-  const float l1 = log1p_acc(vf * inv_a);
-  const float z = a + vf;
-  const float lw = hw_log2(z * inv1pb) * kLn2f;
-  const float s = stirling_tail(hw_rcp(z));
-  float acc = cms + neg_lgv1;
-  acc = fmaf(amh, l1, acc);
-  acc = fmaf(vf, lw - 1.0f, acc);
-  return acc + s;
+MSC_DEV double stirling_tail(double z) {  // S(z) = 1/(12z) - 1/(360z^3) + 1/(1260z^5) - 1/(1680z^7), z >= 32
+  const double r = 1.0 / z, r2 = r * r;
+  return r * (1.0 / 12.0 - r2 * (1.0 / 360.0 - r2 * (1.0 / 1260.0 - r2 * (1.0 / 1680.0))));
+}
+// per-row constant of the large-count path: -ln(2 pi v)/2 - stirlerr(v)
+MSC_DEV double gp_row_const(uint32_t v) {
+  const double x = (double)v;
+  const double stirlerr_v = lgamma(x + 1.0) - ((x + 0.5) * log(x) - x + kHalfLog2Pi);
+  return -0.5 * log(2.0 * kPi * x) - stirlerr_v;
+}
+MSC_DEV float gp_eval_large(double v, double rowc, double a, double b, double nse_a) {
+  const double q = 1.0 / (1.0 + b);
+  const double d = (a - v * b) * q;
+  const double u = -d / a, w = d / v;
+  return (float)(rowc + nse_a - 0.5 * log1p(v / a) + stirling_tail(a + v) - a * (u - log1p(u)) -
+                 v * (w - log1p(w)));
 }
 MSC_DEV double gp_loo(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
   const double a = (double)hp[0] + (double)sum - (double)v, b = (double)hp[1] + (double)count - 1.0;

@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       fd.tab[kpad + k] = s1;
     } break;
     case MSC_GP: {
-      float o[GP_ROWS];
-      gp_prepare(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], o);
-#pragma unroll
-      for (int i = 0; i < GP_ROWS; i++) fd.tab[(size_t)i * kpad + k] = o[i];
+      const uint32_t cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
+      gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
+      for (uint32_t v = 0; v < GP_TABLE; v++)
+        fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
     } break;
     case MSC_DD: {
       double asum = 0;
@@ -270,24 +270,34 @@ __global__ __launch_bounds__(256) void k_score_mixed(const FeatDesc *__restrict_
           }
         } break;
         case MSC_GP: {
-          const float4 a = ld4(tab + (size_t)GP_A * kpad), ia = ld4(tab + (size_t)GP_INV_A * kpad),
-                       amh = ld4(tab + (size_t)GP_AMH * kpad), i1b = ld4(tab + (size_t)GP_INV1PB * kpad),
-                       cms = ld4(tab + (size_t)GP_CMS * kpad);
           const uint32_t v = has_row ? reinterpret_cast<const uint32_t *>(fd.col)[myrow] : 0u;
-          const float nlg = -(float)lgamma((double)v + 1.0);
           if (LOO && gz >= 0) own += (float)gp_loo(fd.hp, fd.raw_u32[gz], fd.raw_u32[kpad + gz], v);
+          // wave-uniform: does any row of the block need the large-count path?
+          const bool any_large = __builtin_amdgcn_ballot_w64(v >= (uint32_t)GP_TABLE) != 0ull;
+          double ga[4], gb[4], gn[4], rowc = 0.0;
+          if (any_large) {
+            const double al = fd.hp[0], ib = fd.hp[1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              gb[j] = ib + (double)fd.raw_u32[kb + j];                      // row 0: count
+              ga[j] = al + (double)fd.raw_u32[(size_t)kpad + kb + j];      // row 1: sum
+              gn[j] = (double)tab[(size_t)GP_NSE_HI * kpad + j] + (double)tab[(size_t)GP_NSE_LO * kpad + j];
+            }
+            if (v >= (uint32_t)GP_TABLE) rowc = gp_row_const(v);
+          }
 #pragma unroll
           for (int r = 0; r < R; r++) {
             const uint32_t vr = (uint32_t)lane_bcast((int)v, r);
             float4 s;
-            if (vr < 4u) {
+            if (vr < (uint32_t)GP_TABLE) {
               s = ld4(tab + (size_t)(GP_T0 + vr) * kpad);
             } else {
-              const float vf = (float)vr, nl = lane_bcast(nlg, r);
-              s.x = gp_eval_large(vf, nl, a.x, ia.x, amh.x, i1b.x, cms.x);
-              s.y = gp_eval_large(vf, nl, a.y, ia.y, amh.y, i1b.y, cms.y);
-              s.z = gp_eval_large(vf, nl, a.z, ia.z, amh.z, i1b.z, cms.z);
-              s.w = gp_eval_large(vf, nl, a.w, ia.w, amh.w, i1b.w, cms.w);
+              const double vd = (double)vr;
+              const double rc = __hiloint2double(lane_bcast(__double2hiint(rowc), r), lane_bcast(__double2loint(rowc), r));
+              s.x = gp_eval_large(vd, rc, ga[0], gb[0], gn[0]);
+              s.y = gp_eval_large(vd, rc, ga[1], gb[1], gn[1]);
+              s.z = gp_eval_large(vd, rc, ga[2], gb[2], gn[2]);
+              s.w = gp_eval_large(vd, rc, ga[3], gb[3], gn[3]);
             }
             acc[r].x += s.x; acc[r].y += s.y; acc[r].z += s.z; acc[r].w += s.w;
           }

@@ -88,7 +88,7 @@ struct FeatDesc {
 inline uint32_t tab_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
-    case MSC_GP: return 9;   // GP_ROWS in family_math.hpp
+    case MSC_GP: return 2 + 32;   // GP_ROWS in family_math.hpp
     case MSC_DD: return dim;
     case MSC_NICH: return 6; // NICH_ROWS
     case MSC_NIW: return 4;  // NIW_ROWS

@@ -54,6 +54,27 @@ def test_score_value_leave_one_out(gpu_ctx, fam, dim):
     assert rel_err(got2[1::3], want[1::3]).max() <= TOL
 
 
+def test_gp_large_counts_take_the_saddle_point_path(gpu_ctx):
+    """counts >= 32 leave the exact table (family_math.hpp GP_TABLE) for Loader's form"""
+    import common_amd
+    rng = np.random.default_rng(77)
+    N, K = 900, 40
+    z = rng.integers(0, K - 2, N).astype(np.int32)
+    lam = np.concatenate([rng.gamma(2.0, 2.0, K // 2), rng.uniform(20, 3000, K - K // 2)])
+    vals = rng.poisson(lam[z]).astype(np.uint32)
+    vals[:8] = [0, 31, 32, 33, 1000, 65535, 1 << 20, 5]
+    feats = [dict(family=orc.GP, dim=0, hp=dict(alpha=0.7, inv_beta=0.3), values=vals, np_dtype=np.uint32)]
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.GP, 0)], K)
+    load_state(st, fs)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
 def test_score_value_mixed_features_sum_over_columns(gpu_ctx):
     specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 32), (orc.NICH, 0)] * 3
     N, K = 600, 300
