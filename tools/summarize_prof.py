@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (gpurun_out/prof/...) into the small summaries kept under profiles/.
+
+usage: tools/summarize_prof.py <round-tag> <kernel-trace-dir> [<pmc-dir> ...]
+Writes profiles/<tag>_kernel_stats.csv (name truncated to 90 chars, our msc:: kernels first) and
+profiles/<tag>_pmc.json with per-kernel per-launch averages of every counter found, plus the HBM
+traffic per launch derived as MI355X_MICROARCH.md prescribes for gfx950:
+  read bytes  = 2 * FETCH_SIZE * 1024   (FETCH_SIZE reads exactly half of a coalesced stream)
+  write bytes = WRITE_SIZE * 1024
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("void ", "")
+    cut = name.find("(")
+    if cut > 0:
+        name = name[:cut]
+    return name[:90]
+
+
+def main():
+    tag, ktdir = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(ktdir, "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        rows.sort(key=lambda r: (not r["Name"].startswith(("msc::", "void msc::")), -float(r["TotalDurationNs"])))
+        with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
+                            r["Percentage"], r["MinNs"], r["MaxNs"], "%.1f" % float(r["StdDev"])])
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sys.argv[3:]:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "msc::" in r["Kernel_Name"]:
+                    pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summary = {}
+    for k, counters in pmc.items():
+        e = {c: {"launches": len(v), "avg": sum(v) / len(v)} for c, v in counters.items()}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            rd, wr = 2.0 * e["FETCH_SIZE"]["avg"] * 1024.0, e["WRITE_SIZE"]["avg"] * 1024.0
+            e["hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr}
+        summary[k] = e
+    if summary:
+        with open(os.path.join(out, tag + "_pmc.json"), "w") as fh:
+            json.dump(summary, fh, indent=1, sort_keys=True)
+            fh.write("\n")
+    print("wrote", sorted(os.listdir(out)))
+
+
+if __name__ == "__main__":
+    main()
