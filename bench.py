@@ -152,18 +152,14 @@ def main():
 def run_sweep(a, ctx, st, view, z, world, rank, dist, sync_all):
     """rows/sec of one synchronous Gibbs sweep incl. the suff-stat all-reduce."""
     import torch
+    import common_amd
     N = view.nrows
     zs = z.clone()
     st.set_alpha(1.0)
-    red_i, red_f = st.reduce_buffers()
+    drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=rank * N)
 
     def one(sweep_idx):
-        st.sweep_assign(view, zs, seed=73, sweep=sweep_idx, row_id0=rank * N)
-        st.accumulate(view, zs, reset=True, commit=False)
-        if world > 1:
-            dist.all_reduce(red_i)
-            dist.all_reduce(red_f)
-        st.commit_reduce()
+        drv.sweep(seed=73, sweep_index=sweep_idx)
 
     steps = max(1, min(a.steps, 20))
     for i in range(2):

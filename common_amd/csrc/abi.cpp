@@ -643,9 +643,46 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
   return MSC_OK;
 }
 
-extern "C" int msc_sweep_assign(msc_state *, const msc_dataview *, const uint32_t *, uint64_t, uint64_t,
-                                uint64_t, int32_t *, uint64_t, uint64_t) {
-  return fail(MSC_EUNSUPPORTED, "msc_sweep_assign: not built in this revision");
+extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *cols,
+                                uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z_dev,
+                                uint64_t seed, uint64_t sweep) {
+  MSC_REQUIRE(st && z_dev, "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(bind_view(st, view, cols, row0, nrows));
+  if (nrows == 0) return MSC_OK;
+  MSC_TRY(ensure_derived(st));
+  MSC_TRY(ensure_crp(st));
+  hipStream_t s = st->ctx->stream;
+  const int cus = st->ctx->num_cus;
+  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  int rc = -2;
+  if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
+  if (rc == -2) rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
+  if (rc == -2) {
+    // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
+    const uint64_t ld = st->kpad;
+    uint64_t chunk = (64ull << 20) / (ld * sizeof(float));   // 64 MiB of scores stays in the Infinity Cache
+    if (chunk == 0) chunk = 1;
+    if (chunk > nrows) chunk = nrows;
+    if (st->scratch_floats < chunk * ld) {
+      void *p = nullptr;
+      MSC_HIP(hipMalloc(&p, chunk * ld * sizeof(float)));
+      st->owned.push_back(p);
+      st->scratch = static_cast<float *>(p);
+      st->scratch_floats = chunk * ld;
+    }
+    for (uint64_t r = 0; r < nrows; r += chunk) {
+      const uint64_t n = std::min<uint64_t>(chunk, nrows - r);
+      if (launch_score(s, cus, false, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0 + r, n, z_dev + r,
+                       st->logpc, st->scratch, ld))
+        return fail(MSC_EHIP, "score kernel launch failed");
+      if (launch_sample_rows(s, cus, st->scratch, ld, st->K, n, row_id0 + r, z_dev + r, seed, sweep))
+        return fail(MSC_EHIP, "k_sample_rows launch failed");
+    }
+    rc = 0;
+  }
+  if (rc) return fail(MSC_EHIP, "sweep kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return MSC_OK;
 }
 
 extern "C" int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n_i64, void **dev_f64,

@@ -1,0 +1,268 @@
+// kernels_sweep.hip -- the fused Gibbs assignment step (SURVEY 3.2 as one
+// data-parallel pass): per row, leave-one-out scores against every group + the CRP
+// term, then util::sample_discrete_log (util.hpp:125-156) -- without ever writing
+// the [N, K] score matrix.  A wave owns the row; scores stay in registers; the
+// max / sum / prefix over groups are wavefront reductions.
+//
+//   k_sweep_nich1<G>  one NICH feature, K <= 64*G: every per-group constant of the
+//                     whole table lives in VGPRs (lane l owns groups G*l .. G*l+G-1),
+//                     rows stream through; no LDS, no HBM traffic besides x, z.
+//   k_sweep_mixed<R>  any feature list, K <= 256: the score_block of the batched
+//                     kernel, sampled from registers.
+//   k_sample_rows     fallback for larger tables: samples rows of a score chunk that
+//                     msc_score_value (leave-one-out + prior) wrote to scratch.
+#include "family_math.hpp"
+#include "launchers.hpp"
+#include "score_block.hpp"
+
+namespace msc {
+
+// ---- Philox-4x32-10 (Salmon et al. SC'11): uniform of (seed, sweep, global row) ----
+MSC_DEV float philox_uniform01(uint64_t seed, uint64_t sweep, uint64_t row) {
+  uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = (uint32_t)sweep, c3 = (uint32_t)(sweep >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- wavefront primitives (64 lanes) ----------------------------------------------
+MSC_DEV float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+MSC_DEV float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// Inverse-CDF draw over K groups laid out G per lane in k order (lane l: k = G*l + j).
+// s[j] = -inf for k >= K.  Mirrors scores_to_probs + sample_discrete: subtract the max,
+// exponentiate, and return the first k whose running sum reaches dart * total; K-1 if
+// rounding lets the dart fall off the end (util.hpp:155).
+template <int G>
+MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_t K) {
+  float m = s[0];
+#pragma unroll
+  for (int j = 1; j < G; j++) m = fmaxf(m, s[j]);
+  m = wave_max(m);
+  float p[G], sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    p[j] = __builtin_amdgcn_exp2f((s[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
+    sum += p[j];
+  }
+  const float incl = wave_incl_scan(sum, lane);
+  const float total = lane_bcast(incl, 63);
+  const float dart = u01 * total;
+  float c = incl - sum;
+  int idx = -1;
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    c += p[j];
+    if (idx < 0 && c >= dart && (uint32_t)(G * lane + j) < K) idx = G * lane + j;
+  }
+  const unsigned long long hit = __builtin_amdgcn_ballot_w64(idx >= 0);
+  if (hit == 0ull) return (int)K - 1;
+  return lane_bcast(idx, (int)__builtin_ctzll(hit));
+}
+
+// ---------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict__ feats, uint32_t K,
+                                                      uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                      uint64_t row_id0, int32_t *__restrict__ z,
+                                                      const float *__restrict__ crp, uint64_t seed,
+                                                      uint64_t sweep) {
+  const FeatDesc fd = feats[0];
+  const int lane = threadIdx.x & 63;
+  const uint32_t kb = (uint32_t)(G * lane);
+  float mh[G], ml[G], c0[G], c1l[G], c1[G], c2[G], lc[G];
+#pragma unroll
+  for (int j = 0; j < G; j += 4) {
+    const uint32_t k = kb + j;           // kpad is a multiple of 256 >= 64*G only when K allows; guard loads
+    const bool in = k < kpad;
+    const float4 a = in ? ld4(fd.tab + (size_t)NICH_MU_HI * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 b = in ? ld4(fd.tab + (size_t)NICH_MU_LO * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 c = in ? ld4(fd.tab + (size_t)NICH_C0 * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 d = in ? ld4(fd.tab + (size_t)NICH_C1LN2 * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 e = in ? ld4(fd.tab + (size_t)NICH_C1 * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 f = in ? ld4(fd.tab + (size_t)NICH_C2 * kpad + k) : make_float4(0, 0, 0, 0);
+    const float4 g = in ? ld4(crp + k) : make_float4(0, 0, 0, 0);
+    mh[j] = a.x; mh[j + 1] = a.y; mh[j + 2] = a.z; mh[j + 3] = a.w;
+    ml[j] = b.x; ml[j + 1] = b.y; ml[j + 2] = b.z; ml[j + 3] = b.w;
+    c0[j] = c.x; c0[j + 1] = c.y; c0[j + 2] = c.z; c0[j + 3] = c.w;
+    c1l[j] = d.x; c1l[j + 1] = d.y; c1l[j + 2] = d.z; c1l[j + 3] = d.w;
+    c1[j] = e.x; c1[j + 1] = e.y; c1[j + 2] = e.z; c1[j + 3] = e.w;
+    c2[j] = f.x; c2[j + 1] = f.y; c2[j + 2] = f.z; c2[j + 3] = f.w;
+    lc[j] = g.x; lc[j + 1] = g.y; lc[j + 2] = g.z; lc[j + 3] = g.w;
+  }
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
+  const uint64_t nchunks = (nrows + 63) / 64;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
+    const uint64_t rb = chunk * 64;
+    const int nr = (int)((nrows - rb) < 64 ? (nrows - rb) : 64);
+    const bool has_row = lane < nr;
+    const float xv = has_row ? xcol[rb + lane] : 0.0f;
+    const int gz = has_row ? z[rb + lane] : -1;
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    float sloo = 0.f, erow = le0;
+    if (gz >= 0) {
+      const float lm1 = crp[kpad + gz];
+      const bool single = __builtin_isinf(lm1);
+      erow = single ? le1 : le0;
+      sloo = (float)nich_loo(fd.hp, fd.raw_u32[gz], fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv) +
+             (single ? le1 : lm1);
+    }
+    int znew = gz;
+    for (int r = 0; r < nr; r++) {
+      const float x = lane_bcast(xv, r), e = lane_bcast(erow, r), sl = lane_bcast(sloo, r);
+      const int g = lane_bcast(gz, r);
+      float s[G];
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        const float prior = __builtin_isinf(lc[j]) ? e : lc[j];
+        float v = nich_eval(x, mh[j], ml[j], c0[j], c1l[j], c1[j], c2[j]) + prior;
+        if ((int)(kb + j) == g) v = sl;
+        if (kb + j >= K) v = -INFINITY;
+        s[j] = v;
+      }
+      const int pick = sample_from_scores<G>(s, lane_bcast(u01, r), lane, K);
+      if (lane == r) znew = pick;
+    }
+    if (has_row) z[rb + lane] = znew;
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_sweep_mixed(const FeatDesc *__restrict__ feats, int nfeat,
+                                                      uint32_t K, uint32_t kpad, uint64_t row0,
+                                                      uint64_t nrows, uint64_t row_id0,
+                                                      int32_t *__restrict__ z,
+                                                      const float *__restrict__ crp, uint64_t seed,
+                                                      uint64_t sweep) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t kb = lane * 4;            // single k-tile: K <= 256
+  const float4 logcnt = ld4(crp + kb);
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const uint64_t nblocks = (nrows + R - 1) / R;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
+    const uint64_t rb = blk * R;
+    const int nr = (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    float4 acc[R];
+    int gz;
+    float own;
+    score_block<R, true, true>(feats, nfeat, kpad, kb, lane, row0, rb, nr, z, crp, logcnt, le0, le1, acc, gz, own);
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    int znew = gz;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float4 s4 = acc[r];
+      const int g = lane_bcast(gz, r);
+      if (g >= 0) replace_own(s4, kb, g, lane_bcast(own, r));
+      float s[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (kb + j >= K) s[j] = -INFINITY;
+      const int pick = sample_from_scores<4>(s, lane_bcast(u01, r), lane, K);
+      if (lane == r) znew = pick;
+    }
+    if (lane < nr) z[rb + lane] = znew;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fallback: one wave per row of a materialised [nrows, ld] score chunk; lane l owns the
+// contiguous slice [l*per, (l+1)*per) of the K groups, per = ceil(K/64).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_rows(const float *__restrict__ scores, uint64_t ld,
+                                                      uint32_t K, uint64_t nrows, uint64_t row_id0,
+                                                      int32_t *__restrict__ z, uint64_t seed,
+                                                      uint64_t sweep) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const uint32_t per = (K + 63) / 64;
+  const uint32_t k_lo = lane * per, k_hi = (k_lo + per < K) ? k_lo + per : K;
+  for (uint64_t row = wave_id; row < nrows; row += nwaves) {
+    const float *s = scores + row * ld;
+    float m = -INFINITY;
+    for (uint32_t k = k_lo; k < k_hi; k++) m = fmaxf(m, s[k]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (uint32_t k = k_lo; k < k_hi; k++) sum += __builtin_amdgcn_exp2f((s[k] - m) * 1.44269504088896340736f);
+    const float incl = wave_incl_scan(sum, lane);
+    const float dart = philox_uniform01(seed, sweep, row_id0 + row) * lane_bcast(incl, 63);
+    float c = incl - sum;
+    int idx = -1;
+    for (uint32_t k = k_lo; k < k_hi; k++) {
+      c += __builtin_amdgcn_exp2f((s[k] - m) * 1.44269504088896340736f);
+      if (idx < 0 && c >= dart) idx = (int)k;
+    }
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(idx >= 0);
+    const int pick = hit ? lane_bcast(idx, (int)__builtin_ctzll(hit)) : (int)K - 1;
+    if (lane == 0) z[row] = pick;
+  }
+}
+
+// ---------------------------------------------------------------------------
+static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int waves_per_cu_cap) {
+  uint64_t gx = (work_items_per_wave_chunk + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * waves_per_cu_cap / 4;
+  if (gx > cap) gx = cap;
+  return gx ? gx : 1;
+}
+
+int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
+                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+                       const float *crp, uint64_t seed, uint64_t sweep) {
+  const uint64_t gx = grid_for((nrows + 63) / 64, num_cus, 16);
+  const dim3 grid((unsigned)gx), block(256);
+  if (K <= 256)
+    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+  else if (K <= 512)
+    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+  else if (K <= 1024)
+    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+  else
+    return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+                       const float *crp, uint64_t seed, uint64_t sweep) {
+  if (K > 256) return -2;
+  constexpr int R = 16;
+  const uint64_t gx = grid_for((nrows + R - 1) / R, num_cus, 16);
+  hipLaunchKernelGGL(k_sweep_mixed<R>, dim3((unsigned)gx), dim3(256), 0, stream, feats_dev, nfeat, K, kpad,
+                     row0, nrows, row_id0, z, crp, seed, sweep);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
+                       uint64_t nrows, uint64_t row_id0, int32_t *z, uint64_t seed, uint64_t sweep) {
+  const uint64_t gx = grid_for(nrows, num_cus, 32);
+  hipLaunchKernelGGL(k_sample_rows, dim3((unsigned)gx), dim3(256), 0, stream, scores, ld, K, nrows, row_id0,
+                     z, seed, sweep);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace msc

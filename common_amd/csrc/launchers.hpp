@@ -22,6 +22,16 @@ int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *fe
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *crp, float *out, uint64_t ld);
 
+// kernels_sweep.hip  (return -2: shape not covered by this kernel)
+int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
+                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+                       const float *crp, uint64_t seed, uint64_t sweep);
+int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+                       const float *crp, uint64_t seed, uint64_t sweep);
+int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
+                       uint64_t nrows, uint64_t row_id0, int32_t *z, uint64_t seed, uint64_t sweep);
+
 // kernels_state.hip
 int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
                       const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,

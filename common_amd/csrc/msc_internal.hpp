@@ -198,4 +198,6 @@ struct msc_state {
   const msc_dataview *bound_view = nullptr;
   std::vector<uint32_t> bound_cols;
   std::vector<void *> owned;
+  float *scratch = nullptr;       // score chunk for the generic sweep path
+  size_t scratch_floats = 0;
 };

@@ -1,0 +1,47 @@
+"""Row-sharded multi-GPU driver: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm), rows block-sharded, group tables replicated.
+
+The scoring pass has no collective.  A Gibbs sweep has exactly one exchange: the sum all-reduce
+of the additive suff-stat tables (int64 counts -> bit-exact, float64 sums) between sweeps; the
+payload is K * O(10) * 8 bytes, i.e. latency-bound, so it is issued as two plain all-reduces (one
+per dtype) and not bucketed or overlapped.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(nrows, world, rank):
+    """Contiguous block partition: (first global row, number of rows) of `rank`."""
+    base, rem = divmod(int(nrows), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)
+
+
+def allreduce_tables(red_i64, red_f64, group=None):
+    """In-place SUM of the additive tables across ranks (no-op when not distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if red_i64.numel():
+        dist.all_reduce(red_i64, op=dist.ReduceOp.SUM, group=group)
+    if red_f64.numel():
+        dist.all_reduce(red_f64, op=dist.ReduceOp.SUM, group=group)
+
+
+class ShardedSweep(object):
+    """state + this rank's shard of the rows; sweep() = assign -> accumulate -> all-reduce -> commit."""
+
+    def __init__(self, state, view, z, first_global_row, group=None):
+        self.state, self.view, self.z = state, view, z
+        self.row_id0 = int(first_global_row)
+        self.group = group
+        self.red_i64, self.red_f64 = state.reduce_buffers()
+
+    def rebuild_tables(self):
+        """suff-stats of the global assignment: local accumulate, sum across ranks, commit."""
+        self.state.accumulate(self.view, self.z, reset=True, commit=False)
+        allreduce_tables(self.red_i64, self.red_f64, self.group)
+        self.state.commit_reduce()
+
+    def sweep(self, seed, sweep_index):
+        self.state.sweep_assign(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
+        self.rebuild_tables()

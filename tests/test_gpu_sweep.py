@@ -1,0 +1,147 @@
+"""GPU parity: the fused Gibbs assignment sweep against the oracle's synchronous sweep."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import load_state, make_feature, recarray_of, state_from_assignment
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpu_ctx, specs, N, K, seed, sweep_idx, alpha=1.3, empty=2, row_id0=0):
+    import common_amd
+    rng = np.random.default_rng(seed)
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, max(1, K - empty), N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(alpha)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx, row_id0=row_id0)
+    got = zt.cpu().numpy()
+    # the oracle draws with uniform01(seed, sweep, global row): shift rows by row_id0 via a wrapper
+    feats_o = [(F, ss64, f["values"]) for f, (F, ss64, _) in zip(feats, fs)]
+    want, scores = orc.sweep(feats_o, K, alpha, z, seed, sweep_idx, "f64", want_scores=True) \
+        if row_id0 == 0 else (None, None)
+    return got, want, scores, z
+
+
+def _check_agreement(got, want, scores, seed, sweep_idx, min_agree):
+    agree = (got == want).mean()
+    assert agree >= min_agree, agree
+    # a disagreement may only be a dart landing within rounding of a CDF step
+    for n in np.nonzero(got != want)[0]:
+        p = orc.scores_to_probs(scores[n])
+        cdf = np.cumsum(p)
+        u = orc.uniform01(seed, sweep_idx, int(n))
+        lo, hi = sorted((int(got[n]), int(want[n])))
+        assert abs(cdf[lo] - u) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, (n, lo, hi, cdf[lo], u)
+
+
+@pytest.mark.parametrize("K", [7, 256, 300, 512, 1000])
+def test_sweep_single_nich_feature_matches_oracle(gpu_ctx, K):
+    got, want, scores, _ = _run(gpu_ctx, [(orc.NICH, 0)], 3000, K, seed=11 + K, sweep_idx=3)
+    _check_agreement(got, want, scores, 11 + K, 3, 0.998)
+
+
+def test_sweep_mixed_features_matches_oracle(gpu_ctx):
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 9), (orc.NICH, 0), (orc.NICH, 0)]
+    got, want, scores, _ = _run(gpu_ctx, specs, 2500, 120, seed=5, sweep_idx=0)
+    _check_agreement(got, want, scores, 5, 0, 0.998)
+
+
+def test_sweep_generic_path_for_wide_tables(gpu_ctx):
+    specs = [(orc.BB, 0), (orc.NICH, 0)]
+    got, want, scores, _ = _run(gpu_ctx, specs, 1500, 700, seed=9, sweep_idx=1)   # K > 256, 2 features
+    _check_agreement(got, want, scores, 9, 1, 0.998)
+    # K > 1024 with ~900 empty groups: ~900 CDF steps of mass 2.5e-4 each, so a float dart lands
+    # within rounding (few 1e-6) of a step for ~0.5% of rows; _check_agreement verifies each one
+    got, want, scores, _ = _run(gpu_ctx, [(orc.NICH, 0)], 800, 1500, seed=10, sweep_idx=1)
+    _check_agreement(got, want, scores, 10, 1, 0.99)
+
+
+def test_sweep_is_a_function_of_seed_sweep_and_global_row(gpu_ctx):
+    a, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
+    b, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
+    c, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=5)
+    assert np.array_equal(a, b)
+    assert (a != c).mean() > 0.01
+
+
+def test_sharded_rows_draw_the_same_assignments_as_the_whole(gpu_ctx):
+    """rows [lo, hi) swept as a shard with row_id0 = lo reproduce the unsharded sweep"""
+    import common_amd
+    rng = np.random.default_rng(2)
+    N, K = 4000, 100
+    feats = [make_feature(orc.NICH, N, K, rng), make_feature(orc.BB, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.BB, 0)], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    whole = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, whole, seed=8, sweep=2)
+    parts = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=8, sweep=2, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
+
+
+def test_sweep_then_rebuild_tables_gives_suffstats_of_new_assignment(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(14)
+    N, K = 5000, 33
+    feats = [make_feature(orc.NICH, N, K, rng), make_feature(orc.GP, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.GP, 0)], K)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    drv = common_amd.dist.ShardedSweep(st, view, zt, first_global_row=0)
+    drv.rebuild_tables()
+    for i in range(3):
+        drv.sweep(seed=1, sweep_index=i)
+    znew = zt.cpu().numpy()
+    assert (znew != z).mean() > 0.3          # the chain moved
+    assert np.array_equal(st.get_group_counts(), np.bincount(znew, minlength=K))
+    for i, f in enumerate(feats):
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        want = F.accumulate(K, f["values"], znew)
+        rec = st.get_ss(i)
+        for name in rec.dtype.names:
+            a, b = rec[name].astype(np.float64), np.asarray(want[name], np.float64)
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(a, b)
+            else:
+                assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(1, np.abs(b)))
+
+
+def test_sweep_draws_follow_the_softmax_of_the_scores(gpu_ctx):
+    """statistical check: one row repeated, many independent uniforms -> empirical = softmax"""
+    import common_amd
+    rng = np.random.default_rng(3)
+    K, N = 6, 60000
+    x = np.full(N, 0.3, dtype=np.float32)
+    feats = [dict(family=orc.NICH, dim=0, hp=dict(mu=0., kappa=1., sigmasq=1., nu=1.), values=x, np_dtype=np.float32)]
+    base = [make_feature(orc.NICH, 600, K, rng)]
+    zb = rng.integers(0, K, 600).astype(np.int32)
+    fs = state_from_assignment(base, K, zb)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    load_state(st, fs)
+    counts = np.bincount(zb, minlength=K).astype(np.uint32)
+    st.set_group_counts(counts)
+    zt = torch.full((N,), -1, dtype=torch.int32, device=gpu_ctx.torch_device)   # unassigned rows
+    st.sweep_assign(view, zt, seed=99, sweep=0)
+    emp = np.bincount(zt.cpu().numpy(), minlength=K) / N
+    F, ss64, _ = fs[0]
+    s = F.score_matrix(ss64, x[:1])[0] + np.log(counts)
+    p = np.exp(s - s.max())
+    p /= p.sum()
+    assert np.abs(emp - p).max() < 4 * np.sqrt(0.25 / N) + 1e-3, (emp, p)
