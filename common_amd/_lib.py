@@ -16,6 +16,7 @@ BB, GP, DD, NICH, NIW, NOOP = range(6)
 (TYPE_B, TYPE_I8, TYPE_U8, TYPE_I16, TYPE_U16, TYPE_I32, TYPE_U32, TYPE_I64, TYPE_U64, TYPE_F32,
  TYPE_F64) = range(11)
 SCORE_CRP_PRIOR = 0x1
+SCORE_NIW_F32 = 0x2
 ACC_RESET, ACC_SUBTRACT, ACC_NO_COMMIT = 0x1, 0x2, 0x4
 OP_ADD, OP_REMOVE, OP_SCORE_VALUE, OP_SCORE_DATA = range(4)
 ABI_VERSION = 1

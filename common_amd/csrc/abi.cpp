@@ -305,13 +305,14 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     if (h.family == MSC_DD && (h.dim == 0 || h.dim > kMaxDDDim))
       return fail(MSC_EUNSUPPORTED, "feature %u: dd dim %u outside 1..%u (DirichletDiscrete<128>)", f,
                   h.dim, kMaxDDDim);
-    if (h.family == MSC_NIW)
-      return fail(MSC_EUNSUPPORTED, "feature %u: niw tables are not built in this revision", f);
+    if (h.family == MSC_NIW && (h.dim == 0 || h.dim > 32))
+      return fail(MSC_EUNSUPPORTED, "feature %u: niw dim %u outside 1..32 (one 32x32 MFMA tile)", f, h.dim);
     h.i64_off = n_i64;
     h.i64_len = acc_i64_rows(h.family, h.dim) * kpad;
     n_i64 += h.i64_len;
     h.f64_off = n_f64;
-    h.f64_len = acc_f64_rows(h.family) * kpad;
+    h.f64_len = h.family == MSC_NIW ? (size_t)ngroups * (h.dim + (size_t)h.dim * h.dim)
+                                    : acc_f64_rows(h.family) * kpad;
     n_f64 += h.f64_len;
   }
   st->n_i64 = n_i64;
@@ -329,7 +330,16 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     if ((rc = dev_alloc(st->owned, &h.hp_dev, h.hp.size()))) return bail(rc);
     if ((rc = dev_alloc(st->owned, &h.tab, (size_t)tab_rows(h.family, h.dim) * kpad))) return bail(rc);
     if ((rc = dev_alloc(st->owned, &h.raw_u32, (size_t)raw_u32_rows(h.family, h.dim) * kpad))) return bail(rc);
-    if ((rc = dev_alloc(st->owned, &h.raw_f32, (size_t)raw_f32_rows(h.family) * kpad))) return bail(rc);
+    const size_t nf32 = h.family == MSC_NIW ? (size_t)ngroups * (h.dim + (size_t)h.dim * h.dim)
+                                            : (size_t)raw_f32_rows(h.family) * kpad;
+    if ((rc = dev_alloc(st->owned, &h.raw_f32, nf32))) return bail(rc);
+    if (h.family == MSC_NIW) {
+      if ((rc = dev_alloc(st->owned, &h.niw_w, (size_t)ngroups * 32 * 32))) return bail(rc);
+      if ((rc = dev_alloc(st->owned, &h.niw_b, (size_t)ngroups * 64))) return bail(rc);
+      if ((rc = dev_alloc(st->owned, &h.niw_w64, (size_t)ngroups * 32 * 32))) return bail(rc);
+      if ((rc = dev_alloc(st->owned, &h.niw_mu64, (size_t)ngroups * 32))) return bail(rc);
+      if ((rc = dev_alloc(st->owned, &h.niw_c64, (size_t)ngroups * 8))) return bail(rc);
+    }
     if (!h.hp.empty()) {
       hipError_t e = hipMemcpy(h.hp_dev, h.hp.data(), h.hp.size() * sizeof(float), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(MSC_EHIP, "hp upload failed: %s", hipGetErrorString(e)));
@@ -348,6 +358,11 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     d.raw_f32 = h.raw_f32;
     d.acc_i64 = st->red_i64 + h.i64_off;
     d.acc_f64 = st->red_f64 + h.f64_off;
+    d.niw_w = h.niw_w;
+    d.niw_b = h.niw_b;
+    d.niw_w64 = h.niw_w64;
+    d.niw_mu64 = h.niw_mu64;
+    d.niw_c64 = h.niw_c64;
   }
   st->cnt_additive_valid = true;
   if ((rc = upload_desc(st.get()))) return bail(rc);
@@ -398,12 +413,21 @@ extern "C" int msc_state_get_hp(const msc_state *st, uint32_t feature, float *ho
   return MSC_OK;
 }
 
+static int launch_commit_all(msc_state *st) {
+  if (launch_commit(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->kpad, st->red_i64, st->cnt_u32))
+    return fail(MSC_EHIP, "k_commit launch failed");
+  for (uint32_t f = 0; f < st->nfeat; f++)
+    if (st->feats[f].family == MSC_NIW &&
+        launch_niw_commit(st->ctx->stream, st->desc_dev, f, st->feats[f].dim, st->K, st->kpad, 1))
+      return fail(MSC_EHIP, "k_niw_commit launch failed");
+  return MSC_OK;
+}
+
 static int ensure_raw(msc_state *st) {
   bool any = false;
   for (auto &h : st->feats) any |= !h.raw_valid;
   if (!any) return MSC_OK;
-  if (launch_commit(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->kpad, st->red_i64, st->cnt_u32))
-    return fail(MSC_EHIP, "k_commit launch failed");
+  MSC_TRY(launch_commit_all(st));
   for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = false; }
   st->crp_valid = false;
   return MSC_OK;
@@ -426,6 +450,24 @@ extern "C" int msc_state_set_ss(msc_state *st, uint32_t feature, uint32_t first_
   MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(ensure_raw(st));
+  if (h.family == MSC_NIW) {
+    // record = {u32 count, f32 sum_x[d], f32 sum_xxT[d*d]}; device keeps count as a row and the
+    // float block group-major
+    const size_t nf = h.dim + (size_t)h.dim * h.dim;
+    std::vector<uint32_t> cnt(ngroups);
+    std::vector<float> blk(nf * ngroups);
+    const uint8_t *p = static_cast<const uint8_t *>(host_records);
+    for (uint32_t g = 0; g < ngroups; g++) {
+      std::memcpy(&cnt[g], p + (size_t)g * rec, 4);
+      std::memcpy(&blk[nf * g], p + (size_t)g * rec + 4, 4 * nf);
+    }
+    MSC_HIP(hipMemcpyAsync(h.raw_u32 + first_group, cnt.data(), 4 * (size_t)ngroups, hipMemcpyHostToDevice, st->ctx->stream));
+    MSC_HIP(hipMemcpyAsync(h.raw_f32 + nf * first_group, blk.data(), 4 * nf * ngroups, hipMemcpyHostToDevice, st->ctx->stream));
+    MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+    h.additive_valid = false;
+    h.derived_valid = false;
+    return MSC_OK;
+  }
   uint32_t nu32, nf32;
   record_layout(h.family, h.dim, nu32, nf32);
   // AoS records -> SoA rows
@@ -460,6 +502,20 @@ extern "C" int msc_state_get_ss(msc_state *st, uint32_t feature, uint32_t first_
   MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(ensure_raw(st));
+  if (h.family == MSC_NIW) {
+    const size_t nf = h.dim + (size_t)h.dim * h.dim;
+    std::vector<uint32_t> cnt(ngroups);
+    std::vector<float> blk(nf * ngroups);
+    MSC_HIP(hipMemcpyAsync(cnt.data(), h.raw_u32 + first_group, 4 * (size_t)ngroups, hipMemcpyDeviceToHost, st->ctx->stream));
+    MSC_HIP(hipMemcpyAsync(blk.data(), h.raw_f32 + nf * first_group, 4 * nf * ngroups, hipMemcpyDeviceToHost, st->ctx->stream));
+    MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+    uint8_t *p = static_cast<uint8_t *>(host_records);
+    for (uint32_t g = 0; g < ngroups; g++) {
+      std::memcpy(p + (size_t)g * rec, &cnt[g], 4);
+      std::memcpy(p + (size_t)g * rec + 4, &blk[nf * g], 4 * nf);
+    }
+    return MSC_OK;
+  }
   uint32_t nu32, nf32;
   record_layout(h.family, h.dim, nu32, nf32);
   std::vector<uint32_t> su((size_t)nu32 * ngroups);
@@ -557,6 +613,10 @@ static int ensure_derived(msc_state *st) {
   if (!any) return MSC_OK;
   if (launch_prepare(st->ctx->stream, st->desc_dev, st->nfeat, st->kpad))
     return fail(MSC_EHIP, "k_prepare launch failed");
+  for (uint32_t f = 0; f < st->nfeat; f++)
+    if (st->feats[f].family == MSC_NIW && !st->feats[f].derived_valid &&
+        launch_niw_prepare(st->ctx->stream, st->desc_dev, f, st->feats[f].dim, st->K, st->kpad))
+      return fail(MSC_EHIP, "k_niw_prepare launch failed");
   for (auto &h : st->feats) h.derived_valid = true;
   return MSC_OK;
 }
@@ -573,28 +633,48 @@ static int ensure_crp(msc_state *st) {
 // ---------------------------------------------------------------------------
 // hot path
 // ---------------------------------------------------------------------------
+// scalar families go through one fused kernel (scores summed over features in registers);
+// every niw feature then adds its MFMA pass on top.
+static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
+                     bool niw_f32, float *out_dev, uint64_t ld_out) {
+  hipStream_t s = st->ctx->stream;
+  uint32_t n_niw = 0;
+  for (auto &h : st->feats) n_niw += h.family == MSC_NIW;
+  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  bool written = false;
+  if (n_niw < st->nfeat || crp) {
+    if (launch_score(s, st->ctx->num_cus, nich1, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
+                     z_dev, crp ? st->logpc : nullptr, out_dev, ld_out))
+      return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    written = true;
+  }
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    if (st->feats[f].family != MSC_NIW) continue;
+    if (launch_niw_score(s, st->ctx->num_cus, st->desc_dev, f, st->K, st->kpad, row0, nrows, z_dev, written,
+                         niw_f32, out_dev, ld_out))
+      return fail(MSC_EHIP, "k_score_niw launch failed: %s", hipGetErrorString(hipGetLastError()));
+    written = true;
+  }
+  return MSC_OK;
+}
+
 extern "C" int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *cols,
                                uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags,
                                float *out_dev, uint64_t ld_out) {
   MSC_REQUIRE(st && out_dev, "null argument");
   MSC_REQUIRE(ld_out >= st->K, "ld_out %llu < ngroups %u", (unsigned long long)ld_out, st->K);
-  MSC_REQUIRE((flags & ~MSC_SCORE_CRP_PRIOR) == 0, "unknown flags 0x%x", flags);
+  MSC_REQUIRE((flags & ~(MSC_SCORE_CRP_PRIOR | MSC_SCORE_NIW_F32)) == 0, "unknown flags 0x%x", flags);
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
   if (nrows == 0) return MSC_OK;
   MSC_TRY(ensure_derived(st));
   const bool crp = (flags & MSC_SCORE_CRP_PRIOR) != 0;
   if (crp) MSC_TRY(ensure_crp(st));
-  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
-  if (launch_score(st->ctx->stream, st->ctx->num_cus, nich1, st->desc_dev, (int)st->nfeat, st->K, st->kpad,
-                   row0, nrows, z_dev, crp ? st->logpc : nullptr, out_dev, ld_out))
-    return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-  return MSC_OK;
+  return run_score(st, row0, nrows, z_dev, crp, (flags & MSC_SCORE_NIW_F32) != 0, out_dev, ld_out);
 }
 
 static int commit(msc_state *st) {
-  if (launch_commit(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->kpad, st->red_i64, st->cnt_u32))
-    return fail(MSC_EHIP, "k_commit launch failed");
+  MSC_TRY(launch_commit_all(st));
   for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = false; }
   st->crp_valid = false;
   return MSC_OK;
@@ -613,9 +693,12 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
   } else {
     MSC_TRY(ensure_raw(st));
     for (uint32_t f = 0; f < st->nfeat; f++)
-      if (!st->feats[f].additive_valid)
-        if (launch_lift(s, st->desc_dev + f, 1, st->kpad, st->red_i64, st->cnt_u32, 0))
-          return fail(MSC_EHIP, "k_lift launch failed");
+      if (!st->feats[f].additive_valid) {
+        const int rc = st->feats[f].family == MSC_NIW
+                           ? launch_niw_commit(s, st->desc_dev, f, st->feats[f].dim, st->K, st->kpad, 0)
+                           : launch_lift(s, st->desc_dev + f, 1, st->kpad, st->red_i64, st->cnt_u32, 0);
+        if (rc) return fail(MSC_EHIP, "k_lift launch failed");
+      }
     if (!st->cnt_additive_valid)
       if (launch_lift(s, st->desc_dev, 0, st->kpad, st->red_i64, st->cnt_u32, 1))
         return fail(MSC_EHIP, "k_lift launch failed");
@@ -628,6 +711,11 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
                                      (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->red_i64);
     if (rc == -2) return fail(MSC_EUNSUPPORTED, "accumulate tables for %u groups exceed LDS", st->K);
     if (rc) return fail(MSC_EHIP, "k_accumulate launch failed: %s", hipGetErrorString(hipGetLastError()));
+    for (uint32_t f = 0; f < st->nfeat; f++)
+      if (st->feats[f].family == MSC_NIW &&
+          launch_niw_accumulate(s, st->ctx->num_cus, st->desc_dev, f, st->K, row0, nrows, z_dev,
+                                (flags & MSC_ACC_SUBTRACT) ? -1 : 1))
+        return fail(MSC_EHIP, "k_niw_accumulate launch failed");
   }
   for (auto &h : st->feats) h.raw_valid = false;
   if (!(flags & MSC_ACC_NO_COMMIT)) MSC_TRY(commit(st));
@@ -640,6 +728,15 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
   MSC_TRY(ensure_raw(st));
   if (launch_score_data(st->ctx->stream, st->desc_dev, (int)st->nfeat, st->K, st->kpad, out_dev))
     return fail(MSC_EHIP, "k_score_data launch failed");
+  bool any_niw = false;
+  for (auto &h : st->feats) any_niw |= h.family == MSC_NIW;
+  if (any_niw) {
+    MSC_TRY(ensure_derived(st));   // ln det Psi_n comes from the prepare step
+    for (uint32_t f = 0; f < st->nfeat; f++)
+      if (st->feats[f].family == MSC_NIW &&
+          launch_niw_score_data(st->ctx->stream, st->desc_dev, f, st->K, st->kpad, out_dev))
+        return fail(MSC_EHIP, "k_niw_score_data launch failed");
+  }
   return MSC_OK;
 }
 
@@ -657,7 +754,9 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   int rc = -2;
   if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
-  if (rc == -2) rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
+  bool any_niw = false;
+  for (auto &h : st->feats) any_niw |= h.family == MSC_NIW;
+  if (rc == -2 && !any_niw) rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;
@@ -673,9 +772,7 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
     }
     for (uint64_t r = 0; r < nrows; r += chunk) {
       const uint64_t n = std::min<uint64_t>(chunk, nrows - r);
-      if (launch_score(s, cus, false, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0 + r, n, z_dev + r,
-                       st->logpc, st->scratch, ld))
-        return fail(MSC_EHIP, "score kernel launch failed");
+      MSC_TRY(run_score(st, row0 + r, n, z_dev + r, true, false, st->scratch, ld));
       if (launch_sample_rows(s, cus, st->scratch, ld, st->K, n, row_id0 + r, z_dev + r, seed, sweep))
         return fail(MSC_EHIP, "k_sample_rows launch failed");
     }

@@ -1,0 +1,480 @@
+// kernels_niw.hip -- Normal-Inverse-Wishart (distributions.hpp:87-91,481-509), dim <= 32.
+//
+//   k_niw_prepare   one wave per group: posterior (kappa_n, nu_n, mu_n, Psi_n) in double,
+//                   Cholesky Psi_n = L L^T and L^-1 in LDS, then
+//                     W_k = L^-1 * sqrt(kappa_n / (kappa_n + 1))        (float, [32][32], zero padded)
+//                   so that the multivariate-t predictive is
+//                     score(x) = c0_k - c1_k * log1p(|W_k (x - mu_k)|^2)
+//                   (the reference refactors Sigma for every (row, group) pair).
+//   k_score_niw     the only dense contraction on the path -> fp32 MFMA
+//                   (v_mfma_f32_32x32x2_f32, exact f32 fma chains): per group, A = W_k
+//                   (32 x 32), B = (X_tile - mu_k)^T (32 features x 32 rows); |.|^2 over the
+//                   output rows is an in-register sum + one cross-half shuffle; lane <-> data row.
+//   k_score_niw64   the default: the same contraction on the f64 matrix pipe
+//                   (v_mfma_f64_16x16x4_f64).  In float the score error is c1 * eps(q) with
+//                   c1 >= dim/2, which breaks the 1e-6 gate for small groups at dim 32; the f32
+//                   kernel stays available behind MSC_SCORE_NIW_F32 at twice the matrix rate.
+//   k_niw_accumulate  sum_x, sum_xxT by group (double atomics, 256-B contiguous per instruction)
+//
+// Leave-one-out needs no second factorisation: with u = x - mu_n, t = u^T Psi_n^-1 u,
+// c = kappa_n/(kappa_n-1):  Psi' = Psi_n - c u u^T,  det Psi' = det Psi_n (1 - c t),
+// u^T Psi'^-1 u = t / (1 - c t)  (Sherman-Morrison), x - mu' = c u, hence
+//   score_loo = A_k + B_k * log1p(-C_k q),   q = |W_k u|^2 = t kappa_n/(kappa_n+1),
+//   C_k = (kappa_n+1)/(kappa_n-1),  B_k = (dof-1+d-1)/2,
+//   A_k = lgamma((dof-1+d)/2) - lgamma((dof-1)/2) - (d/2) ln((dof-1) pi)
+//         - logdet(Psi_n)/2 - (d/2) ln(kappa_n/((kappa_n-1)(dof-1)))
+#include "family_math.hpp"
+#include "launchers.hpp"
+#include "score_block.hpp"
+
+namespace msc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { NIW_C0 = 0, NIW_C1 = 1, NIW_A_LOO = 2, NIW_B_LOO = 3, NIW_C_LOO = 4, NIW_LOGDET_HI = 5, NIW_LOGDET_LO = 6,
+       NIW_ROWS = 7 };   // row NIW_ROWS holds the prior's ln det Psi (hi, lo) in its first two slots
+constexpr int kNiwPad = 32;
+
+// hp layout: {kappa, nu, mu[d], psi[d*d]}; raw_f32 per group: {sum_x[d], sum_xxT[d*d]}
+__global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                     uint32_t K, uint32_t kpad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim, k = blockIdx.x;     // k == K: the prior (n = 0), for score_data
+  const int t = threadIdx.x;
+  double *A = reinterpret_cast<double *>(smem);   // [d][d] Psi_n -> L
+  double *Li = A + (size_t)d * d;                 // [d][d] L^-1
+  double *mun = Li + (size_t)d * d;               // [d]
+  const double kappa = fd.hp[0], nu = fd.hp[1];
+  const float *mu = fd.hp + 2, *psi = fd.hp + 2 + d;
+  const bool prior = k >= K;
+  const double n = prior ? 0.0 : (double)fd.raw_u32[k];
+  const float *sx = fd.raw_f32 + (size_t)(prior ? 0 : k) * (d + (size_t)d * d), *sxx = sx + d;
+  const double kn = kappa + n, nun = nu + n;
+  for (uint32_t i = t; i < d; i += 64) mun[i] = (kappa * (double)mu[i] + (prior ? 0.0 : (double)sx[i])) / kn;
+  __syncthreads();
+  for (uint32_t idx = t; idx < d * d; idx += 64) {
+    const uint32_t i = idx / d, j = idx - i * d;
+    A[idx] = (double)psi[idx] + (prior ? 0.0 : (double)sxx[idx]) + kappa * (double)mu[i] * (double)mu[j] -
+             kn * mun[i] * mun[j];
+  }
+  __syncthreads();
+  // right-looking Cholesky, lower triangle
+  double logdet = 0;
+  for (uint32_t j = 0; j < d; j++) {
+    const double ljj = sqrt(A[(size_t)j * d + j]);
+    logdet += 2.0 * log(ljj);
+    __syncthreads();
+    for (uint32_t i = j + 1 + t; i < d; i += 64) A[(size_t)i * d + j] /= ljj;
+    if (t == 0) A[(size_t)j * d + j] = ljj;
+    __syncthreads();
+    const uint32_t m = d - j - 1;
+    for (uint32_t idx = t; idx < m * m; idx += 64) {
+      const uint32_t i = j + 1 + idx / m, c = j + 1 + idx % m;
+      if (c <= i) A[(size_t)i * d + c] -= A[(size_t)i * d + j] * A[(size_t)c * d + j];
+    }
+    __syncthreads();
+  }
+  // L^-1 by columns: lane c solves L y = e_c
+  for (uint32_t c = t; c < d; c += 64) {
+    for (uint32_t i = 0; i < c; i++) Li[(size_t)i * d + c] = 0.0;
+    Li[(size_t)c * d + c] = 1.0 / A[(size_t)c * d + c];
+    for (uint32_t i = c + 1; i < d; i++) {
+      double s = 0;
+      for (uint32_t m = c; m < i; m++) s += A[(size_t)i * d + m] * Li[(size_t)m * d + c];
+      Li[(size_t)i * d + c] = -s / A[(size_t)i * d + i];
+    }
+  }
+  __syncthreads();
+  if (prior) {
+    if (t == 0) fd.tab[(size_t)NIW_ROWS * kpad] = (float)logdet;       // ln det Psi (hi)
+    if (t == 1) fd.tab[(size_t)NIW_ROWS * kpad + 1] = (float)(logdet - (double)(float)logdet);
+    return;
+  }
+  const double scale = sqrt(kn / (kn + 1.0));
+  float *W = fd.niw_w + (size_t)k * kNiwPad * kNiwPad;
+  for (uint32_t idx = t; idx < kNiwPad * kNiwPad; idx += 64) {
+    const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
+    W[idx] = (i < d && j <= i) ? (float)(Li[(size_t)i * d + j] * scale) : 0.0f;
+  }
+  double *W64 = fd.niw_w64 + (size_t)k * kNiwPad * kNiwPad;
+  for (uint32_t idx = t; idx < kNiwPad * kNiwPad; idx += 64) {
+    const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
+    W64[idx] = (i < d && j <= i) ? Li[(size_t)i * d + j] * scale : 0.0;
+  }
+  for (uint32_t i = t; i < kNiwPad; i += 64) fd.niw_mu64[(size_t)k * kNiwPad + i] = i < d ? mun[i] : 0.0;
+  float *B = fd.niw_b + (size_t)k * 2 * kNiwPad;      // mu hi[32] | lo[32]
+  for (uint32_t i = t; i < kNiwPad; i += 64) {
+    float hi = 0.f, lo = 0.f;
+    if (i < d) split_hi_lo(mun[i], hi, lo);
+    B[i] = hi;
+    B[kNiwPad + i] = lo;
+  }
+  if (t == 0) {
+    const double dd = d, dof = nun - dd + 1.0;
+    const double s = (kn + 1.0) / (kn * dof);
+    const double logdet_sigma = logdet + dd * log(s);
+    fd.tab[(size_t)NIW_C0 * kpad + k] =
+        (float)(lgamma(0.5 * (dof + dd)) - lgamma(0.5 * dof) - 0.5 * dd * log(dof * kPi) - 0.5 * logdet_sigma);
+    fd.tab[(size_t)NIW_C1 * kpad + k] = (float)(0.5 * (dof + dd));
+    split_hi_lo(logdet, fd.tab[(size_t)NIW_LOGDET_HI * kpad + k], fd.tab[(size_t)NIW_LOGDET_LO * kpad + k]);
+    double a_loo = 0, b_loo = 0, c_loo = 0;
+    if (n >= 1.0) {
+      const double k1 = kn - 1.0, dof1 = dof - 1.0;
+      a_loo = lgamma(0.5 * (dof1 + dd)) - lgamma(0.5 * dof1) - 0.5 * dd * log(dof1 * kPi) - 0.5 * logdet -
+              0.5 * dd * log(kn / (k1 * dof1));
+      b_loo = 0.5 * (dof1 + dd - 1.0);
+      c_loo = (kn + 1.0) / k1;
+    }
+    fd.tab[(size_t)NIW_A_LOO * kpad + k] = (float)a_loo;
+    fd.tab[(size_t)NIW_B_LOO * kpad + k] = (float)b_loo;
+    fd.tab[(size_t)NIW_C_LOO * kpad + k] = (float)c_loo;
+    double *c64 = fd.niw_c64 + (size_t)k * 8;     // the same constants, unrounded, for k_score_niw64
+    c64[0] = lgamma(0.5 * (dof + dd)) - lgamma(0.5 * dof) - 0.5 * dd * log(dof * kPi) - 0.5 * logdet_sigma;
+    c64[1] = 0.5 * (dof + dd);
+    c64[2] = a_loo; c64[3] = b_loo; c64[4] = c_loo;
+  }
+}
+
+// score_data (distributions niw; special.hpp:13-22 for the multivariate gamma)
+MSC_DEV double lmultigamma(uint32_t d, double a) {
+  double t = 0.25 * (double)(d * (d - 1)) * kLogPi;
+  for (uint32_t j = 1; j <= d; j++) t += lgamma(a + 0.5 * (1.0 - (double)j));
+  return t;
+}
+__global__ __launch_bounds__(256) void k_niw_score_data(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                         uint32_t K, uint32_t kpad, float *__restrict__ out) {
+  const FeatDesc fd = feats[f];
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const double d = fd.dim, kappa = fd.hp[0], nu = fd.hp[1], n = fd.raw_u32[k];
+  const double ld0 = (double)fd.tab[(size_t)NIW_ROWS * kpad] + (double)fd.tab[(size_t)NIW_ROWS * kpad + 1];
+  const double ldn = (double)fd.tab[(size_t)NIW_LOGDET_HI * kpad + k] + (double)fd.tab[(size_t)NIW_LOGDET_LO * kpad + k];
+  const double kn = kappa + n, nun = nu + n;
+  out[(size_t)f * K + k] = n == 0.0 ? 0.0f
+      : (float)(lmultigamma(fd.dim, 0.5 * nun) - lmultigamma(fd.dim, 0.5 * nu) + 0.5 * nu * ld0 -
+                0.5 * nun * ldn + 0.5 * d * log(kappa / kn) - 0.5 * n * d * kLogPi);
+}
+
+// ---------------------------------------------------------------------------
+// score: a wave owns T tiles of 32 rows and walks all groups.
+// MFMA 32x32x2 operand maps (cdna_hip_programming.md section 3): lane l = (r = l & 31, h = l >> 5)
+//   A[i = r][kk = h], B[kk = h][j = r], D[i = (reg&3) + 8 (reg>>2) + 4 h][j = r].
+// The contraction order over the 32 features is free, so step s pairs features
+// (s, 16 + s): lane (r, h) then needs the 16 *contiguous* floats W[r][16h .. 16h+15] and
+// x[row r][16h .. 16h+15] -- four 16-byte loads each, whole 128-B rows per lane pair.
+// ---------------------------------------------------------------------------
+template <int T, bool LOO, bool ACCUM>
+__global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                    uint32_t K, uint32_t kpad, uint64_t row0,
+                                                    uint64_t nrows, const int32_t *__restrict__ z,
+                                                    float *__restrict__ out, uint64_t ld) {
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const uint64_t nblocks = (nrows + 32 * T - 1) / (32 * T);
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
+    const uint64_t rb = blk * 32 * T;
+    float xr[T][16];
+    int gz[T];
+    bool live[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const uint64_t row = rb + 32 * t + r;          // relative to row0
+      live[t] = row < nrows;
+      const float *xp = X + (row0 + (live[t] ? row : 0)) * d + 16 * h;
+      if (d == 32) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 v = live[t] ? ld4(xp + 4 * q) : make_float4(0, 0, 0, 0);
+          xr[t][4 * q] = v.x; xr[t][4 * q + 1] = v.y; xr[t][4 * q + 2] = v.z; xr[t][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; s++) xr[t][s] = (live[t] && (uint32_t)(16 * h + s) < d) ? xp[s] : 0.0f;
+      }
+      gz[t] = (LOO && live[t]) ? z[row] : -1;
+    }
+    float4 pend[T];
+    for (uint32_t k = 0; k < K; k++) {
+      const float *Wk = fd.niw_w + ((size_t)k * kNiwPad + r) * kNiwPad + 16 * h;
+      const float *Bk = fd.niw_b + (size_t)k * 2 * kNiwPad + 16 * h;
+      float w[16], mh[16], ml[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 a = ld4(Wk + 4 * q), b = ld4(Bk + 4 * q), c = ld4(Bk + kNiwPad + 4 * q);
+        w[4 * q] = a.x; w[4 * q + 1] = a.y; w[4 * q + 2] = a.z; w[4 * q + 3] = a.w;
+        mh[4 * q] = b.x; mh[4 * q + 1] = b.y; mh[4 * q + 2] = b.z; mh[4 * q + 3] = b.w;
+        ml[4 * q] = c.x; ml[4 * q + 1] = c.y; ml[4 * q + 2] = c.z; ml[4 * q + 3] = c.w;
+      }
+      const float c0 = fd.tab[(size_t)NIW_C0 * kpad + k], c1 = fd.tab[(size_t)NIW_C1 * kpad + k];
+      float al = 0, bl = 0, cl = 0;
+      if (LOO) {
+        al = fd.tab[(size_t)NIW_A_LOO * kpad + k];
+        bl = fd.tab[(size_t)NIW_B_LOO * kpad + k];
+        cl = fd.tab[(size_t)NIW_C_LOO * kpad + k];
+      }
+      const uint32_t slot = k & 3;
+      const bool mine = (int)((k >> 2) & 1) == h;
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], (xr[t][s] - mh[s]) - ml[s], acc, 0, 0, 0);
+        float qp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) qp = fmaf(acc[i], acc[i], qp);
+        const float q = qp + __shfl_xor(qp, 32, 64);
+        float sc = fmaf(-c1, log1p_acc(q), c0);
+        if (LOO && gz[t] == (int)k) {
+          const float y = fminf(cl * q, 0.99999994f);
+          sc = fmaf(bl, log1p_acc(-y), al);
+        }
+        if (mine) {
+          if (slot == 0) pend[t].x = sc;
+          else if (slot == 1) pend[t].y = sc;
+          else if (slot == 2) pend[t].z = sc;
+          else pend[t].w = sc;
+        }
+      }
+      if ((k & 7) == 7 || k == K - 1) {
+        const uint32_t k0 = (k & ~7u) + 4 * h;       // first group of this lane's float4
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          if (!live[t]) continue;
+          float *p = out + (rb + 32 * t + r) * ld + k0;
+          if (vec_ok && k0 + 3 <= k) {
+            float4 v = pend[t];
+            if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4 *>(p) = v;
+          } else {
+            const float vals[4] = {pend[t].x, pend[t].y, pend[t].z, pend[t].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if (k0 + i <= k) p[i] = ACCUM ? p[i] + vals[i] : vals[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// f64 matrix pipe.  v_mfma_f64_16x16x4_f64 maps (cdna_hip_programming.md section 3): lane
+// l = (c = l & 15, kk = l >> 4): A[i = c][k = kk], B[k = kk][j = c],
+// D[i = kk + 4 reg][j = c], reg in [0,4).  i = whitened component (two 16-blocks for dim 32),
+// j = data row.  Step s of the contraction pairs features (s, 8+s, 16+s, 24+s), so lane
+// (c, kk) needs the 8 contiguous values [8kk, 8kk+8) of its W row and of its x row.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+MSC_DEV double shfl_xor_f64(double v, int mask) {
+  const int hi = __shfl_xor(__double2hiint(v), mask, 64), lo = __shfl_xor(__double2loint(v), mask, 64);
+  return __hiloint2double(hi, lo);
+}
+
+template <int JB, bool LOO, bool ACCUM>
+__global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                      uint32_t K, uint32_t kpad, uint64_t row0,
+                                                      uint64_t nrows, const int32_t *__restrict__ z,
+                                                      float *__restrict__ out, uint64_t ld) {
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim;
+  const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
+  const uint64_t nblocks = (nrows + 16 * JB - 1) / (16 * JB);
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
+    const uint64_t rb = blk * 16 * JB;
+    float xr[JB][8];
+    int gz[JB];
+    bool live[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; jb++) {
+      const uint64_t row = rb + 16 * jb + c;
+      live[jb] = row < nrows;
+      const float *xp = X + (row0 + (live[jb] ? row : 0)) * d + 8 * kk;
+      if (d == 32) {
+        const float4 v0 = live[jb] ? ld4(xp) : make_float4(0, 0, 0, 0);
+        const float4 v1 = live[jb] ? ld4(xp + 4) : make_float4(0, 0, 0, 0);
+        xr[jb][0] = v0.x; xr[jb][1] = v0.y; xr[jb][2] = v0.z; xr[jb][3] = v0.w;
+        xr[jb][4] = v1.x; xr[jb][5] = v1.y; xr[jb][6] = v1.z; xr[jb][7] = v1.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; s++) xr[jb][s] = (live[jb] && (uint32_t)(8 * kk + s) < d) ? xp[s] : 0.0f;
+      }
+      gz[jb] = (LOO && live[jb]) ? z[row] : -1;
+    }
+    float4 pend[JB];
+    for (uint32_t k = 0; k < K; k++) {
+      const double *Wk = fd.niw_w64 + ((size_t)k * kNiwPad + c) * kNiwPad + 8 * kk;
+      const double *Mk = fd.niw_mu64 + (size_t)k * kNiwPad + 8 * kk;
+      double a0[8], a1[8], m[8];
+#pragma unroll
+      for (int s = 0; s < 8; s += 2) {
+        const double2 p0 = *reinterpret_cast<const double2 *>(Wk + s);
+        const double2 p1 = *reinterpret_cast<const double2 *>(Wk + 16 * kNiwPad + s);
+        const double2 pm = *reinterpret_cast<const double2 *>(Mk + s);
+        a0[s] = p0.x; a0[s + 1] = p0.y; a1[s] = p1.x; a1[s + 1] = p1.y; m[s] = pm.x; m[s + 1] = pm.y;
+      }
+      const double *c64 = fd.niw_c64 + (size_t)k * 8;
+      const double c0 = c64[0], c1 = c64[1];
+      double al = 0, bl = 0, cl = 0;
+      if (LOO) { al = c64[2]; bl = c64[3]; cl = c64[4]; }
+      const uint32_t slot = k & 3;
+      const bool mine = (int)((k >> 2) & 3) == kk;
+#pragma unroll
+      for (int jb = 0; jb < JB; jb++) {
+        f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const double u = (double)xr[jb][s] - m[s];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], u, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], u, acc1, 0, 0, 0);
+        }
+        double qp = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) qp = fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
+        qp += shfl_xor_f64(qp, 16);
+        const double q = qp + shfl_xor_f64(qp, 32);
+        double sc = c0 - c1 * log1p(q);
+        if (LOO && gz[jb] == (int)k) sc = al + bl * log1p(-fmin(cl * q, 1.0 - 1e-15));
+        if (mine) {
+          const float scf = (float)sc;
+          if (slot == 0) pend[jb].x = scf;
+          else if (slot == 1) pend[jb].y = scf;
+          else if (slot == 2) pend[jb].z = scf;
+          else pend[jb].w = scf;
+        }
+      }
+      if ((k & 15) == 15 || k == K - 1) {
+        const uint32_t k0 = (k & ~15u) + 4 * kk;      // first group of this lane's float4
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++) {
+          if (!live[jb] || k0 > k) continue;
+          float *p = out + (rb + 16 * jb + c) * ld + k0;
+          if (vec_ok && k0 + 3 <= k) {
+            float4 v = pend[jb];
+            if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4 *>(p) = v;
+          } else {
+            const float vals[4] = {pend[jb].x, pend[jb].y, pend[jb].z, pend[jb].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if (k0 + i <= k) p[i] = ACCUM ? p[i] + vals[i] : vals[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// accumulate: wave per row; lanes sweep the d + d*d additive slots of the row's group
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_niw_accumulate(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                         uint32_t K, uint64_t row0, uint64_t nrows,
+                                                         const int32_t *__restrict__ z, int sign) {
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const size_t stride = d + (size_t)d * d;
+  for (uint64_t n = wave_id; n < nrows; n += nwaves) {
+    const int g = z[n];
+    if (g < 0 || (uint32_t)g >= K) continue;
+    const float *x = X + (row0 + n) * d;
+    double *dst = fd.acc_f64 + (size_t)g * stride;
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[g]), (unsigned long long)(long long)sign);
+    for (uint32_t i = lane; i < d; i += 64) atomicAdd(&dst[i], (double)sign * (double)x[i]);
+    for (uint32_t idx = lane; idx < d * d; idx += 64) {
+      const uint32_t i = idx / d, j = idx - i * d;
+      atomicAdd(&dst[d + idx], (double)sign * (double)x[i] * (double)x[j]);
+    }
+  }
+}
+
+// additive <-> raw for one niw feature (thread per element of the group-major block)
+__global__ __launch_bounds__(256) void k_niw_commit(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                     uint32_t K, uint32_t kpad, int to_raw) {
+  const FeatDesc fd = feats[f];
+  const size_t stride = fd.dim + (size_t)fd.dim * fd.dim, total = (size_t)K * stride;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) {
+    if (to_raw) fd.raw_f32[i] = (float)fd.acc_f64[i];
+    else fd.acc_f64[i] = (double)fd.raw_f32[i];
+  }
+  if (i < kpad) {
+    if (to_raw) fd.raw_u32[i] = (uint32_t)fd.acc_i64[i];
+    else fd.acc_i64[i] = fd.raw_u32[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+int launch_niw_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
+                       uint32_t kpad) {
+  const size_t lds = sizeof(double) * (2 * (size_t)dim * dim + dim);
+  hipLaunchKernelGGL(k_niw_prepare, dim3(K + 1), dim3(64), lds, stream, feats_dev, f, K, kpad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                          uint32_t kpad, float *out) {
+  hipLaunchKernelGGL(k_niw_score_data, dim3((K + 255) / 256), dim3(256), 0, stream, feats_dev, f, K, kpad, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <bool LOO, bool ACCUM>
+static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, const FeatDesc *feats_dev,
+                               uint32_t f, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                               const int32_t *z, float *out, uint64_t ld) {
+  constexpr int kRowsPerWave = 64;             // 2 tiles of 32 (f32) or 4 blocks of 16 (f64)
+  const uint64_t nblocks = (nrows + kRowsPerWave - 1) / kRowsPerWave;
+  uint64_t gx = (nblocks + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * 8;
+  if (gx > cap) gx = cap;
+  const dim3 grid((unsigned)(gx ? gx : 1)), block(256);
+  if (f32_fast)
+    hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  else
+    hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+}
+
+int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                     uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
+                     float *out, uint64_t ld) {
+  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign) {
+  uint64_t gx = (nrows + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * 8;
+  if (gx > cap) gx = cap;
+  if (gx == 0) gx = 1;
+  hipLaunchKernelGGL(k_niw_accumulate, dim3((unsigned)gx), dim3(256), 0, stream, feats_dev, f, K, row0, nrows, z, sign);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_niw_commit(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
+                      uint32_t kpad, int to_raw) {
+  size_t total = (size_t)K * (dim + (size_t)dim * dim);
+  if (total < kpad) total = kpad;
+  hipLaunchKernelGGL(k_niw_commit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feats_dev, f, K, kpad, to_raw);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace msc

@@ -32,6 +32,19 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_de
 int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
                        uint64_t nrows, uint64_t row_id0, int32_t *z, uint64_t seed, uint64_t sweep);
 
+// kernels_niw.hip
+int launch_niw_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
+                       uint32_t kpad);
+int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                          uint32_t kpad, float *out);
+int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                     uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
+                     float *out, uint64_t ld);
+int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign);
+int launch_niw_commit(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
+                      uint32_t kpad, int to_raw);
+
 // kernels_state.hip
 int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
                       const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,

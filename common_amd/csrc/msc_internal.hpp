@@ -82,7 +82,10 @@ struct FeatDesc {
   long long *acc_i64;
   double *acc_f64;
   float *niw_w;            // niw only: [K][d][d] whitening matrix (row-major), scaled
-  float *niw_b;            // niw only: [K][d] posterior mean
+  float *niw_b;            // niw only: [K][2][32] posterior mean, hi | lo floats
+  double *niw_w64;         // niw only: the same whitening matrix, unrounded
+  double *niw_mu64;        // niw only: [K][32] posterior mean
+  double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
 };
 
 inline uint32_t tab_rows(int family, uint32_t dim) {
@@ -91,7 +94,7 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
     case MSC_GP: return 2 + 32;   // GP_ROWS in family_math.hpp
     case MSC_DD: return dim;
     case MSC_NICH: return 6; // NICH_ROWS
-    case MSC_NIW: return 4;  // NIW_ROWS
+    case MSC_NIW: return 8;  // NIW_ROWS + 1 (kernels_niw.hip)
     default: return 0;
   }
 }
@@ -174,6 +177,7 @@ struct msc_feature_host {
   float *raw_f32 = nullptr;
   float *niw_raw = nullptr;     // [K][d + d*d] float
   float *niw_w = nullptr, *niw_b = nullptr;
+  double *niw_w64 = nullptr, *niw_mu64 = nullptr, *niw_c64 = nullptr;
   size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
   size_t f64_off = 0, f64_len = 0;
   bool raw_valid = true;        // raw tables hold the truth

@@ -289,7 +289,8 @@ class State(object):
             return None
         return (C.c_uint32 * len(cols))(*[int(c) for c in cols])
 
-    def score_value(self, view, out=None, row0=0, nrows=None, z=None, crp_prior=False, cols=None):
+    def score_value(self, view, out=None, row0=0, nrows=None, z=None, crp_prior=False, cols=None,
+                    niw_f32=False):
         """[nrows, K] float32 device tensor of summed score_value (see msc_score_value)."""
         n = view.nrows - row0 if nrows is None else nrows
         if out is None:
@@ -303,7 +304,8 @@ class State(object):
                 raise ValueError("z must be a contiguous int32 tensor of nrows entries")
             zp = C.c_void_p(z.data_ptr())
         L.check(self.ctx.lib.msc_score_value(self._h, view._h, self._cols(cols), row0, n, zp,
-                                             L.SCORE_CRP_PRIOR if crp_prior else 0,
+                                             (L.SCORE_CRP_PRIOR if crp_prior else 0) |
+                                             (L.SCORE_NIW_F32 if niw_f32 else 0),
                                              C.c_void_p(out.data_ptr()), ld))
         return out
 

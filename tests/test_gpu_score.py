@@ -9,7 +9,7 @@ from tests.gpu_helpers import (TOL, crp_prior_matrix, load_state, make_feature, 
 
 pytestmark = pytest.mark.gpu
 
-SINGLE = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0)]
+SINGLE = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0), (orc.NIW, 3), (orc.NIW, 32)]
 
 
 def _setup(gpu_ctx, specs, N, K, seed, empty_groups=0):
@@ -73,6 +73,27 @@ def test_gp_large_counts_take_the_saddle_point_path(gpu_ctx):
     zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
     got = st.score_value(view, z=zt).cpu().numpy()
     assert rel_err(got, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
+def test_niw_mixed_with_scalar_families_and_leave_one_out(gpu_ctx):
+    specs = [(orc.NICH, 0), (orc.NIW, 5), (orc.BB, 0), (orc.NIW, 32)]
+    N, K = 700, 21            # K not a multiple of 8: exercises the tail of the niw store
+    feats, z, fs, view, st, counts = _setup(gpu_ctx, specs, N, K, seed=44, empty_groups=2)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    want = oracle_scores(feats, fs, z=z) + crp_prior_matrix(counts, 1.0, z)
+    assert rel_err(got, want).max() <= TOL
+
+
+def test_niw_f32_matrix_pipe_is_the_documented_looser_variant(gpu_ctx):
+    feats, z, fs, view, st, _ = _setup(gpu_ctx, [(orc.NIW, 32)], 640, 48, seed=61)
+    want = oracle_scores(feats, fs)
+    fast = st.score_value(view, niw_f32=True).cpu().numpy()
+    exact = st.score_value(view).cpu().numpy()
+    assert rel_err(exact, want).max() <= TOL
+    assert rel_err(fast, want).max() <= 2e-5      # MSC_SCORE_NIW_F32: c1 * eps(q), see kernels_niw.hip
 
 
 def test_score_value_mixed_features_sum_over_columns(gpu_ctx):
@@ -139,7 +160,7 @@ def test_golden_vectors_through_the_device(gpu_ctx):
     """the scipy known answers (tests/golden) reproduced by the HIP path itself"""
     import common_amd
     from tests.conftest import load_golden
-    for name, fam in (("bb", orc.BB), ("gp", orc.GP), ("dd", orc.DD), ("nich", orc.NICH)):
+    for name, fam in (("bb", orc.BB), ("gp", orc.GP), ("dd", orc.DD), ("nich", orc.NICH), ("niw", orc.NIW)):
         for case in load_golden(name):
             dim = case.get("dim", 0)
             st = common_amd.State(gpu_ctx, [(fam, dim)], 1)
@@ -151,7 +172,7 @@ def test_golden_vectors_through_the_device(gpu_ctx):
             probe = np.asarray(case["probe"]).astype(orc.value_dtype(fam, dim).base)
             if fam == orc.BB:
                 probe = probe.astype(np.bool_)
-            arr = np.zeros(len(probe), dtype=[("f0", probe.dtype)])
+            arr = np.zeros(len(probe), dtype=[("f0", probe.dtype, probe.shape[1:])])
             arr["f0"] = probe
             view = common_amd.DataView.from_recarray(gpu_ctx, arr)
             got = st.score_value(view).cpu().numpy()[:, 0]

@@ -64,6 +64,11 @@ def test_sweep_generic_path_for_wide_tables(gpu_ctx):
     _check_agreement(got, want, scores, 10, 1, 0.99)
 
 
+def test_sweep_with_niw_feature_takes_the_generic_path(gpu_ctx):
+    got, want, scores, _ = _run(gpu_ctx, [(orc.NIW, 6), (orc.NICH, 0)], 1200, 30, seed=17, sweep_idx=2)
+    _check_agreement(got, want, scores, 17, 2, 0.995)
+
+
 def test_sweep_is_a_function_of_seed_sweep_and_global_row(gpu_ctx):
     a, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
     b, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
