@@ -798,7 +798,48 @@ extern "C" int msc_state_commit_reduce(msc_state *st) {
   return commit(st);
 }
 
-extern "C" int msc_value_op_single(msc_context *, int, uint32_t, int, const float *, void *, const void *,
-                                   float *) {
-  return fail(MSC_EUNSUPPORTED, "msc_value_op_single: not built in this revision");
+extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, int op,
+                                   const float *host_hp, void *host_ss, const void *host_value,
+                                   float *score) {
+  MSC_REQUIRE(ctx, "null context");
+  MSC_REQUIRE(family_ok(family), "unknown family %d", family);
+  MSC_REQUIRE(op >= MSC_OP_ADD && op <= MSC_OP_SCORE_DATA, "unknown op %d", op);
+  if (family == MSC_NOOP) {           // models/noop.hpp:13-27: nothing to compute, nothing to launch
+    if (score) *score = 0.f;
+    return MSC_OK;
+  }
+  MSC_REQUIRE(host_hp && host_ss, "null hp / suff-stats");
+  MSC_REQUIRE(op == MSC_OP_SCORE_DATA || host_value, "null value");
+  MSC_REQUIRE(op <= MSC_OP_REMOVE || score, "null score");
+  if (family == MSC_DD) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dd dim %u outside 1..%u", dim, kMaxDDDim);
+  if (family == MSC_NIW) MSC_REQUIRE(dim >= 1 && dim <= 32, "niw dim %u outside 1..32", dim);
+  const size_t hp_bytes = msc_hp_floats(family, dim) * sizeof(float), ss_bytes = msc_ss_bytes(family, dim);
+  const size_t v_bytes = family == MSC_BB ? 1 : family == MSC_NIW ? 4 * (size_t)dim : 4;
+  auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+  MailboxHeader hd;
+  hd.family = family; hd.dim = (int32_t)dim; hd.op = op; hd.status = 0; hd.score = 0.f;
+  hd.hp_off = 64;
+  hd.ss_off = (uint32_t)up16(hd.hp_off + hp_bytes);
+  hd.value_off = (uint32_t)up16(hd.ss_off + ss_bytes);
+  MSC_REQUIRE(hd.value_off + v_bytes <= ctx->mailbox_bytes, "record too large for the mailbox");
+  if (family == MSC_DD && host_value && op != MSC_OP_SCORE_DATA) {
+    int32_t v;
+    std::memcpy(&v, host_value, 4);
+    MSC_REQUIRE(v >= 0 && (uint32_t)v < dim, "dd value %d outside [0,%u)", v, dim);
+  }
+  MSC_HIP(hipSetDevice(ctx->device));
+  unsigned char *mb = static_cast<unsigned char *>(ctx->mailbox_host);
+  std::memcpy(mb, &hd, sizeof hd);
+  std::memcpy(mb + hd.hp_off, host_hp, hp_bytes);
+  std::memcpy(mb + hd.ss_off, host_ss, ss_bytes);
+  if (host_value) std::memcpy(mb + hd.value_off, host_value, v_bytes);
+  if (launch_value_op(ctx->stream, ctx->mailbox_dev, dim, family))
+    return fail(MSC_EHIP, "k_value_op launch failed: %s", hipGetErrorString(hipGetLastError()));
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  MailboxHeader back;
+  std::memcpy(&back, mb, sizeof back);
+  if (back.status != 1) return fail(MSC_EHIP, "k_value_op did not complete");
+  if (op <= MSC_OP_REMOVE) std::memcpy(host_ss, mb + hd.ss_off, ss_bytes);
+  else *score = back.score;
+  return MSC_OK;
 }

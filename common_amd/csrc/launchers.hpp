@@ -14,6 +14,14 @@ struct UnpackFeat {
   uint32_t pad;
 };
 
+// kernels_single.hip
+struct MailboxHeader {
+  int32_t family, dim, op, status;
+  float score;
+  uint32_t hp_off, ss_off, value_off;
+};
+int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int family);
+
 // kernels_score.hip
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad);
 int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,

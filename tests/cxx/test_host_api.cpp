@@ -1,0 +1,173 @@
+// CPU-only checks of the host side of the plugin surface (no device needed): the runtime
+// type system, the packed-record accessors, the CRP group manager and the wire format.
+// Data of the first three blocks is the data the reference's own tests hold
+// (test/test_dataview.py:31-75, test/cxx/test_group_manager.cpp:22-66).
+#include <microscopes/common/group_manager.hpp>
+#include <microscopes/common/recarray/dataview.hpp>
+#include <microscopes/models/noop.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace microscopes::common;
+using namespace microscopes::common::recarray;
+
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+      std::exit(1);                                                          \
+    }                                                                        \
+  } while (0)
+
+static void test_types_and_offsets() {
+  CHECK(runtime_type(TYPE_B).size() == 1 && runtime_type(TYPE_F64).size() == 8);
+  CHECK(runtime_type(TYPE_F32, 3).size() == 12 && runtime_type(TYPE_F32, 3).vec());
+  CHECK(runtime_type(TYPE_I32) == runtime_type(TYPE_I32) && runtime_type(TYPE_I32) != runtime_type(TYPE_I32, 1));
+  CHECK(runtime_type(TYPE_U16, 4).str() == "TYPE_U16[4]");
+  // (bool, float64) records: offsets 0, 1; rowsize 9; mask row 2
+  std::vector<runtime_type> t1 = {runtime_type(TYPE_B), runtime_type(TYPE_F64)};
+  auto r = runtime_type::GetOffsetsAndSize(t1);
+  CHECK(r.offsets_[0] == 0 && r.offsets_[1] == 1 && r.rowsize_ == 9 && r.maskrowsize_ == 2);
+  // (int32, float32[2]) records: offsets 0, 4; rowsize 12; mask row 3
+  std::vector<runtime_type> t2 = {runtime_type(TYPE_I32), runtime_type(TYPE_F32, 2)};
+  r = runtime_type::GetOffsetsAndSize(t2);
+  CHECK(r.offsets_[1] == 4 && r.rowsize_ == 12 && r.maskrowsize_ == 3);
+  // casts follow the implicit C++ conversion
+  const double dv = -2.75;
+  CHECK(runtime_cast::cast<int32_t>(reinterpret_cast<const uint8_t *>(&dv), TYPE_F64) == -2);
+  CHECK(runtime_cast::cast<bool>(reinterpret_cast<const uint8_t *>(&dv), TYPE_F64) == true);
+  uint8_t u = 200;
+  CHECK(runtime_cast::cast<float>(&u, TYPE_U8) == 200.f);
+  float f = 0;
+  runtime_cast::uncast<int>(reinterpret_cast<uint8_t *>(&f), TYPE_F32, 7);
+  CHECK(f == 7.f);
+}
+
+static void test_row_accessor_over_reference_rows() {
+  // [(False, 32.), (True, 943.), (False, -32.)] with dtype (bool, float64)
+  uint8_t buf[27];
+  const bool b[3] = {false, true, false};
+  const double d[3] = {32., 943., -32.};
+  for (int i = 0; i < 3; i++) {
+    buf[9 * i] = b[i];
+    std::memcpy(buf + 9 * i + 1, &d[i], 8);
+  }
+  std::vector<runtime_type> types = {runtime_type(TYPE_B), runtime_type(TYPE_F64)};
+  row_major_dataview view(buf, nullptr, 3, types);
+  CHECK(view.size() == 3);
+  int acc = 0, rows = 0;
+  for (view.reset(); !view.end(); view.next(), rows++) {
+    row_accessor a = view.get();
+    CHECK(a.nfeatures() == 2 && !a.anymasked());
+    CHECK(a.get().get<bool>(0) == b[view.index()]);
+    acc += a.get().get<int>(0);
+    a.bump();
+    CHECK(a.get().get<double>(0) == d[view.index()]);
+    CHECK(a.get().get<float>(0) == float(d[view.index()]));   // cross-type read
+    a.bump();
+    CHECK(a.end());
+  }
+  CHECK(rows == 3 && acc == 1);
+  // permutation visits every row exactly once
+  rng_t rng(73);
+  view.permute(rng);
+  std::vector<int> seen(3, 0);
+  for (view.reset(); !view.end(); view.next()) seen[view.index()]++;
+  CHECK(seen[0] == 1 && seen[1] == 1 && seen[2] == 1);
+  // masked record: one row of five bools, last three masked
+  const uint8_t vals[5] = {1, 0, 1, 1, 1};
+  const bool mask[5] = {false, false, true, true, true};
+  std::vector<runtime_type> t5(5, runtime_type(TYPE_B));
+  row_accessor m(vals, mask, &t5);
+  for (int i = 0; i < 5; i++, m.bump()) {
+    CHECK(m.ismasked(0) == mask[i]);
+    if (!mask[i]) CHECK(m.get().get<bool>(0) == (vals[i] != 0));
+  }
+  // row_mutator copies with conversion
+  uint8_t out[12] = {0};
+  std::vector<runtime_type> tf = {runtime_type(TYPE_F32), runtime_type(TYPE_F64)};
+  row_mutator mut(out, &tf);
+  row_accessor src(buf + 9, nullptr, &types);   // (True, 943.)
+  mut.set(src); mut.bump(); src.bump();
+  mut.set(src);
+  float f0; double d1;
+  std::memcpy(&f0, out, 4); std::memcpy(&d1, out + 4, 8);
+  CHECK(f0 == 1.f && d1 == 943.);
+}
+
+static void test_group_manager_bookkeeping_and_serialization() {
+  typedef group_manager<size_t> gm;
+  gm g(10);
+  g.get_hp_mutator("alpha").set<float>(2.0f, 0);
+  const ssize_t assignment[10] = {-1, 2, 1, 0, 6, 1, 2, -1, -1, 5};
+  for (int i = 0; i < 7; i++) g.create_group();
+  g.delete_group(3);
+  for (size_t i = 0; i < 10; i++)
+    if (assignment[i] != -1) g.add_value(size_t(assignment[i]), i)++;
+  CHECK(g.ngroups() == 6 && g.nentities() == 10);
+  CHECK(g.groupsize(1) == 2 && g.groupsize(2) == 2 && g.groupsize(4) == 0 && g.groupsize(6) == 1);
+  CHECK(g.empty_groups().size() == 1 && g.empty_groups().count(4) == 1);
+  CHECK(g.pseudocount(1, g.group(1)) == 2.f && g.pseudocount(4, g.group(4)) == 2.f);   // alpha / 1 empty group
+  bool threw = false;
+  try { g.delete_group(1); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  const auto blob = g.serialize([](size_t v) { return std::to_string(v); });
+  gm g1(blob, [](const std::string &s) { return size_t(std::strtoul(s.c_str(), nullptr, 10)); });
+  CHECK(std::fabs(g.get_hp_mutator("alpha").accessor().get<float>(0) - g1.get_hp_mutator("alpha").accessor().get<float>(0)) <= 1e-5f);
+  CHECK(g.assignments() == g1.assignments() && g.ngroups() == g1.ngroups());
+  for (auto gid : g.groups()) CHECK(g.group(gid) == g1.group(gid));
+  // remove / re-add moves the empty set
+  auto rem = g.remove_value(9);   // entity 9 was the only member of group 5
+  CHECK(rem.first == 5 && g.empty_groups().count(5) == 1 && g.assignments()[9] == -1);
+  CHECK(std::fabs(g.pseudocount(5, g.group(5)) - 1.0f) < 1e-6f);   // alpha / 2 empty groups
+  g.add_value(4, 9);
+  CHECK(g.empty_groups().count(4) == 0);
+  // sequential CRP probability
+  gm h(4);
+  h.get_hp_mutator("alpha").set<float>(1.5f, 0);
+  for (int i = 0; i < 2; i++) h.create_group();
+  h.add_value(0, 0); h.add_value(0, 1); h.add_value(1, 2); h.add_value(0, 3);
+  const float want = std::log(1.f / 2.5f) + std::log(1.5f / 3.5f) + std::log(2.f / 4.5f);
+  CHECK(std::fabs(h.score_assignment() - want) < 1e-6f);
+}
+
+static void test_sampling_helpers() {
+  std::vector<float> s = {-1.f, -2.f, -0.5f, -30.f};
+  util::scores_to_probs(s);
+  float tot = 0;
+  for (float p : s) tot += p;
+  CHECK(std::fabs(tot - 1.f) < 1e-6f && s[2] > s[0] && s[0] > s[1] && s[3] < 1e-10f);
+  rng_t rng(5);
+  std::vector<int> hist(4, 0);
+  for (int i = 0; i < 20000; i++) hist[util::sample_discrete(s, rng)]++;
+  CHECK(std::fabs(hist[2] / 20000.0 - s[2]) < 0.02 && hist[3] == 0);
+}
+
+static void test_noop_model_and_wire() {
+  microscopes::models::noop_model m;
+  rng_t rng(1);
+  auto h = m.create_hypers();
+  auto g = h->create_group(rng);
+  const bool v = true;
+  CHECK(g->score_value(*h, value_accessor(&v), rng) == 0.f && g->score_data(*h, rng) == 0.f);
+  CHECK(m.get_runtime_type() == runtime_type(TYPE_B));
+  microscopes::wire::writer w;
+  w.put_float_field(1, 2.5f);
+  w.put_varint_field(2, 300);
+  w.put_bytes_field(3, "abc");
+  const auto fs = microscopes::wire::parse(w.str());
+  CHECK(fs.size() == 3 && fs[0].f32 == 2.5f && fs[1].varint == 300 && fs[2].bytes == "abc");
+}
+
+int main() {
+  test_types_and_offsets();
+  test_row_accessor_over_reference_rows();
+  test_group_manager_bookkeeping_and_serialization();
+  test_sampling_helpers();
+  test_noop_model_and_wire();
+  std::puts("test_host_api ok");
+  return 0;
+}

@@ -1,0 +1,192 @@
+// GPU: the virtual model / hypers / group API (include/microscopes/models) driven exactly
+// as downstream code drives the reference's, checked against the oracle's double twin.
+// Every add / remove / score here is msc_value_op_single -> one launch on the device.
+#include <microscopes/common/recarray/dataview.hpp>
+#include <microscopes/models/distributions.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "../../oracle/msc_oracle.h"
+
+using namespace distributions;
+using namespace microscopes;
+using namespace microscopes::common;
+
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+      std::exit(1);                                                          \
+    }                                                                        \
+  } while (0)
+
+static bool close(double got, double want, double tol = 1e-6) {
+  const bool ok = std::fabs(got - want) <= tol * std::fmax(1.0, std::fabs(want));
+  if (!ok) std::fprintf(stderr, "  got %.9g want %.9g\n", got, want);
+  return ok;
+}
+
+// drive one scalar family through the API and the oracle side by side
+template <typename Tag, typename V, typename Gen>
+static void run_scalar(int fam, unsigned dim, models::model &m, const std::vector<float> &hp,
+                       const std::vector<std::pair<const char *, float>> &hp_keys, Gen gen) {
+  rng_t r(73);
+  auto h = m.create_hypers();
+  for (const auto &kv : hp_keys) h->get_hp_mutator(kv.first).template set<float>(kv.second);
+  auto g = h->create_group(r);
+  std::vector<uint8_t> oss(orc_f64_ss_size(fam, dim));
+  orc_f64_init(fam, dim, hp.data(), oss.data());
+  V vals[25];   // (not std::vector: vector<bool> has no addressable elements)
+  for (int i = 0; i < 25; i++) {
+    vals[i] = gen(r);
+    g->add_value(*h, value_accessor(&vals[i]), r);
+    orc_f64_add_value(fam, dim, hp.data(), oss.data(), &vals[i]);
+    if (i % 6 == 0) {
+      const V probe = gen(r);
+      CHECK(close(g->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), oss.data(), &probe)));
+      CHECK(close(g->score_data(*h, r), orc_f64_score_data(fam, dim, hp.data(), oss.data())));
+    }
+  }
+  // remove half again
+  for (int i = 0; i < 12; i++) {
+    g->remove_value(*h, value_accessor(&vals[i]), r);
+    orc_f64_remove_value(fam, dim, hp.data(), oss.data(), &vals[i]);
+  }
+  const V probe = gen(r);
+  CHECK(close(g->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), oss.data(), &probe), 2e-6));
+  CHECK(close(g->score_data(*h, r), orc_f64_score_data(fam, dim, hp.data(), oss.data()), 2e-6));
+  // bags round-trip, copies keep scoring identically
+  auto g2 = h->create_group(r);
+  g2->set_ss(g->get_ss());
+  CHECK(g2->score_value(*h, value_accessor(&probe), r) == g->score_value(*h, value_accessor(&probe), r));
+  auto g3 = h->create_group(r);
+  g3->set_ss(*g);
+  CHECK(g3->score_data(*h, r) == g->score_data(*h, r));
+  auto h2 = m.create_hypers();
+  h2->set_hp(h->get_hp());
+  CHECK(g->score_value(*h2, value_accessor(&probe), r) == g->score_value(*h, value_accessor(&probe), r));
+  auto h3 = m.create_hypers();
+  h3->set_hp(*h);
+  CHECK(g->score_data(*h3, r) == g->score_data(*h, r));
+  // a fresh group scores like the prior
+  auto g0 = h->create_group(r);
+  std::vector<uint8_t> o0(orc_f64_ss_size(fam, dim));
+  orc_f64_init(fam, dim, hp.data(), o0.data());
+  CHECK(close(g0->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), o0.data(), &probe)));
+  CHECK(g0->score_data(*h, r) == 0.f);
+}
+
+static void test_bb_mutators_write_through() {
+  rng_t r(1);
+  models::distributions_model<BetaBernoulli> m;
+  CHECK(m.get_runtime_type() == runtime_type(TYPE_B));
+  auto h = m.create_hypers();
+  h->get_hp_mutator("alpha").set<float>(2.0f);
+  h->get_hp_mutator("beta").set<float>(2.0f);
+  auto g = h->create_group(r);
+  g->get_ss_mutator("heads").set<uint32_t>(7);      // raw pointer into the live state
+  g->get_ss_mutator("tails").set<int>(1);           // any source type converts
+  const bool t = true;
+  CHECK(close(g->score_value(*h, value_accessor(&t), r), std::log(9.0 / 12.0)));
+  CHECK(g->get_ss_mutator("heads").accessor().get<uint32_t>(0) == 7);
+  bool threw = false;
+  try { g->get_ss_mutator("nope"); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { h->get_hp_mutator("nope"); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  // values of another primitive type are cast on the way in (runtime_cast)
+  const double as_double = 1.0;
+  g->add_value(*h, value_accessor(&as_double), r);
+  CHECK(g->get_ss_mutator("heads").accessor().get<uint32_t>(0) == 8);
+}
+
+static void test_dd_and_niw() {
+  rng_t r(3);
+  {
+    const unsigned dim = 5;
+    models::distributions_model_dd128 m(dim);
+    auto h = m.create_hypers();
+    auto am = h->get_hp_mutator("alphas");
+    CHECK(am.shape() == dim);
+    std::vector<float> hp(dim);
+    for (unsigned i = 0; i < dim; i++) { hp[i] = 0.5f + 0.25f * float(i); am.set<float>(hp[i], i); }
+    auto g = h->create_group(r);
+    std::vector<uint8_t> oss(orc_f64_ss_size(ORC_DD, dim));
+    orc_f64_init(ORC_DD, dim, hp.data(), oss.data());
+    for (int i = 0; i < 40; i++) {
+      const int v = std::uniform_int_distribution<int>(0, int(dim) - 1)(r);
+      g->add_value(*h, value_accessor(&v), r);
+      orc_f64_add_value(ORC_DD, dim, hp.data(), oss.data(), &v);
+    }
+    for (int v = 0; v < int(dim); v++)
+      CHECK(close(g->score_value(*h, value_accessor(&v), r), orc_f64_score_value(ORC_DD, dim, hp.data(), oss.data(), &v)));
+    CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_DD, dim, hp.data(), oss.data())));
+    CHECK(g->get_ss_mutator("count_sum").accessor().get<uint32_t>(0) == 40);
+    auto g2 = h->create_group(r);
+    g2->set_ss(g->get_ss());
+    const int v0 = 2;
+    CHECK(g2->score_value(*h, value_accessor(&v0), r) == g->score_value(*h, value_accessor(&v0), r));
+  }
+  {
+    const unsigned d = 4;
+    models::distributions_model_niwv m(d);
+    CHECK(m.get_runtime_type() == runtime_type(TYPE_F32, d));
+    auto h = m.create_hypers();     // default hp: mu = 0, kappa = 1, psi = I, nu = d
+    std::vector<float> hp(2 + d + d * d, 0.f);
+    hp[0] = 1.f; hp[1] = float(d);
+    for (unsigned i = 0; i < d; i++) hp[2 + d + i * d + i] = 1.f;
+    auto g = h->create_group(r);
+    std::vector<uint8_t> oss(orc_f64_ss_size(ORC_NIW, d));
+    orc_f64_init(ORC_NIW, d, hp.data(), oss.data());
+    std::normal_distribution<float> nd(1.f, 2.f);
+    const runtime_type vt(TYPE_F32, d);
+    std::vector<std::vector<float>> xs;
+    for (int i = 0; i < 15; i++) {
+      xs.emplace_back(d);
+      for (auto &x : xs.back()) x = nd(r);
+      g->add_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(xs.back().data()), nullptr, vt), r);
+      orc_f64_add_value(ORC_NIW, d, hp.data(), oss.data(), xs.back().data());
+    }
+    std::vector<float> probe(d);
+    for (auto &x : probe) x = nd(r);
+    const value_accessor pa(reinterpret_cast<const uint8_t *>(probe.data()), nullptr, vt);
+    CHECK(close(g->score_value(*h, pa, r), orc_f64_score_value(ORC_NIW, d, hp.data(), oss.data(), probe.data()), 5e-6));
+    CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_NIW, d, hp.data(), oss.data()), 5e-6));
+    g->remove_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(xs[0].data()), nullptr, vt), r);
+    orc_f64_remove_value(ORC_NIW, d, hp.data(), oss.data(), xs[0].data());
+    CHECK(close(g->score_value(*h, pa, r), orc_f64_score_value(ORC_NIW, d, hp.data(), oss.data(), probe.data()), 2e-5));
+    auto g2 = h->create_group(r);
+    g2->set_ss(g->get_ss());
+    CHECK(g2->score_value(*h, pa, r) == g->score_value(*h, pa, r));
+  }
+}
+
+int main() {
+  {
+    models::distributions_model<BetaBernoulli> m;
+    run_scalar<BetaBernoulli, bool>(ORC_BB, 0, m, {2.f, 0.5f}, {{"alpha", 2.f}, {"beta", 0.5f}},
+                                    [](rng_t &r) { return std::bernoulli_distribution(0.7)(r); });
+  }
+  {
+    models::distributions_model<GammaPoisson> m;
+    CHECK(m.get_runtime_type() == runtime_type(TYPE_U32));
+    run_scalar<GammaPoisson, uint32_t>(ORC_GP, 0, m, {1.5f, 0.75f}, {{"alpha", 1.5f}, {"inv_beta", 0.75f}},
+                                       [](rng_t &r) { return uint32_t(std::poisson_distribution<int>(6.0)(r)); });
+  }
+  {
+    models::distributions_model<NormalInverseChiSq> m;
+    CHECK(m.get_runtime_type() == runtime_type(TYPE_F32));
+    run_scalar<NormalInverseChiSq, float>(ORC_NICH, 0, m, {0.5f, 2.f, 1.5f, 3.f},
+                                          {{"mu", 0.5f}, {"kappa", 2.f}, {"sigmasq", 1.5f}, {"nu", 3.f}},
+                                          [](rng_t &r) { return std::normal_distribution<float>(4.f, 2.f)(r); });
+  }
+  test_bb_mutators_write_through();
+  test_dd_and_niw();
+  std::puts("test_plugin_gpu ok");
+  return 0;
+}
