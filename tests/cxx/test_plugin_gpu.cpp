@@ -77,7 +77,7 @@ static void run_scalar(int fam, unsigned dim, models::model &m, const std::vecto
   std::vector<uint8_t> o0(orc_f64_ss_size(fam, dim));
   orc_f64_init(fam, dim, hp.data(), o0.data());
   CHECK(close(g0->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), o0.data(), &probe)));
-  CHECK(g0->score_data(*h, r) == 0.f);
+  CHECK(std::fabs(g0->score_data(*h, r)) < 1e-6f);   // empty group: log marginal of no data (0 up to fma rounding)
 }
 
 static void test_bb_mutators_write_through() {
