@@ -166,6 +166,7 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
     v->masks.push_back(uf[i].dst_mask);
     v->types.push_back(msc_runtime_type{uf[i].dst_type, types[i].count});
   }
+  v->col_max.assign(ntypes, -1);
   if (nrows > 0) {
     if ((rc = dev_alloc(scratch, &rec_dev, (size_t)nrows * rowsize))) return cleanup(rc);
     if ((rc = dev_alloc(scratch, &uf_dev, ntypes))) return cleanup(rc);
@@ -205,6 +206,7 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
     v->cols.push_back(dev_columns[i]);
     v->masks.push_back(dev_masks ? dev_masks[i] : nullptr);
   }
+  v->col_max.assign(ntypes, -1);
   *out = v.release();
   return MSC_OK;
 }
@@ -324,6 +326,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->cnt_u32, kpad))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->logpc, 2 * kpad + 4))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
     msc_feature_host &h = st->feats[f];
     default_hp(h.family, h.dim, h.hp);
@@ -363,6 +366,9 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     d.niw_w64 = h.niw_w64;
     d.niw_mu64 = h.niw_mu64;
     d.niw_c64 = h.niw_c64;
+    d.vcap = 32;
+    d.aux = 0.0;
+    for (float a : h.hp) d.aux += h.family == MSC_DD ? (double)a : 0.0;
   }
   st->cnt_additive_valid = true;
   if ((rc = upload_desc(st.get()))) return bail(rc);
@@ -400,6 +406,13 @@ extern "C" int msc_state_set_hp(msc_state *st, uint32_t feature, const float *ho
     MSC_HIP(hipStreamSynchronize(st->ctx->stream));
   }
   h.derived_valid = false;
+  if (h.family == MSC_DD) {
+    double asum = 0;
+    for (float a : h.hp) asum += (double)a;
+    st->desc_host[feature].aux = asum;
+    MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat, hipMemcpyHostToDevice, st->ctx->stream));
+    MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+  }
   return MSC_OK;
 }
 
@@ -601,6 +614,25 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
     st->desc_host[f].col = view->cols[c];
     st->desc_host[f].mask = static_cast<const uint8_t *>(view->masks[c]);
     st->desc_host[f].col_type = t.type;
+    if (h.family == MSC_GP) {
+      // the exact gp table covers counts 0..max of the bound column (capped): find the max once
+      if (view->col_max[c] < 0) {
+        uint32_t mx = 0;
+        if (view->nrows > 0) {
+          MSC_HIP(hipMemsetAsync(st->colmax_dev, 0, 4, st->ctx->stream));
+          if (launch_col_max_u32(st->ctx->stream, static_cast<const uint32_t *>(view->cols[c]), view->nrows, st->colmax_dev))
+            return fail(MSC_EHIP, "k_col_max_u32 launch failed");
+          MSC_HIP(hipMemcpyAsync(&mx, st->colmax_dev, 4, hipMemcpyDeviceToHost, st->ctx->stream));
+          MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+        }
+        view->col_max[c] = (long long)mx;
+      }
+      const uint32_t vcap = (uint32_t)std::min<long long>(view->col_max[c] + 1, (long long)kGpMaxTable);
+      if (vcap != st->desc_host[f].vcap) {
+        st->desc_host[f].vcap = vcap;
+        st->feats[f].derived_valid = false;
+      }
+    }
   }
   st->bound_view = view;
   return upload_desc(st);
@@ -635,18 +667,42 @@ static int ensure_crp(msc_state *st) {
 // ---------------------------------------------------------------------------
 // scalar families go through one fused kernel (scores summed over features in registers);
 // every niw feature then adds its MFMA pass on top.
+static int ensure_own(msc_state *st, uint64_t nrows) {
+  if (st->own_cap >= nrows) return MSC_OK;
+  void *p = nullptr;
+  MSC_HIP(hipMalloc(&p, nrows * sizeof(float)));
+  st->owned.push_back(p);
+  st->own = static_cast<float *>(p);
+  st->own_cap = nrows;
+  return MSC_OK;
+}
+
+static bool gp_beyond_table(const msc_state *st, uint32_t f) {
+  return st->feats[f].family == MSC_GP && st->bound_view &&
+         st->bound_view->col_max[st->bound_cols[f]] >= (long long)kGpMaxTable;
+}
+
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
                      bool niw_f32, float *out_dev, uint64_t ld_out) {
   hipStream_t s = st->ctx->stream;
+  if (z_dev) {
+    MSC_TRY(ensure_own(st, nrows));
+    if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+      return fail(MSC_EHIP, "k_loo_own launch failed");
+  }
   uint32_t n_niw = 0;
   for (auto &h : st->feats) n_niw += h.family == MSC_NIW;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   bool written = false;
   if (n_niw < st->nfeat || crp) {
     if (launch_score(s, st->ctx->num_cus, nich1, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
-                     z_dev, crp ? st->logpc : nullptr, out_dev, ld_out))
+                     z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
+    for (uint32_t f = 0; f < st->nfeat; f++)
+      if (gp_beyond_table(st, f) &&
+          launch_gp_large_fix(s, st->ctx->num_cus, st->desc_dev, (int)f, st->K, st->kpad, row0, nrows, z_dev, out_dev, ld_out))
+        return fail(MSC_EHIP, "k_gp_large_fix launch failed");
   }
   for (uint32_t f = 0; f < st->nfeat; f++) {
     if (st->feats[f].family != MSC_NIW) continue;
@@ -752,11 +808,16 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
   hipStream_t s = st->ctx->stream;
   const int cus = st->ctx->num_cus;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  bool fused_ok = true;        // niw and gp-beyond-table features need the materialised path
+  for (uint32_t f = 0; f < st->nfeat; f++) fused_ok &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
   int rc = -2;
-  if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
-  bool any_niw = false;
-  for (auto &h : st->feats) any_niw |= h.family == MSC_NIW;
-  if (rc == -2 && !any_niw) rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, seed, sweep);
+  if (fused_ok && (nich1 ? st->K <= 1024 : st->K <= 256)) {
+    MSC_TRY(ensure_own(st, nrows));
+    if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      return fail(MSC_EHIP, "k_loo_own launch failed");
+    if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
+    else rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
+  }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;

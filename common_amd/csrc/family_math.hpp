@@ -85,15 +85,15 @@ MSC_DEV double dd_loo(float alpha_v, uint32_t count_v, double alpha_sum, uint32_
 //   score(v) = lgamma(a+v) - lgamma(a) - lgamma(v+1) + a ln b - (a+v) ln(1+b).
 // The terms are ~v ln a each while the result is O(1..v): float cannot subtract
 // them to 1e-6.  So:
-//  * v < GP_TABLE: an exact per-group table built in double by the prepare step
-//    (rows GP_T0 + v) -- one 16-byte load per (row, 4 groups), no arithmetic.
-//  * v >= GP_TABLE (rare for count data): Loader's saddle-point form (C. Loader
+//  * v < vcap = min(max count of the bound column + 1, 1024): an exact per-group table built
+//    in double by the prepare step (rows GP_T0 + v) -- one 16-byte load per (row, 4 groups).
+//  * v >= 1024 (k_gp_large_fix, a separate pass that only exists for such columns): Loader's saddle-point form (C. Loader
 //    2000, the form R's dnbinom uses), in which every term is of the size of the
 //    result, evaluated in double:
 //      score = -log1p(v/a)/2 - ln(2 pi v)/2 - e(v) + S(a+v) - e(a) - a g(-d/a) - v g(d/v)
 //      d = (a - v b)/(1+b),  g(y) = y - log1p(y),  e(y) = stirlerr(y) = lgamma(y+1) - Stirling(y)
 //    e(a) comes from the prepare step (hi/lo floats), e(v) and ln(2 pi v) once per row.
-enum { GP_NSE_HI = 0, GP_NSE_LO = 1, GP_T0 = 2, GP_TABLE = 32, GP_ROWS = GP_T0 + GP_TABLE };
+enum { GP_NSE_HI = 0, GP_NSE_LO = 1, GP_T0 = 2 };   // rows GP_T0 + v, v < FeatDesc::vcap: the exact table
 
 MSC_DEV double gp_score_exact(double a, double b, double v) {
   return lgamma(a + v) - lgamma(a) - lgamma(v + 1.0) + a * log(b) - (a + v) * log1p(b);
@@ -107,7 +107,7 @@ MSC_DEV void gp_prepare_consts(const float *hp, uint32_t count, uint32_t sum, fl
 MSC_DEV float gp_prepare_table(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
   return (float)gp_score_exact((double)hp[0] + (double)sum, (double)hp[1] + (double)count, (double)v);
 }
-MSC_DEV double stirling_tail(double z) {  // S(z) = 1/(12z) - 1/(360z^3) + 1/(1260z^5) - 1/(1680z^7), z >= 32
+MSC_DEV double stirling_tail(double z) {  // S(z) = 1/(12z) - 1/(360z^3) + 1/(1260z^5) - 1/(1680z^7), z >= 1024
   const double r = 1.0 / z, r2 = r * r;
   return r * (1.0 / 12.0 - r2 * (1.0 / 360.0 - r2 * (1.0 / 1260.0 - r2 * (1.0 / 1680.0))));
 }

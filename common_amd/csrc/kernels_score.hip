@@ -1,15 +1,20 @@
 // kernels_score.hip -- gfx950 kernels for the scoring side of the hot path:
-//   k_prepare      suff-stats -> per-group float score constants (double math)
-//   k_crp_prepare  group sizes -> log pseudocounts (group_manager.hpp:274-283)
-//   k_score_nich1  one NICH feature, [nrows x K] scores, streaming 1 KiB stores
-//   k_score_mixed  any feature list; scores summed over features in registers
+//   k_prepare       suff-stats -> per-group float score constants / tables (double math)
+//   k_crp_prepare   group sizes -> log pseudocounts (group_manager.hpp:274-283)
+//   k_loo_own       per row: score of the row against its own group with the row removed
+//                   (remove_value then score_value), summed over features, in double
+//   k_score_nich1   one NICH feature, [nrows x K] scores, constants in VGPRs, streaming stores
+//   k_score_tile    any feature list; per-feature tables staged through LDS per workgroup
+//                   (score_block.hpp), scores summed over features in registers, one store per row
+//   k_gp_large_fix  gp counts beyond the exact table: Loader's saddle-point form in double
 //
-// Mapping used by every score kernel: a wave owns a block of rows and one k-tile
-// of 256 groups; lane l owns groups 4l..4l+3 of the tile, so a row of the tile
-// is one 16-byte value per lane = one 1 KiB contiguous store per wave
-// (HBM-write-bound configs need nothing else on the critical path).  Row values
-// are loaded coalesced (lane r <- row r of the block) and broadcast with
-// v_readlane; per-group constants live in VGPRs for the whole block.
+// Mapping used by every score kernel: a wave owns a block of rows and one k-tile of 256
+// groups; lane l owns groups 4l..4l+3 of the tile, so a row of the tile is one 16-byte value
+// per lane = one 1 KiB contiguous store per wave (HBM-write-bound configs need nothing else on
+// the critical path).  Row values are loaded coalesced (lane r <- row r of the block) and
+// broadcast with v_readlane.
+#include <cstdlib>
+
 #include "family_math.hpp"
 #include "launchers.hpp"
 #include "score_block.hpp"
@@ -17,8 +22,8 @@
 namespace msc {
 
 // ---------------------------------------------------------------------------
-// prepare: one thread per (feature, group slot); pads (k >= K) are prepared from
-// their zeroed raw stats so that vector loads of a full tile stay finite.
+// prepare: one thread per (feature, group slot); pads (k >= K) are prepared from their
+// zeroed raw stats so that vector loads of a full tile stay finite.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ feats, uint32_t kpad) {
   const FeatDesc fd = feats[blockIdx.y];
@@ -34,16 +39,14 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
     case MSC_GP: {
       const uint32_t cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
       gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
-      for (uint32_t v = 0; v < GP_TABLE; v++)
+      for (uint32_t v = 0; v < fd.vcap; v++)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
     } break;
     case MSC_DD: {
-      double asum = 0;
-      for (uint32_t i = 0; i < fd.dim; i++) asum += (double)fd.hp[i];
       const uint32_t csum = fd.raw_u32[k];
       for (uint32_t i = 0; i < fd.dim; i++)
         fd.tab[(size_t)i * kpad + k] =
-            dd_prepare_entry(fd.hp[i], fd.raw_u32[(size_t)(1 + i) * kpad + k], asum, csum);
+            dd_prepare_entry(fd.hp[i], fd.raw_u32[(size_t)(1 + i) * kpad + k], fd.aux, csum);
     } break;
     case MSC_NICH: {
       float o[NICH_ROWS];
@@ -79,6 +82,52 @@ __global__ __launch_bounds__(256) void k_crp_prepare(const uint32_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// leave-one-out pre-pass: own[n] = (prior of z[n] with the row removed, if crp) +
+// sum over scalar features of score_value(group z[n] minus row n, row n).  One thread per row,
+// everything in double; niw features add theirs inside the niw kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ feats, int nfeat,
+                                                  uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                  const int32_t *__restrict__ z,
+                                                  const float *__restrict__ crp, float *__restrict__ own) {
+  const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nrows) return;
+  const int g = z[n];
+  if (g < 0) {
+    own[n] = 0.f;
+    return;
+  }
+  const uint64_t row = row0 + n;
+  double s = 0.0;
+  if (crp) {
+    const float lm1 = crp[kpad + g];
+    s = __builtin_isinf(lm1) ? crp[2 * (size_t)kpad + 1] : lm1;
+  }
+  for (int f = 0; f < nfeat; f++) {
+    const FeatDesc fd = feats[f];
+    switch (fd.family) {
+      case MSC_BB:
+        s += bb_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
+        break;
+      case MSC_GP:
+        s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);
+        break;
+      case MSC_DD: {
+        int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+        v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
+        s += dd_loo(fd.hp[v], fd.raw_u32[(size_t)(1 + v) * kpad + g], fd.aux, fd.raw_u32[g]);
+      } break;
+      case MSC_NICH:
+        s += nich_loo(fd.hp, fd.raw_u32[g], fd.raw_f32[g], fd.raw_f32[kpad + g],
+                      reinterpret_cast<const float *>(fd.col)[row]);
+        break;
+      default: break;
+    }
+  }
+  own[n] = (float)s;
+}
+
+// ---------------------------------------------------------------------------
 // single NICH feature (config C2 / C5 scoring pass)
 //   grid.x = row chunks (grid-stride), grid.y = k-tiles, block = 4 waves
 // ---------------------------------------------------------------------------
@@ -86,6 +135,7 @@ template <bool LOO, bool CRP>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
+                                                      const float *__restrict__ own,
                                                       const float *__restrict__ crp,
                                                       float *__restrict__ out, uint64_t ld) {
   const FeatDesc fd = feats[0];
@@ -112,20 +162,11 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
     const int nr = (int)((nrows - rb) < 64 ? (nrows - rb) : 64);
     const float xv = lane < nr ? xcol[rb + lane] : 0.0f;
     int gz = -1;
-    float sloo = 0, pg = 0, erow = le0;
-    if (LOO) {
-      if (lane < nr) gz = z[rb + lane];
-      if (gz >= 0) {
-        const uint32_t cg = fd.raw_u32[gz];
-        sloo = (float)nich_loo(fd.hp, cg, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
-        if (CRP) {
-          const float lm1 = crp[kpad + gz];
-          const bool single = __builtin_isinf(lm1);
-          pg = single ? le1 : lm1;
-          erow = single ? le1 : le0;
-          sloo += pg;
-        }
-      }
+    float sloo = 0, erow = le0;
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+      if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
     }
 #pragma unroll 4
     for (int r = 0; r < nr; r++) {
@@ -135,10 +176,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
       s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
       s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
       s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-      if (CRP) {
-        const float4 p = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-      }
+      if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
       if (LOO) {
         const int g = lane_bcast(gz, r);
         if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
@@ -149,20 +187,21 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// general path: any feature list, R rows per wave block kept in registers.
+// general path: any feature list, workgroup tiles with LDS-staged tables.
+//   grid.x = row chunks of 8*R rows (grid-stride), grid.y = k-tiles, block = 8 waves
 // ---------------------------------------------------------------------------
-template <int R, bool LOO, bool CRP>
-__global__ __launch_bounds__(256) void k_score_mixed(const FeatDesc *__restrict__ feats, int nfeat,
-                                                      uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, const int32_t *__restrict__ z,
-                                                      const float *__restrict__ crp,
-                                                      float *__restrict__ out, uint64_t ld) {
-  const int lane = threadIdx.x & 63;
+template <int R, int MINW, bool LOO, bool CRP>
+__global__ __launch_bounds__(kTileThreads, MINW) void k_score_tile(const FeatDesc *__restrict__ feats,
+                                                                 int nfeat, uint32_t K, uint32_t kpad,
+                                                                 uint64_t row0, uint64_t nrows,
+                                                                 const int32_t *__restrict__ z,
+                                                                 const float *__restrict__ own,
+                                                                 const float *__restrict__ crp,
+                                                                 float *__restrict__ out, uint64_t ld) {
+  __shared__ float4 lds[kLdsRows * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const uint64_t nblocks = (nrows + R - 1) / R;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   float4 logcnt = make_float4(0, 0, 0, 0);
   float le0 = 0, le1 = 0;
   if (CRP) {
@@ -170,23 +209,62 @@ __global__ __launch_bounds__(256) void k_score_mixed(const FeatDesc *__restrict_
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
   }
-  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
-    const uint64_t rb = blk * R;                       // relative to row0
-    const int nr = (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+  const uint64_t rows_per_wg = (uint64_t)kTileWaves * R;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;       // relative to row0
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    int gz = -1;
+    float sloo = 0, erow = le0;
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+      if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+    }
     float4 acc[R];
-    int gz;
-    float own;
-    score_block<R, LOO, CRP>(feats, nfeat, kpad, kb, lane, row0, rb, nr, z, crp, logcnt, le0, le1, acc, gz, own);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
+      else acc[r] = make_float4(0, 0, 0, 0);
+    }
+    score_tile<R>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {
         float4 s = acc[r];
         if (LOO) {
           const int g = lane_bcast(gz, r);
-          if (g >= 0) replace_own(s, kb, g, lane_bcast(own, r));
+          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
         }
         store_row(out, ld, rb + r, kb, K, s, vec_ok);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gp counts >= vcap (only when a column's maximum exceeds the table cap): one wave per row,
+// lanes over groups; adds the exact value (the own group's value is already the loo one).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict__ feats, int f, uint32_t K,
+                                                       uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                       const int32_t *__restrict__ z, float *__restrict__ out,
+                                                       uint64_t ld) {
+  const FeatDesc fd = feats[f];
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const double al = fd.hp[0], ib = fd.hp[1];
+  for (uint64_t n = wave_id; n < nrows; n += nwaves) {
+    const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row0 + n];
+    if (v < fd.vcap) continue;
+    const int g = z ? z[n] : -1;
+    const double rowc = gp_row_const(v);
+    for (uint32_t k = lane; k < K; k += 64) {
+      if ((int)k == g) continue;
+      const double a = al + (double)fd.raw_u32[(size_t)kpad + k], b = ib + (double)fd.raw_u32[k];
+      const double nse = (double)fd.tab[(size_t)GP_NSE_HI * kpad + k] + (double)fd.tab[(size_t)GP_NSE_LO * kpad + k];
+      out[n * ld + k] += gp_eval_large((double)v, rowc, a, b, nse);
     }
   }
 }
@@ -206,10 +284,35 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int launch_loo_own(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
+                   uint64_t nrows, const int32_t *z, const float *crp, float *own) {
+  hipLaunchKernelGGL(k_loo_own, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
+                     kpad, row0, nrows, z, crp, own);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
+                        uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld) {
+  uint64_t gx = (nrows + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * 8;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_gp_large_fix, dim3((unsigned)(gx ? gx : 1)), dim3(256), 0, stream, feats_dev, f, K, kpad,
+                     row0, nrows, z, out, ld);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int tile_rows_per_wave() {
+  static const int r = [] {
+    const char *e = std::getenv("MSC_TILE_ROWS");
+    return (e && std::atoi(e) == 8) ? 8 : 16;
+  }();
+  return r;
+}
+
 template <bool LOO, bool CRP>
 static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev,
                            int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
-                           const int32_t *z, const float *crp, float *out, uint64_t ld) {
+                           const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (nich1) {
     const uint64_t nchunks = (nrows + 63) / 64;
@@ -218,27 +321,34 @@ static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const Fe
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
     hipLaunchKernelGGL((k_score_nich1<LOO, CRP>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, z, crp, out, ld);
+                       feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
   } else {
-    constexpr int R = 16;
-    const uint64_t nblocks = (nrows + R - 1) / R;
-    uint64_t gx = (nblocks + 3) / 4;
-    const uint64_t cap = (uint64_t)num_cus * 16;
+    // two tilings: 16 rows per wave at 2 waves/SIMD (default), or 8 rows per wave at 4 waves/SIMD
+    const int R = tile_rows_per_wave();
+    const uint64_t nchunks = (nrows + kTileWaves * R - 1) / (kTileWaves * R);
+    uint64_t gx = nchunks;
+    const uint64_t cap = (uint64_t)num_cus * 8;
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL((k_score_mixed<R, LOO, CRP>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
-                       feats_dev, nfeat, K, kpad, row0, nrows, z, crp, out, ld);
+    const dim3 grid((unsigned)gx, ktiles), block(kTileThreads);
+    if (R == 16)
+      hipLaunchKernelGGL((k_score_tile<16, 2, LOO, CRP>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
+    else
+      hipLaunchKernelGGL((k_score_tile<8, 4, LOO, CRP>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
   }
 }
 
+// own: per-row leave-one-out values from launch_loo_own (required when z != null)
 int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev, int nfeat,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
-                 const float *crp, float *out, uint64_t ld) {
+                 const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;
-  if (loo && pri) launch_score_t<true, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, crp, out, ld);
-  else if (loo) launch_score_t<true, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, crp, out, ld);
-  else if (pri) launch_score_t<false, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, crp, out, ld);
-  else launch_score_t<false, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, crp, out, ld);
+  if (loo && pri) launch_score_t<true, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (loo) launch_score_t<true, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (pri) launch_score_t<false, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else launch_score_t<false, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -299,9 +299,30 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ reco
   }
 }
 
+// maximum of a uint32 column (sizes the gp tables)
+__global__ __launch_bounds__(256) void k_col_max_u32(const uint32_t *__restrict__ col, uint64_t n,
+                                                      uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    m = col[i] > m ? col[i] : m;
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_col_max_u32, dim3((unsigned)blocks), dim3(256), 0, stream, col, n, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 size_t accumulate_lds_bytes(const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t dd_slice) {
   size_t need = (size_t)K * 4;
   for (int f = 0; f < nfeat; f++) {

@@ -7,8 +7,8 @@
 //   k_sweep_nich1<G>  one NICH feature, K <= 64*G: every per-group constant of the
 //                     whole table lives in VGPRs (lane l owns groups G*l .. G*l+G-1),
 //                     rows stream through; no LDS, no HBM traffic besides x, z.
-//   k_sweep_mixed<R>  any feature list, K <= 256: the score_block of the batched
-//                     kernel, sampled from registers.
+//   k_sweep_tile<R>   any feature list, K <= 256: the workgroup tile of the batched kernel
+//                     (tables staged through LDS), sampled from registers.
 //   k_sample_rows     fallback for larger tables: samples rows of a score chunk that
 //                     msc_score_value (leave-one-out + prior) wrote to scratch.
 #include "family_math.hpp"
@@ -83,6 +83,7 @@ template <int G>
 __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict__ feats, uint32_t K,
                                                       uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                       uint64_t row_id0, int32_t *__restrict__ z,
+                                                      const float *__restrict__ own,
                                                       const float *__restrict__ crp, uint64_t seed,
                                                       uint64_t sweep) {
   const FeatDesc fd = feats[0];
@@ -122,11 +123,8 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     float sloo = 0.f, erow = le0;
     if (gz >= 0) {
-      const float lm1 = crp[kpad + gz];
-      const bool single = __builtin_isinf(lm1);
-      erow = single ? le1 : le0;
-      sloo = (float)nich_loo(fd.hp, fd.raw_u32[gz], fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv) +
-             (single ? le1 : lm1);
+      erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+      sloo = own[rb + lane];      // leave-one-out score + prior of the own group (k_loo_own)
     }
     int znew = gz;
     for (int r = 0; r < nr; r++) {
@@ -149,34 +147,46 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256) void k_sweep_mixed(const FeatDesc *__restrict__ feats, int nfeat,
-                                                      uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, uint64_t row_id0,
-                                                      int32_t *__restrict__ z,
-                                                      const float *__restrict__ crp, uint64_t seed,
-                                                      uint64_t sweep) {
-  const int lane = threadIdx.x & 63;
+// any feature list, K <= 256: the workgroup tile of score_block.hpp, sampled from registers
+// ---------------------------------------------------------------------------
+template <int R, int MINW>
+__global__ __launch_bounds__(kTileThreads, MINW) void k_sweep_tile(const FeatDesc *__restrict__ feats, int nfeat,
+                                                                 uint32_t K, uint32_t kpad, uint64_t row0,
+                                                                 uint64_t nrows, uint64_t row_id0,
+                                                                 int32_t *__restrict__ z,
+                                                                 const float *__restrict__ own,
+                                                                 const float *__restrict__ crp, uint64_t seed,
+                                                                 uint64_t sweep) {
+  __shared__ float4 lds[kLdsRows * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = lane * 4;            // single k-tile: K <= 256
   const float4 logcnt = ld4(crp + kb);
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
-  const uint64_t nblocks = (nrows + R - 1) / R;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
-    const uint64_t rb = blk * R;
-    const int nr = (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+  const uint64_t rows_per_wg = (uint64_t)kTileWaves * R;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    int gz = -1;
+    float sloo = 0.f, erow = le0;
+    if (lane < nr) {
+      gz = z[rb + lane];
+      if (gz >= 0) {
+        sloo = own[rb + lane];
+        erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+      }
+    }
     float4 acc[R];
-    int gz;
-    float own;
-    score_block<R, true, true>(feats, nfeat, kpad, kb, lane, row0, rb, nr, z, crp, logcnt, le0, le1, acc, gz, own);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
+    score_tile<R>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float4 s4 = acc[r];
       const int g = lane_bcast(gz, r);
-      if (g >= 0) replace_own(s4, kb, g, lane_bcast(own, r));
+      if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
       float s[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -232,15 +242,15 @@ static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int wa
 
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *crp, uint64_t seed, uint64_t sweep) {
+                       const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
   const uint64_t gx = grid_for((nrows + 63) / 64, num_cus, 16);
   const dim3 grid((unsigned)gx), block(256);
   if (K <= 256)
-    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
   else if (K <= 512)
-    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
   else if (K <= 1024)
-    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
   else
     return -2;
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -248,12 +258,19 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
 
 int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *crp, uint64_t seed, uint64_t sweep) {
+                       const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
   if (K > 256) return -2;
-  constexpr int R = 16;
-  const uint64_t gx = grid_for((nrows + R - 1) / R, num_cus, 16);
-  hipLaunchKernelGGL(k_sweep_mixed<R>, dim3((unsigned)gx), dim3(256), 0, stream, feats_dev, nfeat, K, kpad,
-                     row0, nrows, row_id0, z, crp, seed, sweep);
+  const int R = tile_rows_per_wave();
+  uint64_t gx = (nrows + kTileWaves * R - 1) / (kTileWaves * R);
+  const uint64_t cap = (uint64_t)num_cus * 8;
+  if (gx > cap) gx = cap;
+  const dim3 grid((unsigned)(gx ? gx : 1)), block(kTileThreads);
+  if (R == 16)
+    hipLaunchKernelGGL((k_sweep_tile<16, 2>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, seed, sweep);
+  else
+    hipLaunchKernelGGL((k_sweep_tile<8, 4>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, seed, sweep);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -18,6 +18,7 @@ namespace msc {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kGroupTile = 256;    // groups per k-tile: lane <-> 4 consecutive groups
 constexpr unsigned kMaxDDDim = 128;
+constexpr unsigned kGpMaxTable = 1024;   // gp counts below this are exact table entries
 
 // ---- error plumbing --------------------------------------------------------
 void set_error(const char *fmt, ...);
@@ -86,12 +87,15 @@ struct FeatDesc {
   double *niw_w64;         // niw only: the same whitening matrix, unrounded
   double *niw_mu64;        // niw only: [K][32] posterior mean
   double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
+  double aux;              // dd: sum of the alphas
+  uint32_t vcap;           // gp: rows of the exact table (min(column max + 1, kGpMaxTable))
+  uint32_t pad1;
 };
 
 inline uint32_t tab_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
-    case MSC_GP: return 2 + 32;   // GP_ROWS in family_math.hpp
+    case MSC_GP: return 2 + kGpMaxTable;   // GP_T0 + table rows (family_math.hpp)
     case MSC_DD: return dim;
     case MSC_NICH: return 6; // NICH_ROWS
     case MSC_NIW: return 8;  // NIW_ROWS + 1 (kernels_niw.hip)
@@ -165,6 +169,7 @@ struct msc_dataview {
   std::vector<void *> cols;              // device columns
   std::vector<void *> masks;             // device mask columns or null
   std::vector<void *> owned;             // allocations to free
+  mutable std::vector<long long> col_max;  // lazily computed maximum of uint32 columns (-1 = unknown)
 };
 
 struct msc_feature_host {
@@ -203,5 +208,8 @@ struct msc_state {
   std::vector<uint32_t> bound_cols;
   std::vector<void *> owned;
   float *scratch = nullptr;       // score chunk for the generic sweep path
+  float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
+  size_t own_cap = 0;
+  uint32_t *colmax_dev = nullptr;
   size_t scratch_floats = 0;
 };
