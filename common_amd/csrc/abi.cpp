@@ -167,6 +167,7 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
     v->types.push_back(msc_runtime_type{uf[i].dst_type, types[i].count});
   }
   v->col_max.assign(ntypes, -1);
+  v->chunk_max.assign(ntypes, nullptr);
   if (nrows > 0) {
     if ((rc = dev_alloc(scratch, &rec_dev, (size_t)nrows * rowsize))) return cleanup(rc);
     if ((rc = dev_alloc(scratch, &uf_dev, ntypes))) return cleanup(rc);
@@ -207,6 +208,7 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
     v->masks.push_back(dev_masks ? dev_masks[i] : nullptr);
   }
   v->col_max.assign(ntypes, -1);
+  v->chunk_max.assign(ntypes, nullptr);
   *out = v.release();
   return MSC_OK;
 }
@@ -215,6 +217,7 @@ extern "C" int msc_dataview_destroy(msc_dataview *view) {
   if (!view) return MSC_OK;
   (void)hipSetDevice(view->ctx->device);
   free_all(view->owned);
+  free_all(view->owned_lazy);
   delete view;
   return MSC_OK;
 }
@@ -331,7 +334,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     msc_feature_host &h = st->feats[f];
     default_hp(h.family, h.dim, h.hp);
     if ((rc = dev_alloc(st->owned, &h.hp_dev, h.hp.size()))) return bail(rc);
-    if ((rc = dev_alloc(st->owned, &h.tab, (size_t)tab_rows(h.family, h.dim) * kpad))) return bail(rc);
+    if ((rc = dev_alloc(st->owned, &h.tab, (size_t)(tab_rows(h.family, h.dim) + 4) * kpad))) return bail(rc);   // +4: stage_table1 copies 4 rows per instruction
     if ((rc = dev_alloc(st->owned, &h.raw_u32, (size_t)raw_u32_rows(h.family, h.dim) * kpad))) return bail(rc);
     const size_t nf32 = h.family == MSC_NIW ? (size_t)ngroups * (h.dim + (size_t)h.dim * h.dim)
                                             : (size_t)raw_f32_rows(h.family) * kpad;
@@ -626,7 +629,16 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
           MSC_HIP(hipStreamSynchronize(st->ctx->stream));
         }
         view->col_max[c] = (long long)mx;
+        if (view->nrows > 0) {
+          void *cm = nullptr;
+          MSC_HIP(hipMalloc(&cm, sizeof(uint16_t) * ((view->nrows + 127) / 128 + 1)));
+          view->owned_lazy.push_back(cm);
+          view->chunk_max[c] = static_cast<uint16_t *>(cm);
+          if (launch_chunk_max_u32(st->ctx->stream, static_cast<const uint32_t *>(view->cols[c]), view->nrows, view->chunk_max[c]))
+            return fail(MSC_EHIP, "k_chunk_max_u32 launch failed");
+        }
       }
+      st->desc_host[f].chunk_max = view->chunk_max[c];
       const uint32_t vcap = (uint32_t)std::min<long long>(view->col_max[c] + 1, (long long)kGpMaxTable);
       if (vcap != st->desc_host[f].vcap) {
         st->desc_host[f].vcap = vcap;

@@ -4,8 +4,9 @@
 //   k_loo_own       per row: score of the row against its own group with the row removed
 //                   (remove_value then score_value), summed over features, in double
 //   k_score_nich1   one NICH feature, [nrows x K] scores, constants in VGPRs, streaming stores
-//   k_score_tile    any feature list; per-feature tables staged through LDS per workgroup
-//                   (score_block.hpp), scores summed over features in registers, one store per row
+//   k_score_tile    any feature list; per-feature tables copied to LDS per workgroup by async
+//                   global_load_lds, double-buffered (score_block.hpp); scores summed over
+//                   features in registers, one store per row
 //   k_gp_large_fix  gp counts beyond the exact table: Loader's saddle-point form in double
 //
 // Mapping used by every score kernel: a wave owns a block of rows and one k-tile of 256
@@ -190,15 +191,15 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
 // general path: any feature list, workgroup tiles with LDS-staged tables.
 //   grid.x = row chunks of 8*R rows (grid-stride), grid.y = k-tiles, block = 8 waves
 // ---------------------------------------------------------------------------
-template <int R, int MINW, bool LOO, bool CRP>
-__global__ __launch_bounds__(kTileThreads, MINW) void k_score_tile(const FeatDesc *__restrict__ feats,
+template <int R, int W, bool LOO, bool CRP>
+__global__ __launch_bounds__(W * 64, W / 4) void k_score_tile(const FeatDesc *__restrict__ feats,
                                                                  int nfeat, uint32_t K, uint32_t kpad,
                                                                  uint64_t row0, uint64_t nrows,
                                                                  const int32_t *__restrict__ z,
                                                                  const float *__restrict__ own,
                                                                  const float *__restrict__ crp,
                                                                  float *__restrict__ out, uint64_t ld) {
-  __shared__ float4 lds[kLdsRows * 64];
+  __shared__ float4 lds[2 * kLdsRows * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kTileThreads, MINW) void k_score_tile(const FeatDes
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
   }
-  const uint64_t rows_per_wg = (uint64_t)kTileWaves * R;
+  const uint64_t rows_per_wg = (uint64_t)W * R;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;       // relative to row0
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(kTileThreads, MINW) void k_score_tile(const FeatDes
       if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
       else acc[r] = make_float4(0, 0, 0, 0);
     }
-    score_tile<R>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
+    const uint64_t wg0 = chunk * rows_per_wg;
+    const uint32_t wgn = (uint32_t)((nrows - wg0) < rows_per_wg ? (nrows - wg0) : rows_per_wg);
+    score_tile<R, W>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {
@@ -303,8 +306,8 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
 
 int tile_rows_per_wave() {
   static const int r = [] {
-    const char *e = std::getenv("MSC_TILE_ROWS");
-    return (e && std::atoi(e) == 8) ? 8 : 16;
+    const char *e = std::getenv("MSC_TILE_ROWS");   // tuning knob: rows per wave, 8 (default) | 16
+    return (e && std::atoi(e) == 16) ? 16 : 8;
   }();
   return r;
 }
@@ -323,19 +326,20 @@ static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const Fe
     hipLaunchKernelGGL((k_score_nich1<LOO, CRP>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
                        feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
   } else {
-    // two tilings: 16 rows per wave at 2 waves/SIMD (default), or 8 rows per wave at 4 waves/SIMD
+    // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
+    // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)
     const int R = tile_rows_per_wave();
-    const uint64_t nchunks = (nrows + kTileWaves * R - 1) / (kTileWaves * R);
+    const uint64_t nchunks = (nrows + 127) / 128;
     uint64_t gx = nchunks;
-    const uint64_t cap = (uint64_t)num_cus * 8;
+    const uint64_t cap = (uint64_t)num_cus * 4;
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
-    const dim3 grid((unsigned)gx, ktiles), block(kTileThreads);
+    const dim3 grid((unsigned)gx, ktiles);
     if (R == 16)
-      hipLaunchKernelGGL((k_score_tile<16, 2, LOO, CRP>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else
-      hipLaunchKernelGGL((k_score_tile<8, 4, LOO, CRP>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
   }
 }

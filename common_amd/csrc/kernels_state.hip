@@ -312,9 +312,33 @@ __global__ __launch_bounds__(256) void k_col_max_u32(const uint32_t *__restrict_
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// per 128-row chunk maximum of a uint32 column, saturated to 16 bits (sizes the gp table copies)
+__global__ __launch_bounds__(128) void k_chunk_max_u32(const uint32_t *__restrict__ col, uint64_t n,
+                                                        uint16_t *__restrict__ out) {
+  __shared__ uint32_t part[2];
+  const uint64_t i = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+  uint32_t m = i < n ? col[i] : 0u;
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t mm = part[0] > part[1] ? part[0] : part[1];
+    out[blockIdx.x] = (uint16_t)(mm > 65535u ? 65535u : mm);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_chunk_max_u32, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, col, n, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev) {
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;

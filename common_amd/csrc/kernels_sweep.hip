@@ -149,20 +149,20 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
 // ---------------------------------------------------------------------------
 // any feature list, K <= 256: the workgroup tile of score_block.hpp, sampled from registers
 // ---------------------------------------------------------------------------
-template <int R, int MINW>
-__global__ __launch_bounds__(kTileThreads, MINW) void k_sweep_tile(const FeatDesc *__restrict__ feats, int nfeat,
+template <int R, int W>
+__global__ __launch_bounds__(W * 64, W / 4) void k_sweep_tile(const FeatDesc *__restrict__ feats, int nfeat,
                                                                  uint32_t K, uint32_t kpad, uint64_t row0,
                                                                  uint64_t nrows, uint64_t row_id0,
                                                                  int32_t *__restrict__ z,
                                                                  const float *__restrict__ own,
                                                                  const float *__restrict__ crp, uint64_t seed,
                                                                  uint64_t sweep) {
-  __shared__ float4 lds[kLdsRows * 64];
+  __shared__ float4 lds[2 * kLdsRows * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = lane * 4;            // single k-tile: K <= 256
   const float4 logcnt = ld4(crp + kb);
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
-  const uint64_t rows_per_wg = (uint64_t)kTileWaves * R;
+  const uint64_t rows_per_wg = (uint64_t)W * R;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kTileThreads, MINW) void k_sweep_tile(const FeatDes
     float4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile<R>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, lds, acc);
+    const uint64_t wg0 = chunk * rows_per_wg;
+    const uint32_t wgn = (uint32_t)((nrows - wg0) < rows_per_wg ? (nrows - wg0) : rows_per_wg);
+    score_tile<R, W>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll
@@ -261,15 +263,15 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_de
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
   if (K > 256) return -2;
   const int R = tile_rows_per_wave();
-  uint64_t gx = (nrows + kTileWaves * R - 1) / (kTileWaves * R);
-  const uint64_t cap = (uint64_t)num_cus * 8;
+  uint64_t gx = (nrows + 127) / 128;
+  const uint64_t cap = (uint64_t)num_cus * 4;
   if (gx > cap) gx = cap;
-  const dim3 grid((unsigned)(gx ? gx : 1)), block(kTileThreads);
+  const dim3 grid((unsigned)(gx ? gx : 1));
   if (R == 16)
-    hipLaunchKernelGGL((k_sweep_tile<16, 2>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<16, 8>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
                        row_id0, z, own, crp, seed, sweep);
   else
-    hipLaunchKernelGGL((k_sweep_tile<8, 4>), grid, block, 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<8, 16>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
                        row_id0, z, own, crp, seed, sweep);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -26,7 +26,7 @@ int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int fam
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad);
 int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
                        float *crp);
-int tile_rows_per_wave();   // 16 (default) or 8 via MSC_TILE_ROWS
+int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
 int launch_loo_own(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
@@ -68,6 +68,7 @@ int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32
                 long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt);
 int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                       uint32_t kpad, float *out);
+int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev);
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
                   uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);

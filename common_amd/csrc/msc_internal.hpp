@@ -90,6 +90,7 @@ struct FeatDesc {
   double aux;              // dd: sum of the alphas
   uint32_t vcap;           // gp: rows of the exact table (min(column max + 1, kGpMaxTable))
   uint32_t pad1;
+  const uint16_t *chunk_max;  // gp: max count of every 128-row chunk of the bound column (null: unknown)
 };
 
 inline uint32_t tab_rows(int family, uint32_t dim) {
@@ -170,6 +171,8 @@ struct msc_dataview {
   std::vector<void *> masks;             // device mask columns or null
   std::vector<void *> owned;             // allocations to free
   mutable std::vector<long long> col_max;  // lazily computed maximum of uint32 columns (-1 = unknown)
+  mutable std::vector<uint16_t *> chunk_max;  // and of every 128-row chunk of them (device, owned)
+  mutable std::vector<void *> owned_lazy;
 };
 
 struct msc_feature_host {

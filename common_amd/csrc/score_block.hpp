@@ -1,15 +1,20 @@
 // score_block.hpp -- the workgroup-tile scorer shared by the batched score kernel and the
 // fused sweep kernel.
 //
-// A workgroup of 8 waves owns 8*R consecutive rows and one k-tile of 256 groups; lane l owns
-// groups 4l..4l+3 of the tile, so every per-group quantity is one 16-byte element per lane.
-// Features are processed one after the other: the workgroup stages the feature's per-group
-// table for the tile into LDS once (bb: 2 rows, nich: 6 constants, dd: one row per category,
-// gp: one row per count; a row = 256 floats = 1 KiB), then every wave adds that feature's
-// scores for its R rows into registers with conflict-free ds_read_b128 (address = row*1 KiB +
-// lane*16 B).  Nothing in here evaluates a transcendental in double: leave-one-out terms
-// arrive precomputed per row (k_loo_own), gp counts beyond the table are patched afterwards
-// (k_gp_large_fix).  Table rows beyond the 64 that fit the LDS block are gathered from L2.
+// A workgroup owns a block of consecutive rows and one tile of groups.  Features are processed
+// one after the other: the feature's per-group table for the tile (bb: 2 rows, nich: 6
+// constants, dd: one row per category, gp: one row per count) is copied into LDS once per
+// workgroup with global_load_lds (double-buffered: the copy of feature f+1 runs under the
+// arithmetic of feature f), then every wave adds that feature's scores for its rows into
+// registers with conflict-free ds_read_b128 (lane <-> 4 groups of a 256-group tile, 1 KiB
+// table rows, 128 rows per workgroup).  Table bytes moved per evaluation are
+// table_rows * 4 B / rows_per_workgroup and the global->LDS path moves ~10 B/clk/CU, which is
+// what bounds a table-heavy state (config C3); a lane <-> 1 group tiling (512 rows per
+// workgroup, 4x fewer table bytes) was measured 2x slower: it triples the per-evaluation
+// instruction count of the lookups.
+// Nothing in here evaluates a transcendental in double: leave-one-out terms arrive precomputed
+// per row (k_loo_own), gp counts beyond the table are patched afterwards (k_gp_large_fix).
+// Table rows beyond the 64 that fit an LDS buffer are gathered from L2.
 #pragma once
 
 #include "family_math.hpp"
@@ -25,9 +30,14 @@ MSC_DEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTileWaves = 8;                 // waves per workgroup of the tile kernels
-constexpr int kTileThreads = kTileWaves * 64;
-constexpr int kLdsRows = 64;                  // table rows staged per feature (64 KiB)
+constexpr int kLdsRows = 64;                  // table rows staged per feature and buffer (64 KiB)
+
+// 16-byte global -> LDS copy that bypasses the VGPRs (global_load_lds_dwordx4): every lane
+// supplies its own source address, the destination is lds_wave_base + lane * 16.
+MSC_DEV void glds16(const float *gsrc, float4 *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
 
 // CRP prior for one row of a k-tile.  e_row = log(alpha / n_empty') for this row (n_empty'
 // counts the row's own group if removing it empties it).
@@ -62,44 +72,87 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
 }
 
 // rows of the feature's table block that go to LDS, and where the block starts in fd.tab
-MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row) {
+// wg_row0 / wg_rows: the absolute row range the workgroup scores in this chunk; for gp only the
+// table rows up to the largest count in that range are worth copying (the per-128-row maxima
+// were computed once when the column was bound).
+MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row, uint64_t wg_row0, uint32_t wg_rows) {
   first_row = 0;
   switch (fd.family) {
     case MSC_BB: return 2;
     case MSC_NICH: return NICH_ROWS;
     case MSC_DD: return fd.dim < (uint32_t)kLdsRows ? fd.dim : (uint32_t)kLdsRows;
-    case MSC_GP: first_row = GP_T0; return fd.vcap < (uint32_t)kLdsRows ? fd.vcap : (uint32_t)kLdsRows;
+    case MSC_GP: {
+      first_row = GP_T0;
+      uint32_t need = fd.vcap;
+      if (fd.chunk_max != nullptr) {
+        uint32_t m = 0;
+        for (uint64_t c = wg_row0 >> 7; c <= (wg_row0 + wg_rows - 1) >> 7; c++) {
+          const uint32_t v = fd.chunk_max[c];
+          m = v > m ? v : m;
+        }
+        need = m + 1 < need ? m + 1 : need;
+      }
+      return need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
+    }
     default: return 0;
   }
 }
 
+// the feature's value of this lane's row, as raw 32 bits (reinterpreted per family)
+MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint64_t row, bool has_row) {
+  if (!has_row || fd.col == nullptr) return 0u;
+  if (fd.family == MSC_BB) return (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
+  if (fd.family == MSC_NIW || fd.family == MSC_NOOP) return 0u;
+  return reinterpret_cast<const uint32_t *>(fd.col)[row];
+}
+
+// issue the async copy of feature fd's table block for this k-tile into buf (no wait)
+template <int W>
+MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t kpad, uint32_t ktile, float4 *buf, uint64_t wg_row0,
+                             uint32_t wg_rows) {
+  uint32_t first_row;
+  const uint32_t nrows_lds = lds_rows_of(fd, first_row, wg_row0, wg_rows);
+  const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t row = wave; row < nrows_lds; row += W)          // one 1 KiB table row per wave instruction
+    glds16(tile + (size_t)row * kpad + 4 * lane, buf + row * 64);
+  return nrows_lds;
+}
+
 // ---------------------------------------------------------------------------
 // acc[r] (+)= sum over features of score_value(row rb+r, groups kb..kb+3).
-// All 8 waves of the workgroup must call this together (it contains barriers); a wave whose
-// rows are out of range passes nr = 0.  lds: kLdsRows * 64 float4.
+// All W waves of the workgroup must call this together (it contains barriers); a wave whose
+// rows are out of range passes nr = 0.  lds: two buffers of kLdsRows * 64 float4.
+// Pipeline per feature f: issue the value load and the table copy of f+1 (buffer (f+1)&1),
+// compute f from buffer f&1, wait for the copies, one barrier.  The value load is issued
+// *before* the table copy because vmcnt retires in order.
 // ---------------------------------------------------------------------------
-template <int R>
+template <int R, int W>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
-                        int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
+                        int lane, uint64_t row_abs0, int nr, uint64_t wg_row0, uint32_t wg_rows,
+                        float4 *__restrict__ lds, float4 (&acc)[R]) {
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
   const uint64_t myrow = row_abs0 + lane;
+  __syncthreads();                                      // the previous chunk's readers are done
+  uint32_t raw = load_raw_value(feats[0], myrow, has_row);
+  uint32_t nrows_lds = stage_table<W>(feats[0], kpad, ktile, lds, wg_row0, wg_rows);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int f = 0; f < nfeat; f++) {
     const FeatDesc fd = feats[f];
-    uint32_t first_row;
-    const uint32_t nrows_lds = lds_rows_of(fd, first_row);
-    const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
-    __syncthreads();                                    // readers of the previous feature are done
-    for (uint32_t idx = threadIdx.x; idx < nrows_lds * 64; idx += kTileThreads)
-      lds[idx] = ld4(tile + (size_t)(idx >> 6) * kpad + 4 * (idx & 63));
-    __syncthreads();
+    const float4 *buf = lds + (size_t)(f & 1) * kLdsRows * 64;
+    uint32_t raw_next = 0, nrows_next = 0;
+    if (f + 1 < nfeat) {
+      raw_next = load_raw_value(feats[f + 1], myrow, has_row);
+      nrows_next = stage_table<W>(feats[f + 1], kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
+    }
     switch (fd.family) {
       case MSC_BB: {
-        const float4 s0 = lds[lane], s1 = lds[64 + lane];
-        const int v = has_row ? (int)(reinterpret_cast<const uint8_t *>(fd.col)[myrow] != 0) : 0;
+        const float4 s0 = buf[lane], s1 = buf[64 + lane];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          const bool vr = lane_bcast(v, r) != 0;
+          const bool vr = lane_bcast((int)raw, r) != 0;
           acc[r].x += vr ? s1.x : s0.x;
           acc[r].y += vr ? s1.y : s0.y;
           acc[r].z += vr ? s1.z : s0.z;
@@ -107,29 +160,28 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
         }
       } break;
       case MSC_DD: {
-        int v = has_row ? reinterpret_cast<const int32_t *>(fd.col)[myrow] : 0;
+        int v = (int)raw;
         v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);       // keep the gather in bounds
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const uint32_t vr = (uint32_t)lane_bcast(v, r);
-          add4(acc[r], vr < nrows_lds ? lds[vr * 64 + lane] : ld4(fd.tab + (size_t)vr * kpad + kb));
+          add4(acc[r], vr < nrows_lds ? buf[vr * 64 + lane] : ld4(fd.tab + (size_t)vr * kpad + kb));
         }
       } break;
       case MSC_GP: {
-        const uint32_t v = has_row ? reinterpret_cast<const uint32_t *>(fd.col)[myrow] : 0u;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          const uint32_t vr = (uint32_t)lane_bcast((int)v, r);
-          if (vr < nrows_lds) add4(acc[r], lds[vr * 64 + lane]);
+          const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
+          if (vr < nrows_lds) add4(acc[r], buf[vr * 64 + lane]);
           else if (vr < fd.vcap) add4(acc[r], ld4(fd.tab + (size_t)(GP_T0 + vr) * kpad + kb));
           // counts beyond the table contribute through k_gp_large_fix
         }
       } break;
       case MSC_NICH: {
-        const float4 mh = lds[NICH_MU_HI * 64 + lane], ml = lds[NICH_MU_LO * 64 + lane],
-                     c0 = lds[NICH_C0 * 64 + lane], c1l = lds[NICH_C1LN2 * 64 + lane],
-                     c1 = lds[NICH_C1 * 64 + lane], c2 = lds[NICH_C2 * 64 + lane];
-        const float xv = has_row ? reinterpret_cast<const float *>(fd.col)[myrow] : 0.0f;
+        const float4 mh = buf[NICH_MU_HI * 64 + lane], ml = buf[NICH_MU_LO * 64 + lane],
+                     c0 = buf[NICH_C0 * 64 + lane], c1l = buf[NICH_C1LN2 * 64 + lane],
+                     c1 = buf[NICH_C1 * 64 + lane], c2 = buf[NICH_C2 * 64 + lane];
+        const float xv = __uint_as_float(raw);
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const float x = lane_bcast(xv, r);
@@ -141,6 +193,10 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
       } break;
       default: break;   // noop contributes 0 (models/noop.hpp:17); niw has its own MFMA pass
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // table f+1 has landed (this wave's share)
+    __syncthreads();                                    // ... everyone's share; buffer f&1 is free again
+    raw = raw_next;
+    nrows_lds = nrows_next;
   }
 }
 
