@@ -57,6 +57,22 @@ def cpu_baseline(K, sample_rows):
     }
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_pmc.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc passes)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, e in d.items():
+            if kernel_substr in name and "hbm_bytes_per_launch" in e:
+                best = (e["hbm_bytes_per_launch"]["total"], os.path.basename(f))
+    return best
+
+
 def main():
     a = parse()
     import torch
@@ -135,7 +151,9 @@ def main():
                                    "[N,K] f32 scores materialised" % (N, K),
                        "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (pmc_traffic("k_score_nich1") or (None, None))[0] if (N, K) == (1_000_000, 256) else None,
+                         "traffic_source": (pmc_traffic("k_score_nich1") or (None, None))[1],
                          "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes},
         }

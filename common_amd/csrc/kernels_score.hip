@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
 // single NICH feature (config C2 / C5 scoring pass)
 //   grid.x = row chunks (grid-stride), grid.y = k-tiles, block = 4 waves
 // ---------------------------------------------------------------------------
-template <bool LOO, bool CRP>
+template <bool LOO, bool CRP, int CH, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
@@ -155,12 +155,12 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   }
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
-  const uint64_t nchunks = (nrows + 63) / 64;
+  const uint64_t nchunks = (nrows + CH - 1) / CH;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
-    const uint64_t rb = chunk * 64;
-    const int nr = (int)((nrows - rb) < 64 ? (nrows - rb) : 64);
+    const uint64_t rb = chunk * CH;
+    const int nr = (int)((nrows - rb) < (uint64_t)CH ? (nrows - rb) : (uint64_t)CH);
     const float xv = lane < nr ? xcol[rb + lane] : 0.0f;
     int gz = -1;
     float sloo = 0, erow = le0;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
         const int g = lane_bcast(gz, r);
         if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
       }
-      store_row(out, ld, rb + r, kb, K, s, vec_ok);
+      store_row<NT>(out, ld, rb + r, kb, K, s, vec_ok);
     }
   }
 }
@@ -318,12 +318,15 @@ static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const Fe
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (nich1) {
-    const uint64_t nchunks = (nrows + 63) / 64;
+    // 32 rows per wave chunk, non-temporal stores and a 64-workgroups-per-CU grid cap measured
+    // best on C2 (profiles/r01_nich1_variants.txt): 5.5 TB/s vs 5.3 (64-row chunks), 5.1 (plain stores)
+    constexpr int kChunk = 32;
+    const uint64_t nchunks = (nrows + kChunk - 1) / kChunk;
     uint64_t gx = (nchunks + 3) / 4;
-    const uint64_t cap = (uint64_t)num_cus * 16;
+    const uint64_t cap = (uint64_t)num_cus * 64;
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL((k_score_nich1<LOO, CRP>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, kChunk, true>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
                        feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:

@@ -57,12 +57,14 @@ MSC_DEV void replace_own(float4 &s, uint32_t kb, int g, float v) {
 }
 MSC_DEV void add4(float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
+template <bool NT = true>
 MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint32_t kb, uint32_t K,
                        float4 s, bool vec_ok) {
   float *p = out + row * ld + kb;
   if (vec_ok && kb + 3 < K) {
     const f32x4 v = {s.x, s.y, s.z, s.w};
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<f32x4 *>(p) = v;
   } else {
     if (kb < K) p[0] = s.x;
     if (kb + 1 < K) p[1] = s.y;
