@@ -1,0 +1,157 @@
+"""GPU parity at BASELINE.json's full sizes, through size-independent properties plus oracle checks
+on a seeded sample of rows (the oracle is a scalar CPU restatement: it cannot score 2.56e8 pairs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rows(fam, dim, hp, ss_rec, values, rows, z=None):
+    F = orc.Family(fam, hp, dim, "f64")
+    ss64 = np.zeros(ss_rec.shape[0], dtype=orc.ss_dtype(fam, dim, "f64"))
+    for name in ss_rec.dtype.names:
+        ss64[name] = ss_rec[name]
+    return F.score_matrix(ss64, values[rows], None if z is None else z[rows])
+
+
+def test_c2_nich_1m_rows_256_groups(gpu_ctx):
+    import common_amd
+    N, K = 1_000_000, 256
+    dev = gpu_ctx.torch_device
+    g = torch.Generator(device=dev)
+    g.manual_seed(73)
+    centres = torch.randn(K, generator=g, device=dev) * 10
+    z = torch.randint(0, K, (N,), generator=g, device=dev, dtype=torch.int32)
+    x = (centres[z.long()] + torch.randn(N, generator=g, device=dev)).float()
+    x[N // 2:] = x[:N // 2]                      # second half duplicates the first half row for row
+    z[N // 2:] = z[:N // 2]
+    x = x.contiguous()
+    view = common_amd.DataView.from_tensors(gpu_ctx, [x])
+    st = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    st.accumulate(view, z)
+    xh, zh = x.cpu().numpy(), z.cpu().numpy()
+    # suff-stats: counts bit-exact, mean / ctv vs a float64 two-pass computation
+    rec = st.get_ss(0)
+    cnt = np.bincount(zh, minlength=K)
+    assert np.array_equal(rec["count"], cnt) and np.array_equal(st.get_group_counts(), cnt)
+    sx = np.bincount(zh, weights=xh.astype(np.float64), minlength=K)
+    mean = sx / cnt
+    ctv = np.bincount(zh, weights=(xh.astype(np.float64) - mean[zh]) ** 2, minlength=K)
+    assert rel_err(rec["mean"], mean).max() <= TOL and rel_err(rec["count_times_variance"], ctv).max() <= TOL
+    out = st.score_value(view)
+    assert out.shape == (N, K) and bool(torch.isfinite(out).all())
+    # property: identical rows give bit-identical score rows, wherever they sit in the launch
+    assert torch.equal(out[:N // 2], out[N // 2:])
+    # property: a second pass is bit-identical (no order-dependent arithmetic in the score kernel)
+    assert torch.equal(out, st.score_value(view))
+    # oracle on a seeded sample of rows (plain and leave-one-out)
+    rows = np.random.default_rng(5).choice(N, 2048, replace=False)
+    hp = dict(mu=0., kappa=1., sigmasq=1., nu=1.)
+    want = _oracle_rows(orc.NICH, 0, hp, rec, xh, rows)
+    assert rel_err(out[torch.from_numpy(rows).to(dev)].cpu().numpy(), want).max() <= TOL
+    loo = st.score_value(view, z=z)
+    want = _oracle_rows(orc.NICH, 0, hp, rec, xh, rows, zh)
+    assert rel_err(loo[torch.from_numpy(rows).to(dev)].cpu().numpy(), want).max() <= TOL
+    # leave-one-out differs from the plain score exactly in the row's own column
+    diff = (loo != out)
+    assert int(diff.sum()) <= N and bool(diff[torch.arange(N, device=dev), z.long()].float().mean() > 0.99)
+    # a sweep keeps every row assigned to a valid group and the tables consistent with it
+    zs = z.clone()
+    drv = common_amd.dist.ShardedSweep(st, view, zs, 0)
+    drv.sweep(seed=73, sweep_index=0)
+    zn = zs.cpu().numpy()
+    assert zn.min() >= 0 and zn.max() < K
+    assert np.array_equal(st.get_group_counts(), np.bincount(zn, minlength=K))
+    # 256 unit-variance clusters with centres ~N(0, 10^2) overlap heavily, so rows do move, but a
+    # row is still far likelier to keep its group than to land on a uniformly random one
+    assert (zn == zh).mean() > 10.0 / K
+
+
+def test_c3_mixed_64_columns_1m_rows(gpu_ctx):
+    import common_amd
+    from tools.bench_configs import make_columns
+    N, K = 1_000_000, 256
+    spec = [(common_amd.BB, 0), (common_amd.GP, 0), (common_amd.DD, 32), (common_amd.NICH, 0)] * 16
+    cols, z = make_columns(gpu_ctx, spec, N, K, 7)
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols)
+    st = common_amd.State(gpu_ctx, spec, K)
+    st.accumulate(view, z)
+    out = st.score_value(view)
+    assert bool(torch.isfinite(out).all())
+    zh = z.cpu().numpy()
+    rows = np.random.default_rng(6).choice(N, 256, replace=False)
+    want = np.zeros((len(rows), K))
+    for f, (fam, dim) in enumerate(spec):
+        v = cols[f].cpu().numpy()
+        if fam == common_amd.GP:
+            v = v.view(np.uint32)
+        rec = st.get_ss(f)
+        hp = {orc.BB: dict(alpha=1., beta=1.), orc.GP: dict(alpha=1., inv_beta=1.),
+              orc.DD: dict(alphas=[1.] * 32), orc.NICH: dict(mu=0., kappa=1., sigmasq=1., nu=1.)}[fam]
+        want += _oracle_rows(fam, dim, hp, rec, v, rows)
+        if fam in (common_amd.BB, common_amd.DD):       # integer suff-stats bit-exact at full size
+            if fam == common_amd.BB:
+                assert np.array_equal(rec["heads"], np.bincount(zh, weights=v.astype(np.float64), minlength=K).astype(np.uint32))
+            else:
+                assert np.array_equal(rec["count_sum"], np.bincount(zh, minlength=K))
+    assert rel_err(out[torch.from_numpy(rows).to(gpu_ctx.torch_device)].cpu().numpy(), want).max() <= TOL
+
+
+def test_c4_niw_256k_rows_dim32(gpu_ctx):
+    import common_amd
+    from tools.bench_configs import make_columns
+    N, K, d = 262_144, 128, 32
+    cols, z = make_columns(gpu_ctx, [(common_amd.NIW, d)], N, K, 9)
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols)
+    st = common_amd.State(gpu_ctx, [(common_amd.NIW, d)], K)
+    st.accumulate(view, z)
+    out = st.score_value(view)
+    assert bool(torch.isfinite(out).all())
+    rec = st.get_ss(0)
+    zh, xh = z.cpu().numpy(), cols[0].cpu().numpy()
+    assert np.array_equal(rec["count"], np.bincount(zh, minlength=K))
+    sx = np.zeros((K, d))
+    np.add.at(sx, zh, xh.astype(np.float64))
+    assert rel_err(rec["sum_x"], sx).max() <= TOL
+    rows = np.random.default_rng(8).choice(N, 96, replace=False)
+    hp = dict(mu=np.zeros(d), kappa=1.0, psi=np.eye(d), nu=float(d))
+    want = _oracle_rows(orc.NIW, d, hp, rec, xh, rows)
+    assert rel_err(out[torch.from_numpy(rows).to(gpu_ctx.torch_device)].cpu().numpy(), want).max() <= TOL
+    fast = st.score_value(view, niw_f32=True)
+    assert rel_err(fast[torch.from_numpy(rows).to(gpu_ctx.torch_device)].cpu().numpy(), want).max() <= 2e-5
+
+
+def test_c5_shard_shape_k1024_sweep_only(gpu_ctx):
+    """one GPU's share of config C5 in shape (K = 1024), rows cut to 2M: fused sweep, no score matrix"""
+    import common_amd
+    N, K = 2_000_000, 1024
+    dev = gpu_ctx.torch_device
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    centres = torch.randn(K, generator=g, device=dev) * 30
+    z = torch.randint(0, K, (N,), generator=g, device=dev, dtype=torch.int32)
+    x = (centres[z.long()] + torch.randn(N, generator=g, device=dev)).float().contiguous()
+    view = common_amd.DataView.from_tensors(gpu_ctx, [x])
+    st = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    zs = z.clone()
+    drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=0)
+    drv.rebuild_tables()
+    drv.sweep(seed=3, sweep_index=0)
+    zn = zs.cpu().numpy()
+    assert zn.min() >= 0 and zn.max() < K
+    assert np.array_equal(st.get_group_counts(), np.bincount(zn, minlength=K))
+    # the fused kernel agrees with sampling the materialised leave-one-out scores of the same rows
+    st2 = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    st2.accumulate(view, z)
+    rows = slice(100_000, 100_512)
+    sc = st2.score_value(view, row0=100_000, nrows=512, z=z[rows].contiguous(), crp_prior=True).cpu().numpy()
+    mism = 0
+    for i in range(512):
+        p = orc.scores_to_probs(sc[i].astype(np.float64))
+        pick = orc.sample_discrete(p, orc.uniform01(3, 0, 100_000 + i))
+        mism += int(pick != zn[100_000 + i])
+    assert mism <= 3, mism
