@@ -84,8 +84,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal knob for a 1-GPU box: MSC_BENCH_BACKEND=gloo puts every rank on cuda:0
+        backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
     const uint64_t rb = blk * 32 * T;
     float xr[T][16];
     int gz[T];
-    bool live[T];
+    bool live[T], msk[T];
 #pragma unroll
     for (int t = 0; t < T; t++) {
       const uint64_t row = rb + 32 * t + r;          // relative to row0
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
         for (int s = 0; s < 16; s++) xr[t][s] = (live[t] && (uint32_t)(16 * h + s) < d) ? xp[s] : 0.0f;
       }
       gz[t] = (LOO && live[t]) ? z[row] : -1;
+      msk[t] = false;
+      if (live[t] && fd.mask != nullptr)
+        for (uint32_t e = 0; e < d; e++) msk[t] |= fd.mask[(row0 + row) * d + e] != 0;
     }
     float4 pend[T];
     for (uint32_t k = 0; k < K; k++) {
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
           const float y = fminf(cl * q, 0.99999994f);
           sc = fmaf(bl, log1p_acc(-y), al);
         }
+        if (msk[t]) sc = 0.f;
         if (mine) {
           if (slot == 0) pend[t].x = sc;
           else if (slot == 1) pend[t].y = sc;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
     const uint64_t rb = blk * 16 * JB;
     float xr[JB][8];
     int gz[JB];
-    bool live[JB];
+    bool live[JB], msk[JB];
 #pragma unroll
     for (int jb = 0; jb < JB; jb++) {
       const uint64_t row = rb + 16 * jb + c;
@@ -311,6 +315,9 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
         for (int s = 0; s < 8; s++) xr[jb][s] = (live[jb] && (uint32_t)(8 * kk + s) < d) ? xp[s] : 0.0f;
       }
       gz[jb] = (LOO && live[jb]) ? z[row] : -1;
+      msk[jb] = false;
+      if (live[jb] && fd.mask != nullptr)
+        for (uint32_t e = 0; e < d; e++) msk[jb] |= fd.mask[(row0 + row) * d + e] != 0;
     }
     float4 pend[JB];
     for (uint32_t k = 0; k < K; k++) {
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
         const double q = qp + shfl_xor_f64(qp, 32);
         double sc = c0 - c1 * log1p(q);
         if (LOO && gz[jb] == (int)k) sc = al + bl * log1p(-fmin(cl * q, 1.0 - 1e-15));
+        if (msk[jb]) sc = 0.0;
         if (mine) {
           const float scf = (float)sc;
           if (slot == 0) pend[jb].x = scf;
@@ -392,6 +400,11 @@ __global__ __launch_bounds__(256) void k_niw_accumulate(const FeatDesc *__restri
   for (uint64_t n = wave_id; n < nrows; n += nwaves) {
     const int g = z[n];
     if (g < 0 || (uint32_t)g >= K) continue;
+    if (fd.mask != nullptr) {
+      bool m = false;
+      for (uint32_t e = lane; e < d; e += 64) m |= fd.mask[(row0 + n) * d + e] != 0;
+      if (__builtin_amdgcn_ballot_w64(m) != 0ull) continue;
+    }
     const float *x = X + (row0 + n) * d;
     double *dst = fd.acc_f64 + (size_t)g * stride;
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[g]), (unsigned long long)(long long)sign);

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   }
   for (int f = 0; f < nfeat; f++) {
     const FeatDesc fd = feats[f];
+    if (fd.mask != nullptr && fd.family != MSC_NIW && fd.mask[row] != 0) continue;
     switch (fd.family) {
       case MSC_BB:
         s += bb_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
@@ -162,6 +163,8 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
     const uint64_t rb = chunk * CH;
     const int nr = (int)((nrows - rb) < (uint64_t)CH ? (nrows - rb) : (uint64_t)CH);
     const float xv = lane < nr ? xcol[rb + lane] : 0.0f;
+    const unsigned long long mbits =
+        __builtin_amdgcn_ballot_w64(fd.mask != nullptr && lane < nr && fd.mask[row0 + rb + lane] != 0);
     int gz = -1;
     float sloo = 0, erow = le0;
     if (LOO && lane < nr) {
@@ -172,11 +175,13 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
 #pragma unroll 4
     for (int r = 0; r < nr; r++) {
       const float x = lane_bcast(xv, r);
-      float4 s;
-      s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-      s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-      s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-      s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+      float4 s = make_float4(0, 0, 0, 0);
+      if (!((mbits >> r) & 1ull)) {
+        s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+        s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+        s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+        s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+      }
       if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
       if (LOO) {
         const int g = lane_bcast(gz, r);
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
   const double al = fd.hp[0], ib = fd.hp[1];
   for (uint64_t n = wave_id; n < nrows; n += nwaves) {
     const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row0 + n];
-    if (v < fd.vcap) continue;
+    if (v < fd.vcap || (fd.mask != nullptr && fd.mask[row0 + n] != 0)) continue;
     const int g = z ? z[n] : -1;
     const double rowc = gp_row_const(v);
     for (uint32_t k = lane; k < K; k += 64) {

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
         const int g = z[n];
         if (g < 0 || (uint32_t)g >= K) continue;
         const uint64_t row = row0 + n;
+        if (fd.mask != nullptr && fd.mask[row] != 0) continue;       // masked value: not part of the group
         switch (fd.family) {
           case MSC_BB: {
             const bool v = reinterpret_cast<const uint8_t *>(fd.col)[row] != 0;

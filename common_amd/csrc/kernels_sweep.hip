@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     const float xv = has_row ? xcol[rb + lane] : 0.0f;
     const int gz = has_row ? z[rb + lane] : -1;
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    const unsigned long long mbits =
+        __builtin_amdgcn_ballot_w64(fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0);
     float sloo = 0.f, erow = le0;
     if (gz >= 0) {
       erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
@@ -130,11 +132,12 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     for (int r = 0; r < nr; r++) {
       const float x = lane_bcast(xv, r), e = lane_bcast(erow, r), sl = lane_bcast(sloo, r);
       const int g = lane_bcast(gz, r);
+      const bool masked = (mbits >> r) & 1ull;          // masked value: only the prior speaks
       float s[G];
 #pragma unroll
       for (int j = 0; j < G; j++) {
         const float prior = __builtin_isinf(lc[j]) ? e : lc[j];
-        float v = nich_eval(x, mh[j], ml[j], c0[j], c1l[j], c1[j], c2[j]) + prior;
+        float v = (masked ? 0.f : nich_eval(x, mh[j], ml[j], c0[j], c1l[j], c1[j], c2[j])) + prior;
         if ((int)(kb + j) == g) v = sl;
         if (kb + j >= K) v = -INFINITY;
         s[j] = v;

@@ -108,6 +108,16 @@ MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint64_t row, bool has_row) 
   return reinterpret_cast<const uint32_t *>(fd.col)[row];
 }
 
+// is this lane's row masked for the feature?  (one mask byte per element, runtime_type.hpp:131;
+// a masked value takes no part in scoring or in the suff-stats, as the reference's callers skip it)
+MSC_DEV bool load_masked(const FeatDesc &fd, uint64_t row, bool has_row) {
+  if (!has_row || fd.mask == nullptr) return false;
+  if (fd.family != MSC_NIW) return fd.mask[row] != 0;
+  bool m = false;
+  for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
+  return m;
+}
+
 // issue the async copy of feature fd's table block for this k-tile into buf (no wait)
 template <int W>
 MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t kpad, uint32_t ktile, float4 *buf, uint64_t wg_row0,
@@ -138,6 +148,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
   const uint64_t myrow = row_abs0 + lane;
   __syncthreads();                                      // the previous chunk's readers are done
   uint32_t raw = load_raw_value(feats[0], myrow, has_row);
+  unsigned long long mbits = __builtin_amdgcn_ballot_w64(load_masked(feats[0], myrow, has_row));
   uint32_t nrows_lds = stage_table<W>(feats[0], kpad, ktile, lds, wg_row0, wg_rows);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -145,8 +156,10 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
     const FeatDesc fd = feats[f];
     const float4 *buf = lds + (size_t)(f & 1) * kLdsRows * 64;
     uint32_t raw_next = 0, nrows_next = 0;
+    unsigned long long mbits_next = 0ull;
     if (f + 1 < nfeat) {
       raw_next = load_raw_value(feats[f + 1], myrow, has_row);
+      mbits_next = __builtin_amdgcn_ballot_w64(load_masked(feats[f + 1], myrow, has_row));
       nrows_next = stage_table<W>(feats[f + 1], kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
     }
     switch (fd.family) {
@@ -154,6 +167,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
         const float4 s0 = buf[lane], s1 = buf[64 + lane];
 #pragma unroll
         for (int r = 0; r < R; r++) {
+          if ((mbits >> r) & 1ull) continue;
           const bool vr = lane_bcast((int)raw, r) != 0;
           acc[r].x += vr ? s1.x : s0.x;
           acc[r].y += vr ? s1.y : s0.y;
@@ -166,6 +180,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
         v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);       // keep the gather in bounds
 #pragma unroll
         for (int r = 0; r < R; r++) {
+          if ((mbits >> r) & 1ull) continue;
           const uint32_t vr = (uint32_t)lane_bcast(v, r);
           add4(acc[r], vr < nrows_lds ? buf[vr * 64 + lane] : ld4(fd.tab + (size_t)vr * kpad + kb));
         }
@@ -173,6 +188,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
       case MSC_GP: {
 #pragma unroll
         for (int r = 0; r < R; r++) {
+          if ((mbits >> r) & 1ull) continue;
           const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
           if (vr < nrows_lds) add4(acc[r], buf[vr * 64 + lane]);
           else if (vr < fd.vcap) add4(acc[r], ld4(fd.tab + (size_t)(GP_T0 + vr) * kpad + kb));
@@ -186,6 +202,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
         const float xv = __uint_as_float(raw);
 #pragma unroll
         for (int r = 0; r < R; r++) {
+          if ((mbits >> r) & 1ull) continue;
           const float x = lane_bcast(xv, r);
           acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
           acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
@@ -198,6 +215,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // table f+1 has landed (this wave's share)
     __syncthreads();                                    // ... everyone's share; buffer f&1 is free again
     raw = raw_next;
+    mbits = mbits_next;
     nrows_lds = nrows_next;
   }
 }
