@@ -36,7 +36,7 @@ size_t primitive_size(int t) {
   return (t >= 0 && t < MSC_TYPE_NELEMS) ? sz[t] : 0;
 }
 
-static bool family_ok(int f) { return f >= MSC_BB && f <= MSC_NOOP; }
+static bool family_ok(int f) { return f >= MSC_BB && f <= MSC_BBNC; }
 
 template <typename T>
 static int dev_alloc(std::vector<void *> &owned, T **out, size_t count) {
@@ -244,6 +244,7 @@ extern "C" int msc_dataview_column(const msc_dataview *view, uint32_t feature, v
 extern "C" size_t msc_hp_floats(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
     case MSC_GP: return 2;
     case MSC_DD: return dim;
     case MSC_NICH: return 4;
@@ -255,6 +256,7 @@ extern "C" size_t msc_hp_floats(int family, uint32_t dim) {
 extern "C" size_t msc_ss_bytes(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 8;
+    case MSC_BBNC: return 12;
     case MSC_GP: return 12;
     case MSC_DD: return 4 * (1 + (size_t)dim);
     case MSC_NICH: return 12;
@@ -268,6 +270,7 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
   hp.assign(msc_hp_floats(family, dim), 0.f);
   switch (family) {
     case MSC_BB: hp[0] = 1; hp[1] = 1; break;
+    case MSC_BBNC: hp[0] = 1; hp[1] = 1; break;
     case MSC_GP: hp[0] = 1; hp[1] = 1; break;
     case MSC_DD: std::fill(hp.begin(), hp.end(), 1.f); break;
     case MSC_NICH: hp[0] = 0; hp[1] = 1; hp[2] = 1; hp[3] = 1; break;
@@ -887,7 +890,7 @@ extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, i
   if (family == MSC_DD) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dd dim %u outside 1..%u", dim, kMaxDDDim);
   if (family == MSC_NIW) MSC_REQUIRE(dim >= 1 && dim <= 32, "niw dim %u outside 1..32", dim);
   const size_t hp_bytes = msc_hp_floats(family, dim) * sizeof(float), ss_bytes = msc_ss_bytes(family, dim);
-  const size_t v_bytes = family == MSC_BB ? 1 : family == MSC_NIW ? 4 * (size_t)dim : 4;
+  const size_t v_bytes = (family == MSC_BB || family == MSC_BBNC) ? 1 : family == MSC_NIW ? 4 * (size_t)dim : 4;
   auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
   MailboxHeader hd;
   hd.family = family; hd.dim = (int32_t)dim; hd.op = op; hd.status = 0; hd.score = 0.f;

@@ -71,6 +71,19 @@ MSC_DEV double bb_score_data(const float *hp, uint32_t heads, uint32_t tails) {
          lgamma(b);
 }
 
+// ============== non-conjugate Beta-Bernoulli (src/models/bbnc.cpp:22-73) =================
+// the group carries an explicit p; counts only enter score_data
+MSC_DEV void bbnc_prepare(float p, float &s0, float &s1) {
+  s0 = (float)log(1.0 - (double)p);
+  s1 = (float)log((double)p);
+}
+MSC_DEV double bbnc_score_data(const float *hp, uint32_t heads, uint32_t tails, float pf) {
+  const double p = pf, a = hp[0], b = hp[1];
+  if (p < 0.0 || p > 1.0) return -INFINITY;
+  const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+  return (a - 1.0) * log(p) + (b - 1.0) * log(1.0 - p) - lbeta + (double)heads * log(p) + (double)tails * log(1.0 - p);
+}
+
 // ============================ Dirichlet-Discrete ============================
 // tab rows: i in [0, dim) -> log p(v = i)
 MSC_DEV float dd_prepare_entry(float alpha_i, uint32_t count_i, double alpha_sum, uint32_t count_sum) {

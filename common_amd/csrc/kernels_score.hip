@@ -37,6 +37,12 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       fd.tab[k] = s0;
       fd.tab[kpad + k] = s1;
     } break;
+    case MSC_BBNC: {
+      float s0, s1;
+      bbnc_prepare(fd.raw_f32[k], s0, s1);
+      fd.tab[k] = s0;
+      fd.tab[kpad + k] = s1;
+    } break;
     case MSC_GP: {
       const uint32_t cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
       gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
@@ -110,6 +116,9 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
     switch (fd.family) {
       case MSC_BB:
         s += bb_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
+        break;
+      case MSC_BBNC:     // p does not move when a row leaves
+        s += log(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? (double)fd.raw_f32[g] : 1.0 - (double)fd.raw_f32[g]);
         break;
       case MSC_GP:
         s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);

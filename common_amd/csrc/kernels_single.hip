@@ -116,6 +116,13 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
           score = log((v ? a + hh : b + tt) / (a + b + hh + tt));
         } else score = bb_score_data(hp, su[0], su[1]);
       } break;
+      case MSC_BBNC: {       // record {u32 heads, u32 tails, f32 p}
+        const bool v = val[0] != 0;
+        if (op == MSC_OP_ADD) su[v ? 0 : 1]++;
+        else if (op == MSC_OP_REMOVE) su[v ? 0 : 1]--;
+        else if (op == MSC_OP_SCORE_VALUE) score = log(v ? (double)sf[2] : 1.0 - (double)sf[2]);
+        else score = bbnc_score_data(hp, su[0], su[1], sf[2]);
+      } break;
       case MSC_GP: {
         const uint32_t v = *reinterpret_cast<const uint32_t *>(val);
         if (op == MSC_OP_ADD) { su[0]++; su[1] += v; sf[2] += (float)lgamma((double)v + 1.0); }

@@ -20,6 +20,7 @@ struct AccShape { uint32_t nu32, nu64, nf64; };
 __device__ __host__ inline AccShape acc_shape(int family, uint32_t dim_slice) {
   switch (family) {
     case MSC_BB: return {2, 0, 0};
+    case MSC_BBNC: return {2, 0, 0};
     case MSC_GP: return {1, 1, 1};
     case MSC_DD: return {dim_slice, 0, 0};
     case MSC_NICH: return {1, 0, 2};
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
         const uint64_t row = row0 + n;
         if (fd.mask != nullptr && fd.mask[row] != 0) continue;       // masked value: not part of the group
         switch (fd.family) {
+          case MSC_BBNC:
           case MSC_BB: {
             const bool v = reinterpret_cast<const uint8_t *>(fd.col)[row] != 0;
             atomicAdd(&u32[(v ? 0 : K) + g], 1u);
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void k_commit(const FeatDesc *__restrict__ fea
   }
   const FeatDesc fd = feats[blockIdx.y];
   switch (fd.family) {
+    case MSC_BBNC:
     case MSC_BB:
       fd.raw_u32[k] = (uint32_t)fd.acc_i64[k];
       fd.raw_u32[kpad + k] = (uint32_t)fd.acc_i64[kpad + k];
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256) void k_lift(const FeatDesc *__restrict__ feats
   const FeatDesc fd = feats[blockIdx.y];
   if (fd.acc_i64 == nullptr) return;   // feature already in sync (host passes null to skip)
   switch (fd.family) {
+    case MSC_BBNC:
     case MSC_BB:
       fd.acc_i64[k] = fd.raw_u32[k];
       fd.acc_i64[kpad + k] = fd.raw_u32[kpad + k];
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256) void k_score_data(const FeatDesc *__restrict__
   double s = 0;
   switch (fd.family) {
     case MSC_BB: s = bb_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k]); break;
+    case MSC_BBNC: s = bbnc_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], fd.raw_f32[k]); break;
     case MSC_GP: s = gp_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], (double)fd.raw_f32[k]); break;
     case MSC_DD: {
       double asum = 0;

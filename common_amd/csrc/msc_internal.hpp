@@ -96,6 +96,7 @@ struct FeatDesc {
 inline uint32_t tab_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
     case MSC_GP: return 2 + kGpMaxTable;   // GP_T0 + table rows (family_math.hpp)
     case MSC_DD: return dim;
     case MSC_NICH: return 6; // NICH_ROWS
@@ -106,6 +107,7 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
 inline uint32_t raw_u32_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
     case MSC_GP: return 2;
     case MSC_DD: return 1 + dim;
     case MSC_NICH: return 1;
@@ -117,6 +119,7 @@ inline uint32_t raw_u32_rows(int family, uint32_t dim) {
 inline uint32_t raw_f32_rows(int family) {
   switch (family) {
     case MSC_GP: return 1;
+    case MSC_BBNC: return 1;   // p
     case MSC_NICH: return 2;
     default: return 0;
   }
@@ -124,6 +127,7 @@ inline uint32_t raw_f32_rows(int family) {
 inline uint32_t acc_i64_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
     case MSC_GP: return 2;
     case MSC_DD: return dim;
     case MSC_NICH: return 1;
@@ -141,6 +145,7 @@ inline uint32_t acc_f64_rows(int family) {
 inline int value_type_of(int family) {
   switch (family) {
     case MSC_BB: return MSC_TYPE_B;
+    case MSC_BBNC: return MSC_TYPE_B;
     case MSC_GP: return MSC_TYPE_U32;
     case MSC_DD: return MSC_TYPE_I32;
     case MSC_NICH: return MSC_TYPE_F32;

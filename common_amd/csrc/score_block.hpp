@@ -81,6 +81,7 @@ MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row, uint64_t w
   first_row = 0;
   switch (fd.family) {
     case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
     case MSC_NICH: return NICH_ROWS;
     case MSC_DD: return fd.dim < (uint32_t)kLdsRows ? fd.dim : (uint32_t)kLdsRows;
     case MSC_GP: {
@@ -103,7 +104,7 @@ MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row, uint64_t w
 // the feature's value of this lane's row, as raw 32 bits (reinterpreted per family)
 MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint64_t row, bool has_row) {
   if (!has_row || fd.col == nullptr) return 0u;
-  if (fd.family == MSC_BB) return (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
+  if (fd.family == MSC_BB || fd.family == MSC_BBNC) return (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
   if (fd.family == MSC_NIW || fd.family == MSC_NOOP) return 0u;
   return reinterpret_cast<const uint32_t *>(fd.col)[row];
 }
@@ -163,6 +164,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
       nrows_next = stage_table<W>(feats[f + 1], kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
     }
     switch (fd.family) {
+      case MSC_BBNC:
       case MSC_BB: {
         const float4 s0 = buf[lane], s1 = buf[64 + lane];
 #pragma unroll

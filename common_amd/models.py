@@ -3,7 +3,7 @@
 Same names (`bb`, `bnb`, `gp`, `nich`, `dd(n)`, `niw(d)`, ...), same accessor
 methods and the same default hyper-parameters; `c_desc()` returns the handle the
 HIP state consumes (family tag + dimension) instead of a `shared_ptr[model]`.
-Descriptors the HIP path does not build yet (`bnb`, `bbnc`, `dm`)
+Descriptors the HIP path does not build yet (`bnb`, `dm`)
 exist for name/pickle compatibility and raise when asked for a c_desc.
 """
 import itertools as it
@@ -115,7 +115,7 @@ gp = model_descriptor("gp", py_model(np.uint32), c_model(L.GP), {"alpha": 1., "i
                       _grid2("alpha", "inv_beta"))
 nich = model_descriptor("nich", py_model(np.float32), c_model(L.NICH),
                         {"mu": 0., "kappa": 1., "sigmasq": 1., "nu": 1.}, {}, _nich_grid())
-bbnc = model_descriptor("bbnc", py_model(np.bool_), None, bb._default_hyperparams, {},
+bbnc = model_descriptor("bbnc", py_model(np.bool_), c_model(L.BBNC), bb._default_hyperparams, {},
                         bb._default_partial_hypergrid)
 noop = model_descriptor("noop", py_model(np.bool_), c_model(L.NOOP), {}, {}, [])
 

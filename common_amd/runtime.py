@@ -26,7 +26,7 @@ for _n, _t in (("uint16", L.TYPE_U16), ("uint32", L.TYPE_U32), ("uint64", L.TYPE
         _TYPE_OF_TORCH[getattr(torch, _n)] = _t
         _TORCH_OF_TYPE[_t] = getattr(torch, _n)
 
-VALUE_TYPE = {L.BB: L.TYPE_B, L.GP: L.TYPE_U32, L.DD: L.TYPE_I32, L.NICH: L.TYPE_F32,
+VALUE_TYPE = {L.BB: L.TYPE_B, L.BBNC: L.TYPE_B, L.GP: L.TYPE_U32, L.DD: L.TYPE_I32, L.NICH: L.TYPE_F32,
               L.NIW: L.TYPE_F32, L.NOOP: L.TYPE_B}
 
 
@@ -196,6 +196,8 @@ def ss_dtype(family, dim=0):
     """numpy record of one group's suff-stats as msc_state_set_ss / get_ss exchange it."""
     if family == L.BB:
         return np.dtype([("heads", np.uint32), ("tails", np.uint32)])
+    if family == L.BBNC:
+        return np.dtype([("heads", np.uint32), ("tails", np.uint32), ("p", np.float32)])
     if family == L.GP:
         return np.dtype([("count", np.uint32), ("sum", np.uint32), ("log_prod", np.float32)])
     if family == L.DD:
@@ -212,7 +214,7 @@ def pack_hp(family, hp, dim=0):
     """dict keyed as microscopes/models.pyx:185-290 -> the flat float block of the ABI."""
     if isinstance(hp, np.ndarray):
         return np.ascontiguousarray(hp, dtype=np.float32)
-    if family == L.BB:
+    if family in (L.BB, L.BBNC):
         v = [hp["alpha"], hp["beta"]]
     elif family == L.GP:
         v = [hp["alpha"], hp["inv_beta"]]

@@ -96,6 +96,23 @@ struct NormalInverseWishartV {
   };
 };
 
+// tag for the in-tree non-conjugate Beta-Bernoulli (src/models/bbnc.cpp): p lives in the group
+struct BetaBernoulliNonConj {
+  typedef bool Value;
+  struct Shared { float alpha = 0.f, beta = 0.f; };
+  struct Group {
+    uint32_t heads = 0, tails = 0;   // {heads, tails, p}: the ABI record
+    float p = 0.5f;
+    void init(const Shared &s, rng_t &rng) {
+      heads = tails = 0;
+      // p ~ Beta(alpha, beta) as the ratio of two gamma draws (bbnc.cpp:129-133 uses sample_beta)
+      const float x = std::gamma_distribution<float>(s.alpha > 0 ? s.alpha : 1.f, 1.f)(rng);
+      const float y = std::gamma_distribution<float>(s.beta > 0 ? s.beta : 1.f, 1.f)(rng);
+      p = x / (x + y);
+    }
+  };
+};
+
 }  // namespace distributions
 
 namespace microscopes {
@@ -143,6 +160,16 @@ template <> struct family_traits<BetaBernoulli> {
   static void pack_hp(const BetaBernoulli::Shared &s, std::vector<float> &o) { o = {s.alpha, s.beta}; }
   static void *record(BetaBernoulli::Group &g, std::vector<uint8_t> &) { return &g.heads; }
   static void unpack(BetaBernoulli::Group &, const std::vector<uint8_t> &) {}
+  static void pack_value(const common::value_accessor &v, std::vector<uint8_t> &o) { o.assign(1, uint8_t(v.get<bool>(0))); }
+};
+template <> struct family_traits<distributions::BetaBernoulliNonConj> {
+  typedef distributions::BetaBernoulliNonConj T;
+  enum { family = MSC_BBNC };
+  static unsigned dim(const T::Shared &) { return 0; }
+  static common::runtime_type value_type(unsigned) { return common::runtime_type(TYPE_B); }
+  static void pack_hp(const T::Shared &s, std::vector<float> &o) { o = {s.alpha, s.beta}; }
+  static void *record(T::Group &g, std::vector<uint8_t> &) { return &g.heads; }
+  static void unpack(T::Group &, const std::vector<uint8_t> &) {}
   static void pack_value(const common::value_accessor &v, std::vector<uint8_t> &o) { o.assign(1, uint8_t(v.get<bool>(0))); }
 };
 template <> struct family_traits<GammaPoisson> {
@@ -230,6 +257,16 @@ template <> struct field_access<BetaBernoulli> {
     throw std::runtime_error("Unknown group SS param key: " + key);
   }
 };
+template <> struct field_access<distributions::BetaBernoulliNonConj> {
+  static common::value_mutator hp(distributions::BetaBernoulliNonConj::Shared &s, const std::string &key) {
+    MSC_FIELD(s, alpha); MSC_FIELD(s, beta);
+    throw std::runtime_error("unknown key: " + key);
+  }
+  static common::value_mutator ss(distributions::BetaBernoulliNonConj::Group &g, const std::string &key) {
+    MSC_FIELD(g, p);                       // the only key the reference exposes (bbnc.cpp:112-117)
+    throw std::runtime_error("unknown key: " + key);
+  }
+};
 template <> struct field_access<GammaPoisson> {
   static common::value_mutator hp(GammaPoisson::Shared &s, const std::string &key) {
     MSC_FIELD(s, alpha); MSC_FIELD(s, inv_beta);
@@ -275,6 +312,17 @@ template <> struct bag<BetaBernoulli> {
   static std::string dump(const BetaBernoulli::Group &g) { wire::writer w; w.put_varint_field(1, g.heads); w.put_varint_field(2, g.tails); return w.str(); }
   static void load(BetaBernoulli::Group &g, const std::string &b) {
     for (const auto &f : wire::parse(b)) { if (f.number == 1) g.heads = uint32_t(f.varint); if (f.number == 2) g.tails = uint32_t(f.varint); }
+  }
+};
+template <> struct bag<distributions::BetaBernoulliNonConj> {      // microscopes/io/schema.proto:7-19
+  typedef distributions::BetaBernoulliNonConj T;
+  static std::string dump(const T::Shared &s) { wire::writer w; w.put_float_field(1, s.alpha); w.put_float_field(2, s.beta); return w.str(); }
+  static void load(T::Shared &s, const std::string &b) {
+    for (const auto &f : wire::parse(b)) { if (f.number == 1) s.alpha = f.f32; if (f.number == 2) s.beta = f.f32; }
+  }
+  static std::string dump(const T::Group &g) { wire::writer w; w.put_float_field(1, g.p); w.put_varint_field(2, g.heads); w.put_varint_field(3, g.tails); return w.str(); }
+  static void load(T::Group &g, const std::string &b) {
+    for (const auto &f : wire::parse(b)) { if (f.number == 1) g.p = f.f32; if (f.number == 2) g.heads = uint32_t(f.varint); if (f.number == 3) g.tails = uint32_t(f.varint); }
   }
 };
 template <> struct bag<GammaPoisson> {
@@ -476,6 +524,11 @@ public:
 private:
   unsigned dim_;
 };
+
+// the in-tree non-conjugate model under its reference names (include/microscopes/models/bbnc.hpp:9-73)
+typedef distributions_group<distributions::BetaBernoulliNonConj> bbnc_group;
+typedef distributions_hypers<distributions::BetaBernoulliNonConj> bbnc_hypers;
+typedef distributions_model<distributions::BetaBernoulliNonConj> bbnc_model;
 
 typedef distributions_model<detail::DD128> distributions_model_dd128;
 typedef distributions_model<detail::NormalInverseWishartV> distributions_model_niwv;

@@ -50,7 +50,8 @@ typedef enum msc_family {
   MSC_DD = 2,   /* DirichletDiscrete<128>   value int32 in [0, dim)       */
   MSC_NICH = 3, /* NormalInverseChiSq       value float                   */
   MSC_NIW = 4,  /* NormalInverseWishart<-1> value float[dim]              */
-  MSC_NOOP = 5  /* noop model, models/noop.hpp:13-53 (API-overhead control) */
+  MSC_NOOP = 5, /* noop model, models/noop.hpp:13-53 (API-overhead control) */
+  MSC_BBNC = 6  /* non-conjugate Beta-Bernoulli with explicit p (src/models/bbnc.cpp:22-73), value bool */
 } msc_family;
 
 /* primitive types, include/microscopes/common/type_info.h:10-44 (same order) */
@@ -131,7 +132,7 @@ int msc_state_shape(const msc_state *st, uint32_t *nfeatures, uint32_t *ngroups)
 /*
  * hypers::set_hp / get_hp / get_hp_mutator (base.hpp:44-47) as flat float
  * blocks, field order as the reference names them (distributions.hpp:21-56):
- *   bb {alpha, beta}  gp {alpha, inv_beta}  dd {alphas[dim]}
+ *   bb {alpha, beta}  bbnc {alpha, beta}  gp {alpha, inv_beta}  dd {alphas[dim]}
  *   nich {mu, kappa, sigmasq, nu}  niw {kappa, nu, mu[dim], psi[dim*dim]}
  */
 size_t msc_hp_floats(int family, uint32_t dim);
@@ -143,6 +144,7 @@ int msc_state_get_hp(const msc_state *st, uint32_t feature, float *host_hp, size
  * records, one per group, float fields in float exactly as the reference keeps
  * them (distributions.hpp:21-56,79-91):
  *   bb   {u32 heads, u32 tails}
+ *   bbnc {u32 heads, u32 tails, f32 p}       (p is state, not a count: accumulate leaves it alone)
  *   gp   {u32 count, u32 sum, f32 log_prod}
  *   dd   {u32 count_sum, u32 counts[dim]}
  *   nich {u32 count, f32 mean, f32 count_times_variance}

@@ -13,6 +13,7 @@
 size_t orc_hp_size(int family, unsigned dim) {
   switch (family) {
     case ORC_BB: return 2 * sizeof(float);
+    case ORC_BBNC: return 2 * sizeof(float);
     case ORC_GP: return 2 * sizeof(float);
     case ORC_DD: return dim * sizeof(float);
     case ORC_NICH: return 4 * sizeof(float);
@@ -24,6 +25,7 @@ size_t orc_hp_size(int family, unsigned dim) {
 size_t orc_value_size(int family, unsigned dim) {
   switch (family) {
     case ORC_BB: return 1;
+    case ORC_BBNC: return 1;
     case ORC_GP: return 4;
     case ORC_DD: return 4;
     case ORC_NICH: return 4;

@@ -33,8 +33,8 @@ extern "C" {
 #endif
 
 /* family tags (same numbering as include/microscopes_hip.h) */
-enum { ORC_BB = 0, ORC_GP = 1, ORC_DD = 2, ORC_NICH = 3, ORC_NIW = 4, ORC_NOOP = 5,
-       ORC_NFAMILIES = 6 };
+enum { ORC_BB = 0, ORC_GP = 1, ORC_DD = 2, ORC_NICH = 3, ORC_NIW = 4, ORC_NOOP = 5, ORC_BBNC = 6,
+       ORC_NFAMILIES = 7 };
 
 /* primitive types, include/microscopes/common/type_info.h:10-44 */
 enum { ORC_TYPE_B = 0, ORC_TYPE_I8, ORC_TYPE_U8, ORC_TYPE_I16, ORC_TYPE_U16,
@@ -52,6 +52,7 @@ enum { ORC_TYPE_B = 0, ORC_TYPE_I8, ORC_TYPE_U8, ORC_TYPE_I16, ORC_TYPE_U16,
  *   nich hp {mu, kappa, sigmasq, nu}     ss {u32 count, (f64: u32 pad), R mean, R count_times_variance}
  *   niw  hp {kappa, nu, mu[d], psi[d*d]} ss {u32 count, (f64: u32 pad), R sum_x[d], R sum_xxT[d*d]}
  *   noop hp {}                           ss {u32 unused}
+ *   bbnc hp {alpha, beta}                ss {u32 heads, u32 tails, R p}   (src/models/bbnc.cpp:22-73; f64: 16 B)
  *
  * Values: bb uint8 (bool), gp uint32, dd int32, nich float, niw float[d].
  */

@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BB, GP, DD, NICH, NIW, NOOP = range(6)
-FAMILY_NAMES = {BB: "bb", GP: "gp", DD: "dd", NICH: "nich", NIW: "niw", NOOP: "noop"}
+BB, GP, DD, NICH, NIW, NOOP, BBNC = range(7)
+FAMILY_NAMES = {BB: "bb", GP: "gp", DD: "dd", NICH: "nich", NIW: "niw", NOOP: "noop", BBNC: "bbnc"}
 
 (TYPE_B, TYPE_I8, TYPE_U8, TYPE_I16, TYPE_U16, TYPE_I32, TYPE_U32, TYPE_I64, TYPE_U64,
  TYPE_F32, TYPE_F64) = range(11)
@@ -90,6 +90,8 @@ def ss_dtype(family, dim=0, prec="f64"):
     R = real_dtype(prec)
     if family == BB:
         dt = np.dtype([("heads", np.uint32), ("tails", np.uint32)])
+    elif family == BBNC:
+        dt = np.dtype([("heads", np.uint32), ("tails", np.uint32), ("p", R)], align=True)
     elif family == GP:
         dt = np.dtype([("count", np.uint32), ("sum", np.uint32), ("log_prod", R)])
     elif family == DD:
@@ -110,14 +112,14 @@ def ss_dtype(family, dim=0, prec="f64"):
 
 
 def value_dtype(family, dim=0):
-    return {BB: np.dtype(np.uint8), GP: np.dtype(np.uint32), DD: np.dtype(np.int32),
+    return {BB: np.dtype(np.uint8), BBNC: np.dtype(np.uint8), GP: np.dtype(np.uint32), DD: np.dtype(np.int32),
             NICH: np.dtype(np.float32), NIW: np.dtype((np.float32, (dim,))),
             NOOP: np.dtype(np.uint8)}[family]
 
 
 def pack_hp(family, hp, dim=0):
     """dict of hyperparameters (names as microscopes/models.pyx:185-290) -> float32 block."""
-    if family == BB:
+    if family in (BB, BBNC):
         v = [hp["alpha"], hp["beta"]]
     elif family == GP:
         v = [hp["alpha"], hp["inv_beta"]]
@@ -199,10 +201,10 @@ class Family(object):
                                         _p(zz), N, _p(out))
         return out
 
-    def accumulate(self, K, values, z):
+    def accumulate(self, K, values, z, ss_init=None):
         v = _vals(self.family, values, self.dim)
         zz = np.ascontiguousarray(z, dtype=np.int32)
-        ss = np.zeros(K, dtype=ss_dtype(self.family, self.dim, self.prec))
+        ss = np.zeros(K, dtype=ss_dtype(self.family, self.dim, self.prec)) if ss_init is None else ss_init.copy()
         self._g("accumulate")(self.family, self.dim, _p(self.hp), _p(ss), K, _p(v), _p(zz), v.shape[0])
         return ss
 

@@ -166,7 +166,32 @@ static void test_dd_and_niw() {
   }
 }
 
+static void test_bbnc() {
+  rng_t r(9);
+  models::bbnc_model m;
+  CHECK(m.get_runtime_type() == runtime_type(TYPE_B));
+  auto h = m.create_hypers();
+  h->get_hp_mutator("alpha").set<float>(2.0f);
+  h->get_hp_mutator("beta").set<float>(3.0f);
+  auto g = h->create_group(r);                       // draws p ~ Beta(2, 3)
+  const float p = g->get_ss_mutator("p").accessor().get<float>(0);
+  CHECK(p > 0.f && p < 1.f);
+  const bool t = true, f = false;
+  for (int i = 0; i < 5; i++) g->add_value(*h, value_accessor(&t), r);
+  for (int i = 0; i < 2; i++) g->add_value(*h, value_accessor(&f), r);
+  g->remove_value(*h, value_accessor(&t), r);
+  CHECK(close(g->score_value(*h, value_accessor(&t), r), std::log((double)p)));
+  CHECK(close(g->score_value(*h, value_accessor(&f), r), std::log1p(-(double)p)));
+  const float hp[2] = {2.f, 3.f};
+  struct { uint32_t heads, tails; double p; } oss = {4, 2, (double)p};
+  CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_BBNC, 0, hp, &oss)));
+  auto g2 = h->create_group(r);
+  g2->set_ss(g->get_ss());
+  CHECK(g2->score_data(*h, r) == g->score_data(*h, r));
+}
+
 int main() {
+  test_bbnc();
   {
     models::distributions_model<BetaBernoulli> m;
     run_scalar<BetaBernoulli, bool>(ORC_BB, 0, m, {2.f, 0.5f}, {{"alpha", 2.f}, {"beta", 0.5f}},

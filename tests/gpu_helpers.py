@@ -17,7 +17,7 @@ def rel_err(got, want):
 def make_feature(family, N, K, rng, dim=0, hp=None):
     """-> dict(family, dim, hp, values, np_dtype) with group structure in the data."""
     z_true = rng.integers(0, K, N)
-    if family == orc.BB:
+    if family in (orc.BB, orc.BBNC):
         p = rng.random(K)
         vals = (rng.random(N) < p[z_true]).astype(np.bool_)
         hp = hp or dict(alpha=1.0, beta=1.0)
@@ -64,7 +64,11 @@ def state_from_assignment(features, K, z):
     out = []
     for f in features:
         F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
-        ss64 = F.accumulate(K, f["values"], z)
+        init = None
+        if f["family"] == orc.BBNC:     # the group's explicit p is state, drawn once per group
+            init = np.zeros(K, dtype=orc.ss_dtype(orc.BBNC, 0, "f64"))
+            init["p"] = np.random.default_rng(K).uniform(0.05, 0.95, K).astype(np.float32)
+        ss64 = F.accumulate(K, f["values"], z, ss_init=init)
         ss32 = orc.narrow_ss(f["family"], ss64, f["dim"])
         out.append((F, orc.widen_ss(f["family"], ss32, f["dim"]), ss32))
     return out

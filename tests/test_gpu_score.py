@@ -9,7 +9,7 @@ from tests.gpu_helpers import (TOL, crp_prior_matrix, load_state, make_feature, 
 
 pytestmark = pytest.mark.gpu
 
-SINGLE = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0), (orc.NIW, 3), (orc.NIW, 32)]
+SINGLE = [(orc.BB, 0), (orc.BBNC, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0), (orc.NIW, 3), (orc.NIW, 32)]
 
 
 def _setup(gpu_ctx, specs, N, K, seed, empty_groups=0):

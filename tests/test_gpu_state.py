@@ -101,16 +101,16 @@ def test_score_data_matches_twin(gpu_ctx, K):
     import common_amd
     rng = np.random.default_rng(31 + K)
     N = 5000
-    feats = [make_feature(f, N, K, rng, d) for f, d in SPECS]
+    feats = [make_feature(f, N, K, rng, d) for f, d in SPECS + [(orc.BBNC, 0)]]
     z = rng.integers(0, max(1, K - 1), N).astype(np.int32)   # last group stays empty
     fs = state_from_assignment(feats, K, z)
-    st = common_amd.State(gpu_ctx, SPECS, K)
+    st = common_amd.State(gpu_ctx, SPECS + [(orc.BBNC, 0)], K)
     load_state(st, fs)
     got = st.score_data().cpu().numpy()
     for i, (F, ss64, _) in enumerate(fs):
         want = F.score_data_all(ss64)
         assert rel_err(got[i], want).max() <= TOL, (F.family, rel_err(got[i], want).max())
-    assert np.all(got[:, K - 1] == 0.0)   # empty group: marginal likelihood of no data
+    assert np.all(got[:len(SPECS), K - 1] == 0.0)   # empty group: marginal likelihood of no data
 
 
 def test_dataview_unpack_is_bit_exact_with_runtime_cast(gpu_ctx):
