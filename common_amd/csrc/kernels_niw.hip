@@ -102,7 +102,15 @@ __global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__
     const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
     W64[idx] = (i < d && j <= i) ? Li[(size_t)i * d + j] * scale : 0.0;
   }
-  for (uint32_t i = t; i < kNiwPad; i += 64) fd.niw_mu64[(size_t)k * kNiwPad + i] = i < d ? mun[i] : 0.0;
+  // b = W mu_n, stored in the order the f64 kernel's accumulator wants it: slot [kk][r] holds
+  // row kk + 4r (r < 4) or 16 + kk + 4(r-4) of the whitened mean, so W x - b starts from acc = -b
+  for (uint32_t slot = t; slot < kNiwPad; slot += 64) {
+    const uint32_t kk = slot >> 3, r = slot & 7, i = r < 4 ? kk + 4 * r : 16 + kk + 4 * (r - 4);
+    double b = 0.0;
+    if (i < d)
+      for (uint32_t j = 0; j <= i; j++) b += Li[(size_t)i * d + j] * mun[j];
+    fd.niw_mu64[(size_t)k * kNiwPad + slot] = b * scale;
+  }
   float *B = fd.niw_b + (size_t)k * 2 * kNiwPad;      // mu hi[32] | lo[32]
   for (uint32_t i = t; i < kNiwPad; i += 64) {
     float hi = 0.f, lo = 0.f;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
       if (live[t] && fd.mask != nullptr)
         for (uint32_t e = 0; e < d; e++) msk[t] |= fd.mask[(row0 + row) * d + e] != 0;
     }
-    float4 pend[T];
+    float qkeep[T][4];           // |W(x - mu)|^2 of the 4 groups this lane finalises per batch of 8
     for (uint32_t k = 0; k < K; k++) {
       const float *Wk = fd.niw_w + ((size_t)k * kNiwPad + r) * kNiwPad + 16 * h;
       const float *Bk = fd.niw_b + (size_t)k * 2 * kNiwPad + 16 * h;
@@ -213,13 +221,6 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
         w[4 * q] = a.x; w[4 * q + 1] = a.y; w[4 * q + 2] = a.z; w[4 * q + 3] = a.w;
         mh[4 * q] = b.x; mh[4 * q + 1] = b.y; mh[4 * q + 2] = b.z; mh[4 * q + 3] = b.w;
         ml[4 * q] = c.x; ml[4 * q + 1] = c.y; ml[4 * q + 2] = c.z; ml[4 * q + 3] = c.w;
-      }
-      const float c0 = fd.tab[(size_t)NIW_C0 * kpad + k], c1 = fd.tab[(size_t)NIW_C1 * kpad + k];
-      float al = 0, bl = 0, cl = 0;
-      if (LOO) {
-        al = fd.tab[(size_t)NIW_A_LOO * kpad + k];
-        bl = fd.tab[(size_t)NIW_B_LOO * kpad + k];
-        cl = fd.tab[(size_t)NIW_C_LOO * kpad + k];
       }
       const uint32_t slot = k & 3;
       const bool mine = (int)((k >> 2) & 1) == h;
@@ -233,24 +234,40 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; i++) qp = fmaf(acc[i], acc[i], qp);
         const float q = qp + __shfl_xor(qp, 32, 64);
-        float sc = fmaf(-c1, log1p_acc(q), c0);
-        if (LOO && gz[t] == (int)k) {
-          const float y = fminf(cl * q, 0.99999994f);
-          sc = fmaf(bl, log1p_acc(-y), al);
-        }
-        if (msk[t]) sc = 0.f;
         if (mine) {
-          if (slot == 0) pend[t].x = sc;
-          else if (slot == 1) pend[t].y = sc;
-          else if (slot == 2) pend[t].z = sc;
-          else pend[t].w = sc;
+          if (slot == 0) qkeep[t][0] = q;
+          else if (slot == 1) qkeep[t][1] = q;
+          else if (slot == 2) qkeep[t][2] = q;
+          else qkeep[t][3] = q;
         }
       }
       if ((k & 7) == 7 || k == K - 1) {
         const uint32_t k0 = (k & ~7u) + 4 * h;       // first group of this lane's float4
+        float4 pend[T];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t kg = k0 + i;
+          const bool valid = kg <= k;
+          const size_t kc = valid ? kg : 0;
+          const float c0 = fd.tab[(size_t)NIW_C0 * kpad + kc], c1 = fd.tab[(size_t)NIW_C1 * kpad + kc];
+#pragma unroll
+          for (int t = 0; t < T; t++) {
+            const float q = valid ? qkeep[t][i] : 0.f;
+            float sc = fmaf(-c1, log1p_acc(q), c0);
+            if (LOO && valid && gz[t] == (int)kg) {
+              const float y = fminf(fd.tab[(size_t)NIW_C_LOO * kpad + kc] * q, 0.99999994f);
+              sc = fmaf(fd.tab[(size_t)NIW_B_LOO * kpad + kc], log1p_acc(-y), fd.tab[(size_t)NIW_A_LOO * kpad + kc]);
+            }
+            if (msk[t]) sc = 0.f;
+            if (i == 0) pend[t].x = sc;
+            else if (i == 1) pend[t].y = sc;
+            else if (i == 2) pend[t].z = sc;
+            else pend[t].w = sc;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < T; t++) {
-          if (!live[t]) continue;
+          if (!live[t] || k0 > k) continue;
           float *p = out + (rb + 32 * t + r) * ld + k0;
           if (vec_ok && k0 + 3 <= k) {
             float4 v = pend[t];
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
     const uint64_t rb = blk * 16 * JB;
-    float xr[JB][8];
+    double xd[JB][8];            // this lane's 8 features of its row, widened once
     int gz[JB];
     bool live[JB], msk[JB];
 #pragma unroll
@@ -308,62 +325,75 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
       if (d == 32) {
         const float4 v0 = live[jb] ? ld4(xp) : make_float4(0, 0, 0, 0);
         const float4 v1 = live[jb] ? ld4(xp + 4) : make_float4(0, 0, 0, 0);
-        xr[jb][0] = v0.x; xr[jb][1] = v0.y; xr[jb][2] = v0.z; xr[jb][3] = v0.w;
-        xr[jb][4] = v1.x; xr[jb][5] = v1.y; xr[jb][6] = v1.z; xr[jb][7] = v1.w;
+        xd[jb][0] = v0.x; xd[jb][1] = v0.y; xd[jb][2] = v0.z; xd[jb][3] = v0.w;
+        xd[jb][4] = v1.x; xd[jb][5] = v1.y; xd[jb][6] = v1.z; xd[jb][7] = v1.w;
       } else {
 #pragma unroll
-        for (int s = 0; s < 8; s++) xr[jb][s] = (live[jb] && (uint32_t)(8 * kk + s) < d) ? xp[s] : 0.0f;
+        for (int s = 0; s < 8; s++) xd[jb][s] = (live[jb] && (uint32_t)(8 * kk + s) < d) ? (double)xp[s] : 0.0;
       }
       gz[jb] = (LOO && live[jb]) ? z[row] : -1;
       msk[jb] = false;
       if (live[jb] && fd.mask != nullptr)
         for (uint32_t e = 0; e < d; e++) msk[jb] |= fd.mask[(row0 + row) * d + e] != 0;
     }
-    float4 pend[JB];
+    double qkeep[JB][4];         // |W(x - mu)|^2 of the 4 groups this lane finalises per batch of 16
     for (uint32_t k = 0; k < K; k++) {
+      // (a register double buffer prefetching group k+1's operands was measured slower: 249 VGPRs)
       const double *Wk = fd.niw_w64 + ((size_t)k * kNiwPad + c) * kNiwPad + 8 * kk;
-      const double *Mk = fd.niw_mu64 + (size_t)k * kNiwPad + 8 * kk;
-      double a0[8], a1[8], m[8];
+      const double *Bk = fd.niw_mu64 + (size_t)k * kNiwPad + 8 * kk;
+      double a0[8], a1[8], nb[8];
 #pragma unroll
       for (int s = 0; s < 8; s += 2) {
         const double2 p0 = *reinterpret_cast<const double2 *>(Wk + s);
         const double2 p1 = *reinterpret_cast<const double2 *>(Wk + 16 * kNiwPad + s);
-        const double2 pm = *reinterpret_cast<const double2 *>(Mk + s);
-        a0[s] = p0.x; a0[s + 1] = p0.y; a1[s] = p1.x; a1[s + 1] = p1.y; m[s] = pm.x; m[s + 1] = pm.y;
+        const double2 pb = *reinterpret_cast<const double2 *>(Bk + s);
+        a0[s] = p0.x; a0[s + 1] = p0.y; a1[s] = p1.x; a1[s + 1] = p1.y; nb[s] = -pb.x; nb[s + 1] = -pb.y;
       }
-      const double *c64 = fd.niw_c64 + (size_t)k * 8;
-      const double c0 = c64[0], c1 = c64[1];
-      double al = 0, bl = 0, cl = 0;
-      if (LOO) { al = c64[2]; bl = c64[3]; cl = c64[4]; }
       const uint32_t slot = k & 3;
       const bool mine = (int)((k >> 2) & 3) == kk;
 #pragma unroll
       for (int jb = 0; jb < JB; jb++) {
-        f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        f64x4 acc0 = {nb[0], nb[1], nb[2], nb[3]}, acc1 = {nb[4], nb[5], nb[6], nb[7]};   // W x - W mu
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-          const double u = (double)xr[jb][s] - m[s];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], u, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], u, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], xd[jb][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], xd[jb][s], acc1, 0, 0, 0);
         }
         double qp = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) qp = fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
         qp += shfl_xor_f64(qp, 16);
         const double q = qp + shfl_xor_f64(qp, 32);
-        double sc = c0 - c1 * log1p(q);
-        if (LOO && gz[jb] == (int)k) sc = al + bl * log1p(-fmin(cl * q, 1.0 - 1e-15));
-        if (msk[jb]) sc = 0.0;
         if (mine) {
-          const float scf = (float)sc;
-          if (slot == 0) pend[jb].x = scf;
-          else if (slot == 1) pend[jb].y = scf;
-          else if (slot == 2) pend[jb].z = scf;
-          else pend[jb].w = scf;
+          if (slot == 0) qkeep[jb][0] = q;
+          else if (slot == 1) qkeep[jb][1] = q;
+          else if (slot == 2) qkeep[jb][2] = q;
+          else qkeep[jb][3] = q;
         }
       }
       if ((k & 15) == 15 || k == K - 1) {
-        const uint32_t k0 = (k & ~15u) + 4 * kk;      // first group of this lane's float4
+        // finish the batch: lane (c, kk) turns its 4 kept q's into scores of groups k0 .. k0+3
+        const uint32_t k0 = (k & ~15u) + 4 * kk;
+        float4 pend[JB];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t kg = k0 + i;
+          const bool valid = kg <= k;
+          const double *c64 = fd.niw_c64 + (size_t)(valid ? kg : 0) * 8;
+          const double c0 = c64[0], c1 = c64[1];
+#pragma unroll
+          for (int jb = 0; jb < JB; jb++) {
+            const double q = valid ? qkeep[jb][i] : 0.0;
+            double sc = c0 - c1 * log1p(q);
+            if (LOO && valid && gz[jb] == (int)kg) sc = c64[2] + c64[3] * log1p(-fmin(c64[4] * q, 1.0 - 1e-15));
+            if (msk[jb]) sc = 0.0;
+            const float scf = (float)sc;
+            if (i == 0) pend[jb].x = scf;
+            else if (i == 1) pend[jb].y = scf;
+            else if (i == 2) pend[jb].z = scf;
+            else pend[jb].w = scf;
+          }
+        }
 #pragma unroll
         for (int jb = 0; jb < JB; jb++) {
           if (!live[jb] || k0 > k) continue;
