@@ -32,18 +32,30 @@ MSC_DEV float philox_uniform01(uint64_t seed, uint64_t sweep, uint64_t row) {
   return (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
-// ---- wavefront primitives (64 lanes) ----------------------------------------------
-MSC_DEV float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+// ---- wavefront primitives (64 lanes), on the DPP cross-lane path (no LDS traffic) ---------
+// row_shr:n shifts within each row of 16 lanes; row_bcast:15 / :31 carry the running value of
+// the previous row(s) into rows {1,3} / {2,3}.  Lanes without a source keep `identity`.
+template <int CTRL, int ROW_MASK>
+MSC_DEV float dpp_f32(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-MSC_DEV float wave_incl_scan(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
+MSC_DEV float wave_max(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f32<0x111, 0xf>(ninf, v));   // row_shr:1
+  v = fmaxf(v, dpp_f32<0x112, 0xf>(ninf, v));   // row_shr:2
+  v = fmaxf(v, dpp_f32<0x114, 0xf>(ninf, v));   // row_shr:4
+  v = fmaxf(v, dpp_f32<0x118, 0xf>(ninf, v));   // row_shr:8
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(ninf, v));   // row_bcast:15 -> rows 1, 3
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(ninf, v));   // row_bcast:31 -> rows 2, 3
+  return lane_bcast(v, 63);                      // lane 63 now holds the maximum over the wave
+}
+MSC_DEV float wave_incl_scan(float v, int) {
+  v += dpp_f32<0x111, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf>(0.f, v);
+  v += dpp_f32<0x142, 0xa>(0.f, v);
+  v += dpp_f32<0x143, 0xc>(0.f, v);
   return v;
 }
 
