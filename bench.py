@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--groups", type=int, default=256)
-    ap.add_argument("--cpu-sample-rows", type=int, default=300_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     return ap.parse_args()

@@ -132,6 +132,63 @@ MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t kpad, uint32_t ktile, 
   return nrows_lds;
 }
 
+// one feature's contribution to the R rows of this wave (tables already in `buf`)
+template <int R, bool MASKED>
+MSC_DEV void add_feature(const FeatDesc &fd, const float4 *__restrict__ buf, uint32_t nrows_lds, uint32_t kpad,
+                         uint32_t kb, int lane, uint32_t raw, unsigned long long mbits, float4 (&acc)[R]) {
+    switch (fd.family) {
+    case MSC_BBNC:
+    case MSC_BB: {
+      const float4 s0 = buf[lane], s1 = buf[64 + lane];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (MASKED && ((mbits >> r) & 1ull)) continue;
+        const bool vr = lane_bcast((int)raw, r) != 0;
+        acc[r].x += vr ? s1.x : s0.x;
+        acc[r].y += vr ? s1.y : s0.y;
+        acc[r].z += vr ? s1.z : s0.z;
+        acc[r].w += vr ? s1.w : s0.w;
+      }
+    } break;
+    case MSC_DD: {
+      int v = (int)raw;
+      v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);       // keep the gather in bounds
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (MASKED && ((mbits >> r) & 1ull)) continue;
+        const uint32_t vr = (uint32_t)lane_bcast(v, r);
+        add4(acc[r], vr < nrows_lds ? buf[vr * 64 + lane] : ld4(fd.tab + (size_t)vr * kpad + kb));
+      }
+    } break;
+    case MSC_GP: {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (MASKED && ((mbits >> r) & 1ull)) continue;
+        const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
+        if (vr < nrows_lds) add4(acc[r], buf[vr * 64 + lane]);
+        else if (vr < fd.vcap) add4(acc[r], ld4(fd.tab + (size_t)(GP_T0 + vr) * kpad + kb));
+        // counts beyond the table contribute through k_gp_large_fix
+      }
+    } break;
+    case MSC_NICH: {
+      const float4 mh = buf[NICH_MU_HI * 64 + lane], ml = buf[NICH_MU_LO * 64 + lane],
+                   c0 = buf[NICH_C0 * 64 + lane], c1l = buf[NICH_C1LN2 * 64 + lane],
+                   c1 = buf[NICH_C1 * 64 + lane], c2 = buf[NICH_C2 * 64 + lane];
+      const float xv = __uint_as_float(raw);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (MASKED && ((mbits >> r) & 1ull)) continue;
+        const float x = lane_bcast(xv, r);
+        acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+        acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+        acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+        acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+      }
+    } break;
+    default: break;   // noop contributes 0 (models/noop.hpp:17); niw has its own MFMA pass
+  }
+}
+
 // ---------------------------------------------------------------------------
 // acc[r] (+)= sum over features of score_value(row rb+r, groups kb..kb+3).
 // All W waves of the workgroup must call this together (it contains barriers); a wave whose
@@ -163,57 +220,8 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
       mbits_next = __builtin_amdgcn_ballot_w64(load_masked(feats[f + 1], myrow, has_row));
       nrows_next = stage_table<W>(feats[f + 1], kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
     }
-    switch (fd.family) {
-      case MSC_BBNC:
-      case MSC_BB: {
-        const float4 s0 = buf[lane], s1 = buf[64 + lane];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if ((mbits >> r) & 1ull) continue;
-          const bool vr = lane_bcast((int)raw, r) != 0;
-          acc[r].x += vr ? s1.x : s0.x;
-          acc[r].y += vr ? s1.y : s0.y;
-          acc[r].z += vr ? s1.z : s0.z;
-          acc[r].w += vr ? s1.w : s0.w;
-        }
-      } break;
-      case MSC_DD: {
-        int v = (int)raw;
-        v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);       // keep the gather in bounds
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if ((mbits >> r) & 1ull) continue;
-          const uint32_t vr = (uint32_t)lane_bcast(v, r);
-          add4(acc[r], vr < nrows_lds ? buf[vr * 64 + lane] : ld4(fd.tab + (size_t)vr * kpad + kb));
-        }
-      } break;
-      case MSC_GP: {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if ((mbits >> r) & 1ull) continue;
-          const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
-          if (vr < nrows_lds) add4(acc[r], buf[vr * 64 + lane]);
-          else if (vr < fd.vcap) add4(acc[r], ld4(fd.tab + (size_t)(GP_T0 + vr) * kpad + kb));
-          // counts beyond the table contribute through k_gp_large_fix
-        }
-      } break;
-      case MSC_NICH: {
-        const float4 mh = buf[NICH_MU_HI * 64 + lane], ml = buf[NICH_MU_LO * 64 + lane],
-                     c0 = buf[NICH_C0 * 64 + lane], c1l = buf[NICH_C1LN2 * 64 + lane],
-                     c1 = buf[NICH_C1 * 64 + lane], c2 = buf[NICH_C2 * 64 + lane];
-        const float xv = __uint_as_float(raw);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if ((mbits >> r) & 1ull) continue;
-          const float x = lane_bcast(xv, r);
-          acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-          acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-          acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-          acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-        }
-      } break;
-      default: break;   // noop contributes 0 (models/noop.hpp:17); niw has its own MFMA pass
-    }
+    if (mbits == 0ull) add_feature<R, false>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
+    else add_feature<R, true>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // table f+1 has landed (this wave's share)
     __syncthreads();                                    // ... everyone's share; buffer f&1 is free again
     raw = raw_next;
