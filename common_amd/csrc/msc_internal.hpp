@@ -52,13 +52,13 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 // 4l..4l+3 of a k-tile with one 16-byte load.
 //
 // Derived score tables (float, filled by the prepare kernels from the raw tables):
-//   bb   rows {s0, s1}                       log p(v=0), log p(v=1)
-//   gp   rows {a, inv_a, c, inv_1pb, s_a}    see family_math.hpp
-//   dd   rows {table[0..dim)}                log p(v = i)
-//   nich rows {mu_hi, mu_lo, c0, c1ln2, c1, c2, g_loo}
-//   niw  tab = {c0, c1, inv_dof, kappa_n, logdet_extra...}[kpad]; wmat = L^-1 [K][d][d]; bvec = [K][d]
+//   bb / bbnc rows {s0, s1}                  log p(v=0), log p(v=1)
+//   gp   rows {nse_hi, nse_lo, T[0..vcap)}   -stirlerr(a) as hi/lo, then the exact table log p(v) (family_math.hpp)
+//   dd   rows {T[0..dim)}                    log p(v = i)
+//   nich rows {mu_hi, mu_lo, c0, c1ln2, c1, c2}
+//   niw  rows {c0, c1, A_loo, B_loo, C_loo, logdet_hi, logdet_lo} + the matrices below (kernels_niw.hip)
 // Raw tables (the reference's own fields, u32 / f32):
-//   bb   u32 {heads, tails}
+//   bb   u32 {heads, tails}          bbnc: + f32 {p}
 //   gp   u32 {count, sum}            f32 {log_prod}
 //   dd   u32 {count_sum, counts[dim]}
 //   nich u32 {count}                 f32 {mean, count_times_variance}
