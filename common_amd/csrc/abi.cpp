@@ -3,6 +3,7 @@
 // There is deliberately no CPU arithmetic path here: every score / update is a
 // kernel in kernels_*.hip, and context creation fails without a gfx950 device.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <memory>
 #include <new>
@@ -112,6 +113,11 @@ extern "C" int msc_context_synchronize(msc_context *ctx) {
 // ---------------------------------------------------------------------------
 // dataview
 // ---------------------------------------------------------------------------
+static uint64_t next_view_serial() {
+  static std::atomic<uint64_t> n{0};
+  return ++n;
+}
+
 static void free_all(std::vector<void *> &owned) {
   for (void *p : owned) (void)hipFree(p);
   owned.clear();
@@ -146,6 +152,7 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
   std::unique_ptr<msc_dataview> v(new (std::nothrow) msc_dataview());
   if (!v) return fail(MSC_ENOMEM, "out of host memory");
   v->ctx = ctx;
+  v->serial = next_view_serial();
   v->nrows = nrows;
   int rc = MSC_OK;
   uint8_t *rec_dev = nullptr, *mask_dev = nullptr;
@@ -198,6 +205,7 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
   std::unique_ptr<msc_dataview> v(new (std::nothrow) msc_dataview());
   if (!v) return fail(MSC_ENOMEM, "out of host memory");
   v->ctx = ctx;
+  v->serial = next_view_serial();
   v->nrows = nrows;
   for (uint32_t i = 0; i < ntypes; i++) {
     MSC_REQUIRE(types[i].type >= 0 && types[i].type < MSC_TYPE_NELEMS, "feature %u: bad type", i);
@@ -595,7 +603,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
   MSC_REQUIRE(row0 + nrows <= view->nrows, "rows [%llu,%llu) outside the view (%llu rows)",
               (unsigned long long)row0, (unsigned long long)(row0 + nrows),
               (unsigned long long)view->nrows);
-  bool same = st->bound_view == view && st->bound_cols.size() == st->nfeat;
+  bool same = st->bound_view == view && st->bound_serial == view->serial && st->bound_cols.size() == st->nfeat;
   for (uint32_t f = 0; f < st->nfeat && same; f++) same = st->bound_cols[f] == (cols ? cols[f] : f);
   if (same) {
     for (uint32_t f = 0; f < st->nfeat && same; f++)
@@ -650,6 +658,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
     }
   }
   st->bound_view = view;
+  st->bound_serial = view->serial;
   return upload_desc(st);
 }
 

@@ -170,6 +170,7 @@ struct msc_context {
 
 struct msc_dataview {
   msc_context *ctx = nullptr;
+  uint64_t serial = 0;                   // unique per view: a state's binding is keyed on it, not on the address
   uint64_t nrows = 0;
   std::vector<msc_runtime_type> types;   // per feature, after conversion
   std::vector<void *> cols;              // device columns
@@ -213,6 +214,7 @@ struct msc_state {
   msc::FeatDesc *desc_dev = nullptr;
   std::vector<msc::FeatDesc> desc_host;
   const msc_dataview *bound_view = nullptr;
+  uint64_t bound_serial = 0;
   std::vector<uint32_t> bound_cols;
   std::vector<void *> owned;
   float *scratch = nullptr;       // score chunk for the generic sweep path
