@@ -37,6 +37,7 @@ MSC_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 //   log(1+t) = ln2 * log2(u) + r,  u = fl(1+t),  r = (t - (u-1)) / u     (t >= 0)
 // (u-1 is exact for u >= 1, t-(u-1) is exact, so only the division rounds.)
 MSC_DEV void log1p_parts(float t, float &l2, float &r) {
+#pragma clang fp contract(off)   // same bits from every kernel that inlines this, whatever surrounds it
   const float u = 1.0f + t;
   l2 = hw_log2(u);
   r = (t - (u - 1.0f)) * hw_rcp(u);
@@ -152,6 +153,7 @@ MSC_DEV double gp_score_data(const float *hp, uint32_t count, uint32_t sum, doub
 // Student-t predictive  score(x) = c0 - c1 * log1p(c2 (x - mu')^2)
 //   c0 = lgamma((nu'+1)/2) - lgamma(nu'/2) + ln(lambda/(pi nu'))/2,  c1 = (nu'+1)/2,
 //   c2 = lambda/nu',  lambda = kappa'/((kappa'+1) sigmasq')
+// NICH_MU_* hold s*mu and NICH_C2 holds s = sqrt(c2) (see nich_prepare)
 enum { NICH_MU_HI = 0, NICH_MU_LO = 1, NICH_C0 = 2, NICH_C1LN2 = 3, NICH_C1 = 4, NICH_C2 = 5, NICH_ROWS = 6 };
 
 struct NichPost { double mu, kappa, sigmasq, nu; };
@@ -175,16 +177,22 @@ MSC_DEV void nich_prepare(const float *hp, uint32_t count, float mean, float ctv
   const NichPost p = nich_posterior(hp, (double)count, (double)mean, (double)ctv);
   double c0, c1, c2;
   nich_coeffs(p, c0, c1, c2);
-  split_hi_lo(p.mu, out[NICH_MU_HI], out[NICH_MU_LO]);
+  // the eval works on a = s (x - mu) with s = fl(sqrt(c2)): t = c2 (x - mu)^2 = a^2 up to a relative
+  // error of a few ulp (harmless: the score depends on t through c1 log1p(t)), and
+  // s mu is carried as a hi/lo pair computed from the ROUNDED s so that a is exact in x - mu.
+  const float s = (float)sqrt(c2);
+  split_hi_lo(p.mu * (double)s, out[NICH_MU_HI], out[NICH_MU_LO]);
   out[NICH_C0] = (float)c0;
   out[NICH_C1LN2] = (float)(c1 * 0.69314718055994530942);
   out[NICH_C1] = (float)c1;
-  out[NICH_C2] = (float)c2;
+  out[NICH_C2] = s;
 }
-MSC_DEV float nich_eval(float x, float mu_hi, float mu_lo, float c0, float c1ln2, float c1, float c2) {
-  const float d = (x - mu_hi) - mu_lo;
+// rows of the table: s*mu (hi, lo), c0, c1*ln2, c1, s = sqrt(c2)
+MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1ln2, float c1, float s) {
+#pragma clang fp contract(off)   // explicit fmaf only: a row's score must not depend on the code path that scored it
+  const float a = fmaf(x, s, -smu_hi) - smu_lo;
   float l2, r;
-  log1p_parts(c2 * d * d, l2, r);
+  log1p_parts(a * a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
 }
 // remove_value (Welford downdate) then score_value, all in double

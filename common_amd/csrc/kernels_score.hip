@@ -140,18 +140,28 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
 
 // ---------------------------------------------------------------------------
 // single NICH feature (config C2 / C5 scoring pass)
-//   grid.x = row chunks (grid-stride), grid.y = k-tiles, block = 4 waves
+//   A wave owns one 256-group tile (constants in VGPRs) and a "slot": it scores Q consecutive
+//   rows, then jumps nslots*Q rows ahead.  Waves are numbered tile-fastest, so the waves that are
+//   resident at one moment write one dense, contiguous window of the score matrix that sweeps
+//   forward through it (the pattern a plain fill reaches its best rate with).  The launcher gives
+//   every wave a single quad; the loop only runs when the grid would exceed the launch limit.
 // ---------------------------------------------------------------------------
-template <bool LOO, bool CRP, int CH, bool NT>
+template <bool LOO, bool CRP, int Q, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, const int32_t *__restrict__ z,
+                                                      uint64_t nrows, uint64_t nslots,
+                                                      const int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
                                                       const float *__restrict__ crp,
                                                       float *__restrict__ out, uint64_t ld) {
   const FeatDesc fd = feats[0];
   const int lane = threadIdx.x & 63;
-  const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
+  const uint32_t ktiles = kpad / kGroupTile;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t slot = wave_id / ktiles;
+  if (slot >= nslots) return;
+  const uint32_t kt = (uint32_t)(wave_id - slot * ktiles);
+  const uint32_t kb = kt * kGroupTile + lane * 4;
   const float *tab = fd.tab + kb;
   const float4 mh = ld4(tab + (size_t)NICH_MU_HI * kpad), ml = ld4(tab + (size_t)NICH_MU_LO * kpad),
                c0 = ld4(tab + (size_t)NICH_C0 * kpad), c1l = ld4(tab + (size_t)NICH_C1LN2 * kpad),
@@ -164,13 +174,10 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
     le1 = crp[2 * (size_t)kpad + 1];
   }
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const bool tile_full = (kt + 1) * kGroupTile <= K;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
-  const uint64_t nchunks = (nrows + CH - 1) / CH;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-  for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
-    const uint64_t rb = chunk * CH;
-    const int nr = (int)((nrows - rb) < (uint64_t)CH ? (nrows - rb) : (uint64_t)CH);
+  for (uint64_t rb = slot * Q; rb < nrows; rb += nslots * Q) {
+    const int nr = (int)((nrows - rb) < (uint64_t)Q ? (nrows - rb) : (uint64_t)Q);
     const float xv = lane < nr ? xcol[rb + lane] : 0.0f;
     const unsigned long long mbits =
         __builtin_amdgcn_ballot_w64(fd.mask != nullptr && lane < nr && fd.mask[row0 + rb + lane] != 0);
@@ -181,22 +188,42 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
       sloo = own[rb + lane];
       if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
     }
-#pragma unroll 4
-    for (int r = 0; r < nr; r++) {
-      const float x = lane_bcast(xv, r);
-      float4 s = make_float4(0, 0, 0, 0);
-      if (!((mbits >> r) & 1ull)) {
+    if (nr == Q && mbits == 0ull && vec_ok && tile_full) {     // straight-line: no per-row branches
+#pragma unroll
+      for (int r = 0; r < Q; r++) {
+        const float x = lane_bcast(xv, r);
+        float4 s;
         s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
         s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
         s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
         s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
+        if (LOO) {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
+        }
+        const f32x4 v = {s.x, s.y, s.z, s.w};
+        f32x4 *p = reinterpret_cast<f32x4 *>(out + (rb + r) * ld + kb);
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
       }
-      if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
-      if (LOO) {
-        const int g = lane_bcast(gz, r);
-        if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
+    } else {
+      for (int r = 0; r < nr; r++) {
+        const float x = lane_bcast(xv, r);
+        float4 s = make_float4(0, 0, 0, 0);
+        if (!((mbits >> r) & 1ull)) {
+          s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+          s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+          s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+          s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+        }
+        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
+        if (LOO) {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
+        }
+        store_row<NT>(out, ld, rb + r, kb, K, s, vec_ok);
       }
-      store_row<NT>(out, ld, rb + r, kb, K, s, vec_ok);
     }
   }
 }
@@ -332,16 +359,18 @@ static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const Fe
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (nich1) {
-    // 32 rows per wave chunk, non-temporal stores and a 64-workgroups-per-CU grid cap measured
-    // best on C2 (profiles/r01_nich1_variants.txt): 5.5 TB/s vs 5.3 (64-row chunks), 5.1 (plain stores)
-    constexpr int kChunk = 32;
-    const uint64_t nchunks = (nrows + kChunk - 1) / kChunk;
-    uint64_t gx = (nchunks + 3) / 4;
-    const uint64_t cap = (uint64_t)num_cus * 64;
-    if (gx > cap) gx = cap;
-    if (gx == 0) gx = 1;
-    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, kChunk, true>), dim3((unsigned)gx, ktiles), dim3(256), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
+    // One 4-row quad per wave and non-temporal stores measured best on C2 and on the C5 shard
+    // (profiles/r01_nich1_variants.txt, second table): 5.8-6.0 TB/s vs 5.4-5.6 for 32-row chunks per wave.
+    // A wave only loops when the grid would otherwise exceed the launch limit.
+    constexpr int kQuad = 4;
+    const uint64_t nquads = (nrows + kQuad - 1) / kQuad;
+    const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
+    const uint64_t iters = (nquads + max_slots - 1) / max_slots;
+    uint64_t nslots = iters ? (nquads + iters - 1) / iters : 1;
+    if (nslots == 0) nslots = 1;
+    const uint64_t gx = (nslots * ktiles + 3) / 4;
+    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, kQuad, true>), dim3((unsigned)gx), dim3(256), 0, stream,
+                       feats_dev, K, kpad, row0, nrows, nslots, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)
