@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmicroscopes_hip.so")
 
 # families / primitive types / flags, mirrored from the header
-BB, GP, DD, NICH, NIW, NOOP, BBNC = range(7)
+BB, GP, DD, NICH, NIW, NOOP, BBNC, BNB, DM = range(9)
 (TYPE_B, TYPE_I8, TYPE_U8, TYPE_I16, TYPE_U16, TYPE_I32, TYPE_U32, TYPE_I64, TYPE_U64, TYPE_F32,
  TYPE_F64) = range(11)
 SCORE_CRP_PRIOR = 0x1

@@ -37,7 +37,7 @@ size_t primitive_size(int t) {
   return (t >= 0 && t < MSC_TYPE_NELEMS) ? sz[t] : 0;
 }
 
-static bool family_ok(int f) { return f >= MSC_BB && f <= MSC_BBNC; }
+static bool family_ok(int f) { return f >= MSC_BB && f <= MSC_DM; }
 
 template <typename T>
 static int dev_alloc(std::vector<void *> &owned, T **out, size_t count) {
@@ -175,6 +175,8 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
   }
   v->col_max.assign(ntypes, -1);
   v->chunk_max.assign(ntypes, nullptr);
+  v->dm_max.assign(ntypes, std::vector<uint32_t>());
+  v->dm_tot.assign(ntypes, nullptr);
   if (nrows > 0) {
     if ((rc = dev_alloc(scratch, &rec_dev, (size_t)nrows * rowsize))) return cleanup(rc);
     if ((rc = dev_alloc(scratch, &uf_dev, ntypes))) return cleanup(rc);
@@ -217,6 +219,8 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
   }
   v->col_max.assign(ntypes, -1);
   v->chunk_max.assign(ntypes, nullptr);
+  v->dm_max.assign(ntypes, std::vector<uint32_t>());
+  v->dm_tot.assign(ntypes, nullptr);
   *out = v.release();
   return MSC_OK;
 }
@@ -257,6 +261,8 @@ extern "C" size_t msc_hp_floats(int family, uint32_t dim) {
     case MSC_DD: return dim;
     case MSC_NICH: return 4;
     case MSC_NIW: return 2 + (size_t)dim + (size_t)dim * dim;
+    case MSC_BNB: return 3;
+    case MSC_DM: return dim;
     default: return 0;
   }
 }
@@ -269,6 +275,8 @@ extern "C" size_t msc_ss_bytes(int family, uint32_t dim) {
     case MSC_DD: return 4 * (1 + (size_t)dim);
     case MSC_NICH: return 12;
     case MSC_NIW: return 4 * (1 + (size_t)dim + (size_t)dim * dim);
+    case MSC_BNB: return 8;
+    case MSC_DM: return 4 * ((size_t)dim + 1);
     default: return 4;
   }
 }
@@ -281,6 +289,8 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
     case MSC_BBNC: hp[0] = 1; hp[1] = 1; break;
     case MSC_GP: hp[0] = 1; hp[1] = 1; break;
     case MSC_DD: std::fill(hp.begin(), hp.end(), 1.f); break;
+    case MSC_DM: std::fill(hp.begin(), hp.end(), 1.f); break;     // models.pyx:287 (dd's defaults)
+    case MSC_BNB: hp[0] = 1; hp[1] = 1; hp[2] = 1; break;          // models.pyx:200
     case MSC_NICH: hp[0] = 0; hp[1] = 1; hp[2] = 1; hp[3] = 1; break;
     case MSC_NIW:
       hp[0] = 1; hp[1] = (float)dim;
@@ -321,6 +331,8 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     if (h.family == MSC_DD && (h.dim == 0 || h.dim > kMaxDDDim))
       return fail(MSC_EUNSUPPORTED, "feature %u: dd dim %u outside 1..%u (DirichletDiscrete<128>)", f,
                   h.dim, kMaxDDDim);
+    if (h.family == MSC_DM && (h.dim == 0 || h.dim > kMaxDDDim))
+      return fail(MSC_EUNSUPPORTED, "feature %u: dm categories %u outside 1..%u", f, h.dim, kMaxDDDim);
     if (h.family == MSC_NIW && (h.dim == 0 || h.dim > 32))
       return fail(MSC_EUNSUPPORTED, "feature %u: niw dim %u outside 1..32 (one 32x32 MFMA tile)", f, h.dim);
     h.i64_off = n_i64;
@@ -350,6 +362,10 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     const size_t nf32 = h.family == MSC_NIW ? (size_t)ngroups * (h.dim + (size_t)h.dim * h.dim)
                                             : (size_t)raw_f32_rows(h.family) * kpad;
     if ((rc = dev_alloc(st->owned, &h.raw_f32, nf32))) return bail(rc);
+    if (h.family == MSC_DM) {
+      if ((rc = dev_alloc(st->owned, &h.dm_meta_dev, 2 * ((size_t)h.dim + 1)))) return bail(rc);
+      h.dm_meta.assign(2 * ((size_t)h.dim + 1), 0u);
+    }
     if (h.family == MSC_NIW) {
       if ((rc = dev_alloc(st->owned, &h.niw_w, (size_t)ngroups * 32 * 32))) return bail(rc);
       if ((rc = dev_alloc(st->owned, &h.niw_b, (size_t)ngroups * 64))) return bail(rc);
@@ -381,8 +397,9 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     d.niw_mu64 = h.niw_mu64;
     d.niw_c64 = h.niw_c64;
     d.vcap = 32;
+    d.dm_meta = nullptr;       // set when a column is bound
     d.aux = 0.0;
-    for (float a : h.hp) d.aux += h.family == MSC_DD ? (double)a : 0.0;
+    for (float a : h.hp) d.aux += h.family == MSC_DD || h.family == MSC_DM ? (double)a : 0.0;
   }
   st->cnt_additive_valid = true;
   if ((rc = upload_desc(st.get()))) return bail(rc);
@@ -420,7 +437,7 @@ extern "C" int msc_state_set_hp(msc_state *st, uint32_t feature, const float *ho
     MSC_HIP(hipStreamSynchronize(st->ctx->stream));
   }
   h.derived_valid = false;
-  if (h.family == MSC_DD) {
+  if (h.family == MSC_DD || h.family == MSC_DM) {
     double asum = 0;
     for (float a : h.hp) asum += (double)a;
     st->desc_host[feature].aux = asum;
@@ -596,6 +613,63 @@ extern "C" int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, 
 // ---------------------------------------------------------------------------
 // binding a dataview to the state's features
 // ---------------------------------------------------------------------------
+// dm: one exact count table per category and one for the row totals, each covering 0..max of what the
+// bound column holds (capped at kGpMaxTable); the maxima are found once per view column.
+static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, uint32_t c) {
+  msc_feature_host &h = st->feats[f];
+  FeatDesc &d = st->desc_host[f];
+  const uint32_t nst = h.dim + 1;
+  hipStream_t s = st->ctx->stream;
+  const size_t nchunks = (size_t)((view->nrows + 127) / 128);
+  if (view->dm_max[c].empty()) {
+    std::vector<uint32_t> mx(nst, 0u);
+    if (view->nrows > 0) {
+      void *cm = nullptr, *tmp = nullptr, *tot = nullptr;
+      MSC_HIP(hipMalloc(&cm, sizeof(uint16_t) * (nchunks * nst + 1)));
+      view->owned_lazy.push_back(cm);
+      MSC_HIP(hipMalloc(&tmp, sizeof(uint32_t) * nst));
+      view->owned_lazy.push_back(tmp);
+      MSC_HIP(hipMalloc(&tot, sizeof(uint32_t) * view->nrows));
+      view->owned_lazy.push_back(tot);
+      view->dm_tot[c] = static_cast<uint32_t *>(tot);
+      MSC_HIP(hipMemsetAsync(tmp, 0, sizeof(uint32_t) * nst, s));
+      if (launch_dm_stats(s, static_cast<const uint32_t *>(view->cols[c]), view->nrows, h.dim,
+                          static_cast<uint16_t *>(cm), static_cast<uint32_t *>(tmp), view->dm_tot[c]))
+        return fail(MSC_EHIP, "k_dm_stats launch failed");
+      MSC_HIP(hipMemcpyAsync(mx.data(), tmp, sizeof(uint32_t) * nst, hipMemcpyDeviceToHost, s));
+      MSC_HIP(hipStreamSynchronize(s));
+      view->chunk_max[c] = static_cast<uint16_t *>(cm);
+    }
+    view->dm_max[c] = mx;
+  }
+  d.chunk_max = view->chunk_max[c];
+  d.cm_stride = (uint32_t)nchunks;
+  d.dm_tot = view->dm_tot[c];
+  std::vector<uint32_t> meta(2 * (size_t)nst);
+  uint32_t rows = 0;
+  for (uint32_t i = 0; i < nst; i++) {
+    const uint32_t vcap = (uint32_t)std::min<unsigned long long>((unsigned long long)view->dm_max[c][i] + 1ull, kGpMaxTable);
+    meta[2 * i] = rows;
+    meta[2 * i + 1] = vcap;
+    rows += 2 * vcap;                                   // (hi, lo) row pairs
+  }
+  if (meta != h.dm_meta || d.dm_meta == nullptr) {
+    if ((size_t)rows + 4 > h.tab_rows_cap) {           // grow the table buffer (the old one stays owned until destroy)
+      float *t = nullptr;
+      MSC_TRY(dev_alloc(st->owned, &t, ((size_t)rows + 4) * st->kpad));
+      h.tab = t;
+      h.tab_rows_cap = (size_t)rows + 4;
+      d.tab = t;
+    }
+    h.dm_meta = meta;
+    MSC_HIP(hipMemcpyAsync(h.dm_meta_dev, h.dm_meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, s));
+    MSC_HIP(hipStreamSynchronize(s));                  // meta is a local the copy reads from
+    d.dm_meta = h.dm_meta_dev;
+    h.derived_valid = false;
+  }
+  return MSC_OK;
+}
+
 static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
                      uint64_t nrows) {
   MSC_REQUIRE(view, "null dataview");
@@ -618,7 +692,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
     const msc_feature_host &h = st->feats[f];
     const msc_runtime_type t = view->types[c];
     if (h.family != MSC_NOOP) {
-      const uint32_t want_n = h.family == MSC_NIW ? h.dim : 1;
+      const uint32_t want_n = h.family == MSC_NIW || h.family == MSC_DM ? h.dim : 1;
       // model::get_runtime_type() must match the column (distributions.hpp:398-403, _dataview.pyx:27-44)
       MSC_REQUIRE(t.type == value_type_of(h.family) && t.count == want_n,
                   "feature %u: column %u has type (%d x %u) but the model wants (%d x %u); convert at upload",
@@ -628,8 +702,8 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
     st->desc_host[f].col = view->cols[c];
     st->desc_host[f].mask = static_cast<const uint8_t *>(view->masks[c]);
     st->desc_host[f].col_type = t.type;
-    if (h.family == MSC_GP) {
-      // the exact gp table covers counts 0..max of the bound column (capped): find the max once
+    if (is_count_family(h.family)) {
+      // the exact table covers counts 0..max of the bound column (capped): find the max once
       if (view->col_max[c] < 0) {
         uint32_t mx = 0;
         if (view->nrows > 0) {
@@ -656,6 +730,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
         st->feats[f].derived_valid = false;
       }
     }
+    if (h.family == MSC_DM) MSC_TRY(bind_dm_column(st, f, view, c));
   }
   st->bound_view = view;
   st->bound_serial = view->serial;
@@ -673,6 +748,10 @@ static int ensure_derived(msc_state *st) {
     if (st->feats[f].family == MSC_NIW && !st->feats[f].derived_valid &&
         launch_niw_prepare(st->ctx->stream, st->desc_dev, f, st->feats[f].dim, st->K, st->kpad))
       return fail(MSC_EHIP, "k_niw_prepare launch failed");
+  for (uint32_t f = 0; f < st->nfeat; f++)
+    if (st->feats[f].family == MSC_DM && !st->feats[f].derived_valid && st->desc_host[f].dm_meta != nullptr &&
+        launch_dm_prepare(st->ctx->stream, st->desc_dev, (int)f, st->feats[f].dim, st->kpad))
+      return fail(MSC_EHIP, "k_dm_prepare launch failed");
   for (auto &h : st->feats) h.derived_valid = true;
   return MSC_OK;
 }
@@ -702,8 +781,12 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
 }
 
 static bool gp_beyond_table(const msc_state *st, uint32_t f) {
-  return st->feats[f].family == MSC_GP && st->bound_view &&
-         st->bound_view->col_max[st->bound_cols[f]] >= (long long)kGpMaxTable;
+  if (!st->bound_view) return false;
+  const uint32_t c = st->bound_cols[f];
+  if (is_count_family(st->feats[f].family)) return st->bound_view->col_max[c] >= (long long)kGpMaxTable;
+  if (st->feats[f].family == MSC_DM)      // a row goes to the double path when its total is beyond the tables
+    return !st->bound_view->dm_max[c].empty() && st->bound_view->dm_max[c].back() >= kGpMaxTable;
+  return false;
 }
 
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
@@ -719,7 +802,10 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   bool written = false;
   if (n_niw < st->nfeat || crp) {
-    if (launch_score(s, st->ctx->num_cus, nich1, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
+    bool has_dm = false;
+    for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
+    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : MSC_PATH_TILE;
+    if (launch_score(s, st->ctx->num_cus, path, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
                      z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
@@ -833,14 +919,18 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
   const int cus = st->ctx->num_cus;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   bool fused_ok = true;        // niw and gp-beyond-table features need the materialised path
-  for (uint32_t f = 0; f < st->nfeat; f++) fused_ok &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
+  bool has_dm = false;
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    fused_ok &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
+    has_dm |= st->feats[f].family == MSC_DM;
+  }
   int rc = -2;
   if (fused_ok && (nich1 ? st->K <= 1024 : st->K <= 256)) {
     MSC_TRY(ensure_own(st, nrows));
     if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
     if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
-    else rc = launch_sweep_mixed(s, cus, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
+    else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
   }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
@@ -898,8 +988,9 @@ extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, i
   MSC_REQUIRE(op <= MSC_OP_REMOVE || score, "null score");
   if (family == MSC_DD) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dd dim %u outside 1..%u", dim, kMaxDDDim);
   if (family == MSC_NIW) MSC_REQUIRE(dim >= 1 && dim <= 32, "niw dim %u outside 1..32", dim);
+  if (family == MSC_DM) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dm categories %u outside 1..%u", dim, kMaxDDDim);
   const size_t hp_bytes = msc_hp_floats(family, dim) * sizeof(float), ss_bytes = msc_ss_bytes(family, dim);
-  const size_t v_bytes = (family == MSC_BB || family == MSC_BBNC) ? 1 : family == MSC_NIW ? 4 * (size_t)dim : 4;
+  const size_t v_bytes = (family == MSC_BB || family == MSC_BBNC) ? 1 : (family == MSC_NIW || family == MSC_DM) ? 4 * (size_t)dim : 4;
   auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
   MailboxHeader hd;
   hd.family = family; hd.dim = (int32_t)dim; hd.op = op; hd.status = 0; hd.score = 0.f;

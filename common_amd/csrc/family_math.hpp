@@ -148,6 +148,88 @@ MSC_DEV double gp_score_data(const float *hp, uint32_t count, uint32_t sum, doub
   return lgamma(a) - lgamma(al) + al * log(ib) - a * log(b) - log_prod;
 }
 
+// ============================ Beta-Negative-Binomial ========================
+// hp {alpha, beta, r}; posterior a = alpha + r*count, b = beta + sum; predictive
+//   score(v) = lgamma(r+v) - lgamma(v+1) - lgamma(r) + lgamma(a+b) - lgamma(a) - lgamma(b)
+//            + lgamma(a+r) + lgamma(b+v) - lgamma(a+r+b+v)
+// Same evaluation scheme as gp: an exact per-group table (rows GP_T0 + v) for the counts the
+// bound column holds, and the formula in double for counts beyond the table.
+MSC_DEV double bnb_score_exact(double a, double b, double r, double v) {
+  return lgamma(r + v) - lgamma(v + 1.0) - lgamma(r) + lgamma(a + b) - lgamma(a) - lgamma(b) +
+         lgamma(a + r) + lgamma(b + v) - lgamma(a + r + b + v);
+}
+MSC_DEV double bnb_score(const float *hp, double count, double sum, double v) {
+  const double r = hp[2];
+  return bnb_score_exact((double)hp[0] + r * count, (double)hp[1] + sum, r, v);
+}
+// marginal up to the data-only term sum_i log C(r+v_i-1, v_i), which {count, sum} cannot carry
+MSC_DEV double bnb_score_data(const float *hp, uint32_t count, uint32_t sum) {
+  const double al = hp[0], be = hp[1], r = hp[2];
+  const double a = al + r * (double)count, b = be + (double)sum;
+  return lgamma(al + be) - lgamma(al) - lgamma(be) + lgamma(a) + lgamma(b) - lgamma(a + b);
+}
+
+// ============================ Dirichlet-Multinomial =========================
+// src/models/dm.cpp:39-76.  With n_i the group's count of category i, N = sum n_i, A = sum alpha_i,
+// X = sum x_i:
+//   score(x) = sum_i [ lgamma(a_i+n_i+x_i) - lgamma(a_i+n_i) - lgamma(x_i+1) ]
+//            + lgamma(A+N) - lgamma(A+N+X) + lgamma(X+1)
+// i.e. dim+1 independent count lookups: one exact table per category (indexed by x_i) and one for
+// the row total (indexed by X).  The tile kernel treats them as dim+1 gp-like stages.
+// The terms are each ~x ln n while their sum is O(10): a float per entry cannot carry that
+// cancellation.  Every entry is therefore stored as a pair: hi = the value rounded to a multiple
+// of 2^-6 (|hi| < 2^17, so float sums of hi parts are EXACT while |sum| < 2^18, which holds for
+// row totals below the table cap) and lo = the remainder (|lo| <= 2^-7).  The kernel sums the hi
+// and lo parts of a feature's stages separately and adds them to the score once.
+// Rows whose total is beyond the table cap are scored by the large-count kernel in double.
+constexpr double kDmGrid = 64.0;
+MSC_DEV void dm_split(double t, float &hi, float &lo) {
+  const double h = rint(t * kDmGrid) / kDmGrid;
+  hi = (float)h;
+  lo = (float)(t - h);
+}
+MSC_DEV double dm_cat_term(double alpha_i, double n_i, double x) {
+  return lgamma(alpha_i + n_i + x) - lgamma(alpha_i + n_i) - lgamma(x + 1.0);
+}
+MSC_DEV double dm_sum_term(double A, double N, double X) {
+  return lgamma(A + N) - lgamma(A + N + X) + lgamma(X + 1.0);
+}
+// score of the vector at `x` (dim int32) against counts read with stride `cstride` (in u32),
+// each lowered by the vector itself when loo
+MSC_DEV double dm_score_direct(const float *hp, uint32_t dim, const uint32_t *counts, size_t cstride,
+                               const int32_t *x, bool loo) {
+  double s = 0, A = 0, N = 0, X = 0;
+  for (uint32_t i = 0; i < dim; i++) {
+    const double xi = (double)(uint32_t)x[i];
+    const double ni = (double)counts[(size_t)i * cstride] - (loo ? xi : 0.0);
+    s += dm_cat_term((double)hp[i], ni, xi);
+    A += (double)hp[i];
+    N += ni;
+    X += xi;
+  }
+  return s + dm_sum_term(A, N, X);
+}
+// the row's contribution to `ratio` (dm.cpp:10-22)
+MSC_DEV double dm_row_ratio(uint32_t dim, const int32_t *x) {
+  double r = 0, X = 0;
+  for (uint32_t i = 0; i < dim; i++) {
+    const double xi = (double)(uint32_t)x[i];
+    r -= lgamma(xi + 1.0);
+    X += xi;
+  }
+  return r + lgamma(X + 1.0);
+}
+MSC_DEV double dm_score_data(const float *hp, uint32_t dim, const uint32_t *counts, size_t cstride, double ratio) {
+  double s = ratio, A = 0, N = 0;
+  for (uint32_t i = 0; i < dim; i++) {
+    const double a = hp[i], c = counts[(size_t)i * cstride];
+    A += a;
+    N += c;
+    s += lgamma(c + a) - lgamma(a);
+  }
+  return s + lgamma(A) - lgamma(A + N);
+}
+
 // ============================ Normal-Inverse-Chi^2 ==========================
 // Posterior (kappa', mu', nu', sigmasq') from (count, mean, count_times_variance);
 // Student-t predictive  score(x) = c0 - c1 * log1p(c2 (x - mu')^2)

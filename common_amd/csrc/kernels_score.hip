@@ -7,7 +7,8 @@
 //   k_score_tile    any feature list; per-feature tables copied to LDS per workgroup by async
 //                   global_load_lds, double-buffered (score_block.hpp); scores summed over
 //                   features in registers, one store per row
-//   k_gp_large_fix  gp counts beyond the exact table: Loader's saddle-point form in double
+//   k_dm_prepare    the dim+1 exact count tables of a Dirichlet-Multinomial feature
+//   k_gp_large_fix  gp / bnb / dm counts beyond the exact tables, in double (gp: Loader's saddle-point form)
 //
 // Mapping used by every score kernel: a wave owns a block of rows and one k-tile of 256
 // groups; lane l owns groups 4l..4l+3 of the tile, so a row of the tile is one 16-byte value
@@ -49,6 +50,11 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       for (uint32_t v = 0; v < fd.vcap; v++)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
     } break;
+    case MSC_BNB: {
+      const double cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
+      for (uint32_t v = 0; v < fd.vcap; v++)
+        fd.tab[(size_t)(GP_T0 + v) * kpad + k] = (float)bnb_score(fd.hp, cnt, sum, (double)v);
+    } break;
     case MSC_DD: {
       const uint32_t csum = fd.raw_u32[k];
       for (uint32_t i = 0; i < fd.dim; i++)
@@ -62,6 +68,26 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       for (int i = 0; i < NICH_ROWS; i++) fd.tab[(size_t)i * kpad + k] = o[i];
     } break;
     default: break;
+  }
+}
+
+// dm tables: blockIdx.y = stage (category i < dim, or dim = the row total); one thread per group slot
+__global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__ feats, int f, uint32_t kpad) {
+  const FeatDesc fd = feats[f];
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x, sub = blockIdx.y;
+  if (k >= kpad || fd.dm_meta == nullptr) return;
+  const uint32_t first = fd.dm_meta[2 * sub], rows = fd.dm_meta[2 * sub + 1];
+  float *t = fd.tab + (size_t)first * kpad + k;         // count v: rows 2v (hi) and 2v + 1 (lo)
+  double a = 0, n = 0;
+  if (sub < fd.dim) {
+    a = fd.hp[sub];
+    n = fd.raw_u32[(size_t)sub * kpad + k];
+  } else {
+    for (uint32_t i = 0; i < fd.dim; i++) n += (double)fd.raw_u32[(size_t)i * kpad + k];
+  }
+  for (uint32_t v = 0; v < rows; v++) {
+    const double term = sub < fd.dim ? dm_cat_term(a, n, (double)v) : dm_sum_term(fd.aux, n, (double)v);
+    dm_split(term, t[(size_t)(2 * v) * kpad], t[(size_t)(2 * v + 1) * kpad]);
   }
 }
 
@@ -112,7 +138,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   }
   for (int f = 0; f < nfeat; f++) {
     const FeatDesc fd = feats[f];
-    if (fd.mask != nullptr && fd.family != MSC_NIW && fd.mask[row] != 0) continue;
+    if (fd.family != MSC_NIW && load_masked(fd, row, true)) continue;
     switch (fd.family) {
       case MSC_BB:
         s += bb_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
@@ -122,6 +148,15 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         break;
       case MSC_GP:
         s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);
+        break;
+      case MSC_BNB:
+        s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0,
+                       (double)fd.raw_u32[kpad + g] - (double)reinterpret_cast<const uint32_t *>(fd.col)[row],
+                       (double)reinterpret_cast<const uint32_t *>(fd.col)[row]);
+        break;
+      case MSC_DM:
+        s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad,
+                             reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim, true);
         break;
       case MSC_DD: {
         int v = reinterpret_cast<const int32_t *>(fd.col)[row];
@@ -232,8 +267,8 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
 // general path: any feature list, workgroup tiles with LDS-staged tables.
 //   grid.x = row chunks of 8*R rows (grid-stride), grid.y = k-tiles, block = 8 waves
 // ---------------------------------------------------------------------------
-template <int R, int W, bool LOO, bool CRP>
-__global__ __launch_bounds__(W * 64, W / 4) void k_score_tile(const FeatDesc *__restrict__ feats,
+template <int R, int W, bool LOO, bool CRP, bool DM>
+__global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const FeatDesc *__restrict__ feats,
                                                                  int nfeat, uint32_t K, uint32_t kpad,
                                                                  uint64_t row0, uint64_t nrows,
                                                                  const int32_t *__restrict__ z,
@@ -271,7 +306,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_score_tile(const FeatDesc *__
     }
     const uint64_t wg0 = chunk * rows_per_wg;
     const uint32_t wgn = (uint32_t)((nrows - wg0) < rows_per_wg ? (nrows - wg0) : rows_per_wg);
-    score_tile<R, W>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {
@@ -287,8 +322,9 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_score_tile(const FeatDesc *__
 }
 
 // ---------------------------------------------------------------------------
-// gp counts >= vcap (only when a column's maximum exceeds the table cap): one wave per row,
-// lanes over groups; adds the exact value (the own group's value is already the loo one).
+// counts beyond the exact tables of gp / bnb / dm (only launched when a column's maximum exceeds
+// the table cap): one wave per row, lanes over groups; adds the exact value in double (the own
+// group's value is already the leave-one-out one).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict__ feats, int f, uint32_t K,
                                                        uint32_t kpad, uint64_t row0, uint64_t nrows,
@@ -298,17 +334,31 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
   const int lane = threadIdx.x & 63;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  if (fd.family == MSC_DM) {       // rows whose total is beyond the tables were skipped whole by the tile kernel
+    for (uint64_t n = wave_id; n < nrows; n += nwaves) {
+      if (fd.dm_tot[row0 + n] < kGpMaxTable || load_masked(fd, row0 + n, true)) continue;
+      const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + (row0 + n) * fd.dim;
+      const int g = z ? z[n] : -1;
+      for (uint32_t k = lane; k < K; k += 64)
+        if ((int)k != g) out[n * ld + k] += (float)dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + k, kpad, x, false);
+    }
+    return;
+  }
   const double al = fd.hp[0], ib = fd.hp[1];
   for (uint64_t n = wave_id; n < nrows; n += nwaves) {
     const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row0 + n];
     if (v < fd.vcap || (fd.mask != nullptr && fd.mask[row0 + n] != 0)) continue;
     const int g = z ? z[n] : -1;
-    const double rowc = gp_row_const(v);
+    const double rowc = fd.family == MSC_GP ? gp_row_const(v) : 0.0;
     for (uint32_t k = lane; k < K; k += 64) {
       if ((int)k == g) continue;
-      const double a = al + (double)fd.raw_u32[(size_t)kpad + k], b = ib + (double)fd.raw_u32[k];
-      const double nse = (double)fd.tab[(size_t)GP_NSE_HI * kpad + k] + (double)fd.tab[(size_t)GP_NSE_LO * kpad + k];
-      out[n * ld + k] += gp_eval_large((double)v, rowc, a, b, nse);
+      if (fd.family == MSC_GP) {
+        const double a = al + (double)fd.raw_u32[(size_t)kpad + k], b = ib + (double)fd.raw_u32[k];
+        const double nse = (double)fd.tab[(size_t)GP_NSE_HI * kpad + k] + (double)fd.tab[(size_t)GP_NSE_LO * kpad + k];
+        out[n * ld + k] += gp_eval_large((double)v, rowc, a, b, nse);
+      } else {
+        out[n * ld + k] += (float)bnb_score(fd.hp, (double)fd.raw_u32[k], (double)fd.raw_u32[(size_t)kpad + k], (double)v);
+      }
     }
   }
 }
@@ -319,6 +369,11 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad) {
   dim3 grid((kpad + 255) / 256, nfeat);
   hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, stream, feats_dev, kpad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad) {
+  hipLaunchKernelGGL(k_dm_prepare, dim3((kpad + 255) / 256, dim + 1), dim3(256), 0, stream, feats_dev, f, kpad);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -354,11 +409,11 @@ int tile_rows_per_wave() {
 }
 
 template <bool LOO, bool CRP>
-static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev,
+static void launch_score_t(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev,
                            int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
-  if (nich1) {
+  if (path == MSC_PATH_NICH1) {
     // One 4-row quad per wave and non-temporal stores measured best on C2 and on the C5 shard
     // (profiles/r01_nich1_variants.txt, second table): 5.8-6.0 TB/s vs 5.4-5.6 for 32-row chunks per wave.
     // A wave only loops when the grid would otherwise exceed the launch limit.
@@ -374,31 +429,36 @@ static void launch_score_t(hipStream_t stream, int num_cus, bool nich1, const Fe
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)
+    // states with a dm feature: 8 waves x 8 rows (64 rows per workgroup, 256-register budget for the hi/lo sums)
     const int R = tile_rows_per_wave();
-    const uint64_t nchunks = (nrows + 127) / 128;
+    const uint64_t rows_per_wg = path == MSC_PATH_TILE_DM ? 64 : 128;
+    const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
     uint64_t gx = nchunks;
     const uint64_t cap = (uint64_t)num_cus * 4;
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
     const dim3 grid((unsigned)gx, ktiles);
-    if (R == 16)
-      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
+    if (path == MSC_PATH_TILE_DM)
+      hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
+    else if (R == 16)
+      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else
-      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
   }
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)
-int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev, int nfeat,
+int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;
-  if (loo && pri) launch_score_t<true, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (loo) launch_score_t<true, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (pri) launch_score_t<false, true>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else launch_score_t<false, false>(stream, num_cus, nich1, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (loo) launch_score_t<true, false>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (pri) launch_score_t<false, true>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else launch_score_t<false, false>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -131,6 +131,22 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
           score = gp_score_exact((double)hp[0] + (double)su[1], (double)hp[1] + (double)su[0], (double)v);
         else score = gp_score_data(hp, su[0], su[1], (double)sf[2]);
       } break;
+      case MSC_BNB: {       // record {u32 count, u32 sum}
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(val);
+        if (op == MSC_OP_ADD) { su[0]++; su[1] += v; }
+        else if (op == MSC_OP_REMOVE) { su[0]--; su[1] -= v; }
+        else if (op == MSC_OP_SCORE_VALUE) score = bnb_score(hp, (double)su[0], (double)su[1], (double)v);
+        else score = bnb_score_data(hp, su[0], su[1]);
+      } break;
+      case MSC_DM: {        // record {u32 counts[d], f32 ratio} (dm.hpp:86-88)
+        const int32_t *x = reinterpret_cast<const int32_t *>(val);
+        if (op == MSC_OP_ADD || op == MSC_OP_REMOVE) {
+          for (uint32_t i = 0; i < d; i++) su[i] += op == MSC_OP_ADD ? (uint32_t)x[i] : 0u - (uint32_t)x[i];
+          const double rr = dm_row_ratio(d, x);
+          sf[d] = (float)((double)sf[d] + (op == MSC_OP_ADD ? rr : -rr));
+        } else if (op == MSC_OP_SCORE_VALUE) score = dm_score_direct(hp, d, su, 1, x, false);
+        else score = dm_score_data(hp, d, su, 1, (double)sf[d]);
+      } break;
       case MSC_DD: {
         const int v = *reinterpret_cast<const int32_t *>(val);
         if (op == MSC_OP_ADD) { su[0]++; su[1 + v]++; }

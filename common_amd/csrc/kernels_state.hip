@@ -22,6 +22,8 @@ __device__ __host__ inline AccShape acc_shape(int family, uint32_t dim_slice) {
     case MSC_BB: return {2, 0, 0};
     case MSC_BBNC: return {2, 0, 0};
     case MSC_GP: return {1, 1, 1};
+    case MSC_BNB: return {1, 1, 0};
+    case MSC_DM: return {0, dim_slice, 1};      // u64 per category of the slice; f64 = ratio (first slice only)
     case MSC_DD: return {dim_slice, 0, 0};
     case MSC_NICH: return {1, 0, 2};
     default: return {0, 0, 0};
@@ -57,10 +59,13 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
 
   for (int f = 0; f < nfeat; f++) {
     const FeatDesc fd = feats[f];
-    const uint32_t nslices = fd.family == MSC_DD ? (fd.dim + dd_slice - 1) / dd_slice : 1;
+    // dd and dm walk their categories in slices that fit the LDS budget (dm bins are 8 bytes wide)
+    const bool sliced = fd.family == MSC_DD || fd.family == MSC_DM;
+    const uint32_t slice = fd.family == MSC_DM ? (dd_slice > 1 ? dd_slice / 2 : 1) : dd_slice;
+    const uint32_t nslices = sliced ? (fd.dim + slice - 1) / slice : 1;
     for (uint32_t sl = 0; sl < nslices; sl++) {
-      const uint32_t c_lo = sl * dd_slice;
-      const uint32_t c_n = fd.family == MSC_DD ? (fd.dim - c_lo < dd_slice ? fd.dim - c_lo : dd_slice) : 0;
+      const uint32_t c_lo = sl * slice;
+      const uint32_t c_n = sliced ? (fd.dim - c_lo < slice ? fd.dim - c_lo : slice) : 0;
       const AccShape sh = acc_shape(fd.family, c_n);
       double *f64 = reinterpret_cast<double *>(smem);
       unsigned long long *u64 = reinterpret_cast<unsigned long long *>(f64 + (size_t)K * sh.nf64);
@@ -73,7 +78,12 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
         const int g = z[n];
         if (g < 0 || (uint32_t)g >= K) continue;
         const uint64_t row = row0 + n;
-        if (fd.mask != nullptr && fd.mask[row] != 0) continue;       // masked value: not part of the group
+        if (fd.mask != nullptr) {                                    // masked value: not part of the group
+          bool m = false;
+          if (fd.family == MSC_DM) for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
+          else m = fd.mask[row] != 0;
+          if (m) continue;
+        }
         switch (fd.family) {
           case MSC_BBNC:
           case MSC_BB: {
@@ -85,6 +95,19 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
             atomicAdd(&u32[g], 1u);
             atomicAdd(&u64[g], (unsigned long long)v);
             atomicAdd(&f64[g], lgamma((double)v + 1.0));
+          } break;
+          case MSC_BNB: {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+            atomicAdd(&u32[g], 1u);
+            atomicAdd(&u64[g], (unsigned long long)v);
+          } break;
+          case MSC_DM: {
+            const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
+            for (uint32_t i = 0; i < c_n; i++) {
+              const uint32_t v = (uint32_t)x[c_lo + i];
+              if (v) atomicAdd(&u64[(size_t)i * K + g], (unsigned long long)v);
+            }
+            if (sl == 0) atomicAdd(&f64[g], dm_row_ratio(fd.dim, x));
           } break;
           case MSC_DD: {
             const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
@@ -112,8 +135,9 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
       for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) {
         const uint32_t r = i / K, k = i - r * K;
         if (!u64[i]) continue;
-        // gp: u64 row 0 is `sum`, additive row 1
-        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)(1 + r) * kpad + k]),
+        // gp, bnb: u64 row 0 is `sum`, additive row 1; dm: category c_lo + r
+        const uint32_t dst_row = fd.family == MSC_DM ? c_lo + r : 1 + r;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
                   (unsigned long long)(sgn * (long long)u64[i]));
       }
       for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += blockDim.x) {
@@ -147,6 +171,14 @@ __global__ __launch_bounds__(256) void k_commit(const FeatDesc *__restrict__ fea
     case MSC_GP:
       fd.raw_u32[k] = (uint32_t)fd.acc_i64[k];
       fd.raw_u32[kpad + k] = (uint32_t)fd.acc_i64[kpad + k];
+      fd.raw_f32[k] = (float)fd.acc_f64[k];
+      break;
+    case MSC_BNB:
+      fd.raw_u32[k] = (uint32_t)fd.acc_i64[k];
+      fd.raw_u32[kpad + k] = (uint32_t)fd.acc_i64[kpad + k];
+      break;
+    case MSC_DM:
+      for (uint32_t i = 0; i < fd.dim; i++) fd.raw_u32[(size_t)i * kpad + k] = (uint32_t)fd.acc_i64[(size_t)i * kpad + k];
       fd.raw_f32[k] = (float)fd.acc_f64[k];
       break;
     case MSC_DD: {
@@ -197,6 +229,14 @@ __global__ __launch_bounds__(256) void k_lift(const FeatDesc *__restrict__ feats
       fd.acc_i64[kpad + k] = fd.raw_u32[kpad + k];
       fd.acc_f64[k] = fd.raw_f32[k];
       break;
+    case MSC_BNB:
+      fd.acc_i64[k] = fd.raw_u32[k];
+      fd.acc_i64[kpad + k] = fd.raw_u32[kpad + k];
+      break;
+    case MSC_DM:
+      for (uint32_t i = 0; i < fd.dim; i++) fd.acc_i64[(size_t)i * kpad + k] = fd.raw_u32[(size_t)i * kpad + k];
+      fd.acc_f64[k] = fd.raw_f32[k];
+      break;
     case MSC_DD:
       for (uint32_t i = 0; i < fd.dim; i++)
         fd.acc_i64[(size_t)i * kpad + k] = fd.raw_u32[(size_t)(1 + i) * kpad + k];
@@ -234,6 +274,8 @@ __global__ __launch_bounds__(256) void k_score_data(const FeatDesc *__restrict__
       s += lgamma(asum) - lgamma(asum + (double)fd.raw_u32[k]);
     } break;
     case MSC_NICH: s = nich_score_data(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k]); break;
+    case MSC_BNB: s = bnb_score_data(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k]); break;
+    case MSC_DM: s = dm_score_data(fd.hp, fd.dim, fd.raw_u32 + k, kpad, (double)fd.raw_f32[k]); break;
     default: break;
   }
   out[(size_t)blockIdx.y * K + k] = (float)s;
@@ -336,9 +378,50 @@ __global__ __launch_bounds__(128) void k_chunk_max_u32(const uint32_t *__restric
   }
 }
 
+// dm column (uint32 [n][dim]): for every 128-row chunk the maximum of each category and of the row
+// totals (out[(stage) * nchunks + chunk], saturated to 16 bits), and the column-wide maxima
+// (colmax[dim + 1], atomicMax; zeroed by the caller), and every row's total (tot[n]).
+// One block per chunk, one thread per row.
+__global__ __launch_bounds__(128) void k_dm_stats(const uint32_t *__restrict__ col, uint64_t n, uint32_t dim,
+                                                   uint16_t *__restrict__ out, uint32_t *__restrict__ colmax,
+                                                   uint32_t *__restrict__ rowtot) {
+  __shared__ uint32_t part[2];
+  const uint64_t i = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+  const uint32_t *x = col + i * dim;
+  uint32_t tot = 0;
+  for (uint32_t s = 0; s <= dim; s++) {
+    uint32_t m = 0;
+    if (i < n) {
+      m = s < dim ? x[s] : tot;
+      if (s < dim) tot += m;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
+      m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t mm = part[0] > part[1] ? part[0] : part[1];
+      out[(size_t)s * gridDim.x + blockIdx.x] = (uint16_t)(mm > 65535u ? 65535u : mm);
+      atomicMax(&colmax[s], mm);
+    }
+    __syncthreads();
+  }
+  if (i < n) rowtot[i] = tot;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint16_t *out_dev,
+                    uint32_t *colmax_dev, uint32_t *rowtot_dev) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_dm_stats, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, col, n, dim, out_dev,
+                     colmax_dev, rowtot_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_chunk_max_u32, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, col, n, out_dev);
@@ -356,8 +439,9 @@ int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint
 size_t accumulate_lds_bytes(const FeatDesc *feats_host, int nfeat, uint32_t K, uint32_t dd_slice) {
   size_t need = (size_t)K * 4;
   for (int f = 0; f < nfeat; f++) {
-    const uint32_t sl = feats_host[f].family == MSC_DD
-                            ? (feats_host[f].dim < dd_slice ? feats_host[f].dim : dd_slice) : 0;
+    const uint32_t cap = feats_host[f].family == MSC_DM ? (dd_slice > 1 ? dd_slice / 2 : 1) : dd_slice;
+    const uint32_t sl = feats_host[f].family == MSC_DD || feats_host[f].family == MSC_DM
+                            ? (feats_host[f].dim < cap ? feats_host[f].dim : cap) : 0;
     const AccShape sh = acc_shape(feats_host[f].family, sl);
     const size_t b = (size_t)K * (8u * sh.nf64 + 8u * sh.nu64 + 4u * sh.nu32);
     if (b > need) need = b;

@@ -24,6 +24,7 @@ int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int fam
 
 // kernels_score.hip
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad);
+int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad);
 int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
                        float *crp);
 int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
@@ -31,7 +32,9 @@ int launch_loo_own(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uin
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);
-int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *feats_dev, int nfeat,
+// which scoring kernel a state takes (abi.cpp decides from its feature list)
+enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2 };
+int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
 
@@ -39,7 +42,7 @@ int launch_score(hipStream_t stream, int num_cus, bool nich1, const FeatDesc *fe
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep);
-int launch_sweep_mixed(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep);
 int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
@@ -68,6 +71,8 @@ int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32
                 long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt);
 int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                       uint32_t kpad, float *out);
+int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint16_t *out_dev,
+                    uint32_t *colmax_dev, uint32_t *rowtot_dev);
 int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev);
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,

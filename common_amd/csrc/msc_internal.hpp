@@ -63,12 +63,16 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 //   dd   u32 {count_sum, counts[dim]}
 //   nich u32 {count}                 f32 {mean, count_times_variance}
 //   niw  u32 {count}                 f32 group-major {sum_x[d]} then {sum_xxT[d*d]} (see niw_* offsets)
+//   bnb  u32 {count, sum}
+//   dm   u32 {counts[dim]}           f32 {ratio}
 // Additive tables (the all-reduce payload):
 //   bb   i64 {heads, tails}
 //   gp   i64 {count, sum}            f64 {log_prod}
 //   dd   i64 {counts[dim]}
 //   nich i64 {count}                 f64 {sum_x, sum_xx}
 //   niw  i64 {count}                 f64 group-major {sum_x[d]}, {sum_xxT[d*d]}
+//   bnb  i64 {count, sum}
+//   dm   i64 {counts[dim]}           f64 {ratio}
 struct FeatDesc {
   int32_t family;
   uint32_t dim;
@@ -88,16 +92,25 @@ struct FeatDesc {
   double *niw_mu64;        // niw only: [K][32] posterior mean
   double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
   double aux;              // dd: sum of the alphas
-  uint32_t vcap;           // gp: rows of the exact table (min(column max + 1, kGpMaxTable))
-  uint32_t pad1;
-  const uint16_t *chunk_max;  // gp: max count of every 128-row chunk of the bound column (null: unknown)
+  uint32_t vcap;           // gp, bnb: rows of the exact table (min(column max + 1, kGpMaxTable))
+  uint32_t cm_stride;      // dm: entries per stage in chunk_max (= 128-row chunks of the bound view)
+  const uint16_t *chunk_max;  // gp, bnb: max count of every 128-row chunk of the bound column (null: unknown)
+                              // dm: [dim+1][cm_stride], one row per category and one for the row totals
+  const uint32_t *dm_meta;    // dm: [dim+1][2] = {first table row, counts covered} of every stage (device);
+                              //     count v of a stage occupies table rows first + 2v (hi) and first + 2v + 1 (lo)
+  const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)
 };
+
+// families whose score is a lookup of the row's count in an exact per-group table
+__host__ __device__ inline bool is_count_family(int family) { return family == MSC_GP || family == MSC_BNB; }
 
 inline uint32_t tab_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
     case MSC_BBNC: return 2;
     case MSC_GP: return 2 + kGpMaxTable;   // GP_T0 + table rows (family_math.hpp)
+    case MSC_BNB: return 2 + kGpMaxTable;
+    case MSC_DM: return 0;                  // sized when a column is bound (sum of the stages' tables)
     case MSC_DD: return dim;
     case MSC_NICH: return 6; // NICH_ROWS
     case MSC_NIW: return 8;  // NIW_ROWS + 1 (kernels_niw.hip)
@@ -109,6 +122,8 @@ inline uint32_t raw_u32_rows(int family, uint32_t dim) {
     case MSC_BB: return 2;
     case MSC_BBNC: return 2;
     case MSC_GP: return 2;
+    case MSC_BNB: return 2;
+    case MSC_DM: return dim;
     case MSC_DD: return 1 + dim;
     case MSC_NICH: return 1;
     case MSC_NIW: return 1;
@@ -120,6 +135,7 @@ inline uint32_t raw_f32_rows(int family) {
   switch (family) {
     case MSC_GP: return 1;
     case MSC_BBNC: return 1;   // p
+    case MSC_DM: return 1;     // ratio
     case MSC_NICH: return 2;
     default: return 0;
   }
@@ -129,6 +145,8 @@ inline uint32_t acc_i64_rows(int family, uint32_t dim) {
     case MSC_BB: return 2;
     case MSC_BBNC: return 2;
     case MSC_GP: return 2;
+    case MSC_BNB: return 2;
+    case MSC_DM: return dim;
     case MSC_DD: return dim;
     case MSC_NICH: return 1;
     case MSC_NIW: return 1;
@@ -138,6 +156,7 @@ inline uint32_t acc_i64_rows(int family, uint32_t dim) {
 inline uint32_t acc_f64_rows(int family) {
   switch (family) {
     case MSC_GP: return 1;
+    case MSC_DM: return 1;
     case MSC_NICH: return 2;
     default: return 0;
   }
@@ -147,6 +166,8 @@ inline int value_type_of(int family) {
     case MSC_BB: return MSC_TYPE_B;
     case MSC_BBNC: return MSC_TYPE_B;
     case MSC_GP: return MSC_TYPE_U32;
+    case MSC_BNB: return MSC_TYPE_U32;
+    case MSC_DM: return MSC_TYPE_I32;
     case MSC_DD: return MSC_TYPE_I32;
     case MSC_NICH: return MSC_TYPE_F32;
     case MSC_NIW: return MSC_TYPE_F32;
@@ -178,6 +199,8 @@ struct msc_dataview {
   std::vector<void *> owned;             // allocations to free
   mutable std::vector<long long> col_max;  // lazily computed maximum of uint32 columns (-1 = unknown)
   mutable std::vector<uint16_t *> chunk_max;  // and of every 128-row chunk of them (device, owned)
+  mutable std::vector<std::vector<uint32_t>> dm_max;  // dm columns: maxima of each category and of the row totals (lazy)
+  mutable std::vector<uint32_t *> dm_tot;             // dm columns: row totals (device, owned)
   mutable std::vector<void *> owned_lazy;
 };
 
@@ -194,6 +217,9 @@ struct msc_feature_host {
   double *niw_w64 = nullptr, *niw_mu64 = nullptr, *niw_c64 = nullptr;
   size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
   size_t f64_off = 0, f64_len = 0;
+  size_t tab_rows_cap = 0;      // dm: rows (+4) the table buffer holds; it is (re)sized when a column is bound
+  uint32_t *dm_meta_dev = nullptr;   // dm: [dim+1][2] stage table offsets / sizes
+  std::vector<uint32_t> dm_meta;     // host copy
   bool raw_valid = true;        // raw tables hold the truth
   bool additive_valid = false;  // additive tables are in sync with raw
   bool derived_valid = false;   // score tables are in sync with raw

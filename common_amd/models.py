@@ -3,8 +3,7 @@
 Same names (`bb`, `bnb`, `gp`, `nich`, `dd(n)`, `niw(d)`, ...), same accessor
 methods and the same default hyper-parameters; `c_desc()` returns the handle the
 HIP state consumes (family tag + dimension) instead of a `shared_ptr[model]`.
-Descriptors the HIP path does not build yet (`bnb`, `dm`)
-exist for name/pickle compatibility and raise when asked for a c_desc.
+All eight models of microscopes/models.pyx:185-290 have a HIP kernel family.
 """
 import itertools as it
 
@@ -22,7 +21,7 @@ class c_model(object):
     def get_runtime_type(self):
         """(primitive type, count): model::get_runtime_type, distributions.hpp:398-403,497-505."""
         from .runtime import VALUE_TYPE
-        return VALUE_TYPE[self.family], (self.dim if self.family == L.NIW else 1)
+        return VALUE_TYPE[self.family], (self.dim if self.family in (L.NIW, L.DM) else 1)
 
     def __repr__(self):
         return "c_model(family=%d, dim=%d)" % (self.family, self.dim)
@@ -109,7 +108,7 @@ def _nich_grid():
 
 bb = model_descriptor("bb", py_model(np.bool_), c_model(L.BB), {"alpha": 1., "beta": 1.}, {},
                       _grid2("alpha", "beta"))
-bnb = model_descriptor("bnb", py_model(np.uint32), None, {"alpha": 1., "beta": 1., "r": 1}, {},
+bnb = model_descriptor("bnb", py_model(np.uint32), c_model(L.BNB), {"alpha": 1., "beta": 1., "r": 1}, {},
                        bb._default_partial_hypergrid)
 gp = model_descriptor("gp", py_model(np.uint32), c_model(L.GP), {"alpha": 1., "inv_beta": 1.}, {},
                       _grid2("alpha", "inv_beta"))
@@ -137,5 +136,5 @@ def niw(dim):
 def dm(categories):
     if categories <= 0:
         raise ValueError("categories must be positive")
-    return model_descriptor("dm", py_model(np.dtype((np.int32, (categories,)))), None,
+    return model_descriptor("dm", py_model(np.dtype((np.int32, (categories,)))), c_model(L.DM, categories),
                             {"alphas": [1.] * categories}, {}, [])

@@ -27,7 +27,7 @@ for _n, _t in (("uint16", L.TYPE_U16), ("uint32", L.TYPE_U32), ("uint64", L.TYPE
         _TORCH_OF_TYPE[_t] = getattr(torch, _n)
 
 VALUE_TYPE = {L.BB: L.TYPE_B, L.BBNC: L.TYPE_B, L.GP: L.TYPE_U32, L.DD: L.TYPE_I32, L.NICH: L.TYPE_F32,
-              L.NIW: L.TYPE_F32, L.NOOP: L.TYPE_B}
+              L.NIW: L.TYPE_F32, L.NOOP: L.TYPE_B, L.BNB: L.TYPE_U32, L.DM: L.TYPE_I32}
 
 
 def type_of_numpy(dt):
@@ -83,6 +83,24 @@ class Context(object):
 
     def build_info(self):
         return self.lib.msc_build_info().decode()
+
+    def value_op(self, family, dim, op, hp, ss_record, value=None):
+        """One group::{add_value, remove_value, score_value, score_data} call (base.hpp:25-28) as a batch
+        of one on the device.  op: "add" | "remove" | "score_value" | "score_data".  `ss_record` is a
+        1-element array of ss_dtype(family, dim), updated in place by add/remove; returns the score."""
+        code = {"add": 0, "remove": 1, "score_value": 2, "score_data": 3}[op]
+        hpb = pack_hp(family, hp, dim)
+        assert ss_record.dtype == ss_dtype(family, dim) and ss_record.size == 1 and ss_record.flags.c_contiguous
+        vb = None
+        if value is not None:
+            vb = np.ascontiguousarray(value, dtype={L.TYPE_B: np.uint8, L.TYPE_U32: np.uint32, L.TYPE_I32: np.int32,
+                                                    L.TYPE_F32: np.float32}[VALUE_TYPE[family]])
+        score = C.c_float(0)
+        L.check(self.lib.msc_value_op_single(self._h, int(family), int(dim), code, hpb.ctypes.data_as(C.c_void_p),
+                                             ss_record.ctypes.data_as(C.c_void_p),
+                                             vb.ctypes.data_as(C.c_void_p) if vb is not None else None,
+                                             C.byref(score)))
+        return float(score.value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -202,6 +220,10 @@ def ss_dtype(family, dim=0):
         return np.dtype([("count", np.uint32), ("sum", np.uint32), ("log_prod", np.float32)])
     if family == L.DD:
         return np.dtype([("count_sum", np.uint32), ("counts", np.uint32, (dim,))])
+    if family == L.BNB:
+        return np.dtype([("count", np.uint32), ("sum", np.uint32)])
+    if family == L.DM:
+        return np.dtype([("counts", np.uint32, (dim,)), ("ratio", np.float32)])
     if family == L.NICH:
         return np.dtype([("count", np.uint32), ("mean", np.float32), ("count_times_variance", np.float32)])
     if family == L.NIW:
@@ -218,8 +240,10 @@ def pack_hp(family, hp, dim=0):
         v = [hp["alpha"], hp["beta"]]
     elif family == L.GP:
         v = [hp["alpha"], hp["inv_beta"]]
-    elif family == L.DD:
+    elif family in (L.DD, L.DM):
         v = list(hp["alphas"])
+    elif family == L.BNB:
+        v = [hp["alpha"], hp["beta"], hp["r"]]
     elif family == L.NICH:
         v = [hp["mu"], hp["kappa"], hp["sigmasq"], hp["nu"]]
     elif family == L.NIW:

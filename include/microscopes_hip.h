@@ -51,7 +51,9 @@ typedef enum msc_family {
   MSC_NICH = 3, /* NormalInverseChiSq       value float                   */
   MSC_NIW = 4,  /* NormalInverseWishart<-1> value float[dim]              */
   MSC_NOOP = 5, /* noop model, models/noop.hpp:13-53 (API-overhead control) */
-  MSC_BBNC = 6  /* non-conjugate Beta-Bernoulli with explicit p (src/models/bbnc.cpp:22-73), value bool */
+  MSC_BBNC = 6, /* non-conjugate Beta-Bernoulli with explicit p (src/models/bbnc.cpp:22-73), value bool */
+  MSC_BNB = 7,  /* BetaNegativeBinomial (distributions.hpp:29-36,59-64), hp {alpha, beta, r}, value uint32 */
+  MSC_DM = 8    /* Dirichlet-Multinomial (src/models/dm.cpp:10-97), hp alphas[dim], value int32[dim] */
 } msc_family;
 
 /* primitive types, include/microscopes/common/type_info.h:10-44 (same order) */
@@ -68,7 +70,7 @@ typedef struct msc_runtime_type {
 
 typedef struct msc_feature_spec {
   int32_t family; /* msc_family */
-  uint32_t dim;   /* dd: number of categories (<=128); niw: dimension; else 0 */
+  uint32_t dim;   /* dd: number of categories (<=128); niw: dimension; dm: categories (<=128); else 0 */
 } msc_feature_spec;
 
 typedef struct msc_context msc_context;

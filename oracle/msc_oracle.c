@@ -18,6 +18,8 @@ size_t orc_hp_size(int family, unsigned dim) {
     case ORC_DD: return dim * sizeof(float);
     case ORC_NICH: return 4 * sizeof(float);
     case ORC_NIW: return (2u + (size_t)dim + (size_t)dim * dim) * sizeof(float);
+    case ORC_BNB: return 3 * sizeof(float);
+    case ORC_DM: return dim * sizeof(float);
     default: return 0;
   }
 }
@@ -30,6 +32,8 @@ size_t orc_value_size(int family, unsigned dim) {
     case ORC_DD: return 4;
     case ORC_NICH: return 4;
     case ORC_NIW: return 4u * (size_t)dim;
+    case ORC_BNB: return 4;
+    case ORC_DM: return 4u * (size_t)dim;
     default: return 1;
   }
 }

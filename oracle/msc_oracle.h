@@ -34,7 +34,7 @@ extern "C" {
 
 /* family tags (same numbering as include/microscopes_hip.h) */
 enum { ORC_BB = 0, ORC_GP = 1, ORC_DD = 2, ORC_NICH = 3, ORC_NIW = 4, ORC_NOOP = 5, ORC_BBNC = 6,
-       ORC_NFAMILIES = 7 };
+       ORC_BNB = 7, ORC_DM = 8, ORC_NFAMILIES = 9 };
 
 /* primitive types, include/microscopes/common/type_info.h:10-44 */
 enum { ORC_TYPE_B = 0, ORC_TYPE_I8, ORC_TYPE_U8, ORC_TYPE_I16, ORC_TYPE_U16,
@@ -53,8 +53,10 @@ enum { ORC_TYPE_B = 0, ORC_TYPE_I8, ORC_TYPE_U8, ORC_TYPE_I16, ORC_TYPE_U16,
  *   niw  hp {kappa, nu, mu[d], psi[d*d]} ss {u32 count, (f64: u32 pad), R sum_x[d], R sum_xxT[d*d]}
  *   noop hp {}                           ss {u32 unused}
  *   bbnc hp {alpha, beta}                ss {u32 heads, u32 tails, R p}   (src/models/bbnc.cpp:22-73; f64: 16 B)
+ *   bnb  hp {alpha, beta, r}             ss {u32 count, u32 sum}          (distributions.hpp:29-36; r is integral)
+ *   dm   hp {alphas[dim]}                ss {u32 counts[dim], (pad), R ratio}   (include/microscopes/models/dm.hpp:86-88)
  *
- * Values: bb uint8 (bool), gp uint32, dd int32, nich float, niw float[d].
+ * Values: bb uint8 (bool), gp/bnb uint32, dd int32, nich float, niw float[d], dm int32[dim].
  */
 size_t orc_f32_ss_size(int family, unsigned dim);
 size_t orc_f64_ss_size(int family, unsigned dim);

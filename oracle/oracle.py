@@ -13,8 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BB, GP, DD, NICH, NIW, NOOP, BBNC = range(7)
-FAMILY_NAMES = {BB: "bb", GP: "gp", DD: "dd", NICH: "nich", NIW: "niw", NOOP: "noop", BBNC: "bbnc"}
+BB, GP, DD, NICH, NIW, NOOP, BBNC, BNB, DM = range(9)
+FAMILY_NAMES = {BB: "bb", GP: "gp", DD: "dd", NICH: "nich", NIW: "niw", NOOP: "noop", BBNC: "bbnc",
+                BNB: "bnb", DM: "dm"}
 
 (TYPE_B, TYPE_I8, TYPE_U8, TYPE_I16, TYPE_U16, TYPE_I32, TYPE_U32, TYPE_I64, TYPE_U64,
  TYPE_F32, TYPE_F64) = range(11)
@@ -96,6 +97,13 @@ def ss_dtype(family, dim=0, prec="f64"):
         dt = np.dtype([("count", np.uint32), ("sum", np.uint32), ("log_prod", R)])
     elif family == DD:
         dt = np.dtype([("count_sum", np.uint32), ("counts", np.uint32, (dim,))])
+    elif family == BNB:
+        dt = np.dtype([("count", np.uint32), ("sum", np.uint32)])
+    elif family == DM:
+        rs = np.dtype(R).itemsize
+        off = (4 * dim + rs - 1) // rs * rs
+        dt = np.dtype({"names": ["counts", "ratio"], "formats": [(np.uint32, (dim,)), R],
+                       "offsets": [0, off], "itemsize": off + rs})
     elif family == NICH:
         dt = np.dtype([("count", np.uint32), ("mean", R), ("count_times_variance", R)], align=True)
     elif family == NIW:
@@ -114,7 +122,7 @@ def ss_dtype(family, dim=0, prec="f64"):
 def value_dtype(family, dim=0):
     return {BB: np.dtype(np.uint8), BBNC: np.dtype(np.uint8), GP: np.dtype(np.uint32), DD: np.dtype(np.int32),
             NICH: np.dtype(np.float32), NIW: np.dtype((np.float32, (dim,))),
-            NOOP: np.dtype(np.uint8)}[family]
+            NOOP: np.dtype(np.uint8), BNB: np.dtype(np.uint32), DM: np.dtype((np.int32, (dim,)))}[family]
 
 
 def pack_hp(family, hp, dim=0):
@@ -123,8 +131,10 @@ def pack_hp(family, hp, dim=0):
         v = [hp["alpha"], hp["beta"]]
     elif family == GP:
         v = [hp["alpha"], hp["inv_beta"]]
-    elif family == DD:
+    elif family in (DD, DM):
         v = list(hp["alphas"])
+    elif family == BNB:
+        v = [hp["alpha"], hp["beta"], hp["r"]]
     elif family == NICH:
         v = [hp["mu"], hp["kappa"], hp["sigmasq"], hp["nu"]]
     elif family == NIW:

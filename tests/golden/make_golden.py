@@ -11,6 +11,8 @@ oracle (oracle/msc_oracle.c) and the HIP kernels:
   dd    closed form log((a_v+c_v)/(sum a + n))              / gammaln closed form
   nich  scipy.stats.t(df, loc, scale).logpdf                / chain rule
   niw   scipy.stats.multivariate_t(loc, shape, df).logpdf   / chain rule
+  bnb   scipy.stats.betanbinom(r, a', b').logpmf            / chain rule minus the data-only binomial terms
+  dm    scipy.stats.dirichlet_multinomial(alpha+n, X).logpmf / chain rule   (src/models/dm.cpp:39-97)
 
 Suff-stats are computed from the raw rows with two-pass numpy formulas, not with
 the oracle's sequential updates.  Hyperparameters and data are rounded to float32
@@ -91,6 +93,53 @@ def golden_dd(rng):
         cases.append(dict(dim=dim, hp=dict(alphas=alphas), rows=rows,
                           ss=dict(count_sum=n, counts=counts), probe=probe, score_value=sv,
                           score_data=sd))
+    return cases
+
+
+def golden_bnb(rng):
+    cases = []
+    for _ in range(6):
+        al, be = f32(rng.uniform(0.3, 4.0, 2))
+        r = int(rng.integers(1, 6))
+        rows = rng.negative_binomial(r, rng.uniform(0.2, 0.8), int(rng.integers(0, 40))).astype(np.int64)
+        cnt, sm = len(rows), int(rows.sum())
+        a, b = al + r * cnt, be + sm
+        probe = [0, 1, 2, 5, 17, 60, 300]
+        sv = [float(stats.betanbinom(r, a, b).logpmf(v)) for v in probe]
+        # chain rule, minus the terms the suff-stats {count, sum} cannot carry: sum_i log C(r+v_i-1, v_i)
+        sd, s, c = 0.0, 0, 0
+        for v in rows:
+            sd += float(stats.betanbinom(r, al + r * c, be + s).logpmf(v))
+            sd -= float(special.gammaln(r + v) - special.gammaln(v + 1.0) - special.gammaln(r))
+            s += int(v)
+            c += 1
+        cases.append(dict(hp=dict(alpha=al, beta=be, r=r), rows=rows, ss=dict(count=cnt, sum=sm),
+                          probe=probe, score_value=sv, score_data=sd))
+    return cases
+
+
+def _dm_logpmf(alpha, x):
+    n = int(np.sum(x))
+    return 0.0 if n == 0 else float(stats.dirichlet_multinomial(alpha, n).logpmf(x))   # scipy rejects n = 0
+
+
+def golden_dm(rng):
+    cases = []
+    for dim in (2, 3, 8, 40):
+        alphas = f32(rng.uniform(0.2, 3.0, dim))
+        nrows = int(rng.integers(0, 30))
+        rows = rng.multinomial(int(rng.integers(1, 40)), rng.dirichlet(np.ones(dim)), size=nrows).astype(np.int64)
+        rows = rows.reshape(nrows, dim)
+        counts = rows.sum(axis=0) if nrows else np.zeros(dim, dtype=np.int64)
+        ratio = float((special.gammaln(rows.sum(axis=1) + 1.0) - special.gammaln(rows + 1.0).sum(axis=1)).sum())
+        probe = [rng.multinomial(n, rng.dirichlet(np.ones(dim))).astype(np.int64) for n in (0, 1, 7, 150)]
+        sv = [_dm_logpmf(alphas + counts, x) for x in probe]
+        sd, c = 0.0, np.zeros(dim)
+        for x in rows:
+            sd += _dm_logpmf(alphas + c, x)
+            c += x
+        cases.append(dict(dim=dim, hp=dict(alphas=alphas), rows=rows, ss=dict(counts=counts, ratio=ratio),
+                          probe=probe, score_value=sv, score_data=sd))
     return cases
 
 
@@ -199,6 +248,8 @@ def main():
     _dump("dd.json", golden_dd(rng))
     _dump("nich.json", golden_nich(rng))
     _dump("niw.json", golden_niw(rng))
+    _dump("bnb.json", golden_bnb(rng))   # appended after the round-1 families so their vectors stay as they were
+    _dump("dm.json", golden_dm(rng))
     _dump("reference_fixtures.json", reference_fixtures())
 
 

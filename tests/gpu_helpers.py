@@ -27,6 +27,18 @@ def make_feature(family, N, K, rng, dim=0, hp=None):
         vals = rng.poisson(lam[z_true]).astype(np.uint32)
         hp = hp or dict(alpha=1.0, inv_beta=1.0)
         dt = np.uint32
+    elif family == orc.BNB:
+        pr = rng.uniform(0.15, 0.8, K)
+        r = int((hp or {}).get("r", 3))
+        vals = rng.negative_binomial(r, pr[z_true]).astype(np.uint32)
+        hp = hp or dict(alpha=1.5, beta=2.0, r=3)
+        dt = np.uint32
+    elif family == orc.DM:
+        th = rng.dirichlet(np.ones(dim) * 0.7, K)
+        tot = rng.integers(0, 40, N)
+        vals = np.stack([rng.multinomial(t, th[g]) for t, g in zip(tot, z_true)]).astype(np.int32).reshape(N, dim)
+        hp = hp or dict(alphas=list(rng.uniform(0.3, 2.0, dim).astype(np.float32)))
+        dt = np.dtype((np.int32, (dim,)))
     elif family == orc.DD:
         th = rng.dirichlet(np.ones(dim), K)
         cdf = th.cumsum(1)

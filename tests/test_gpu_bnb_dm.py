@@ -1,0 +1,162 @@
+"""GPU parity for the two remaining component models of microscopes/models.pyx:185-290:
+BetaNegativeBinomial (distributions.hpp:29-36; a gp-like exact count table) and the in-tree
+Dirichlet-Multinomial (src/models/dm.cpp:10-97; dim + 1 count lookups per row)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.conftest import load_golden
+from tests.gpu_helpers import (TOL, crp_prior_matrix, load_state, make_feature, oracle_scores, recarray_of, rel_err,
+                               state_from_assignment)
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu_ctx, specs, N, K, seed, hp=None):
+    import common_amd
+    rng = np.random.default_rng(seed)
+    feats = [make_feature(f, N, K, rng, d, hp=(hp or {}).get(i)) for i, (f, d) in enumerate(specs)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    return feats, z, fs, view, st
+
+
+@pytest.mark.parametrize("specs,K", [
+    ([(orc.BNB, 0)], 20),
+    ([(orc.DM, 5)], 33),
+    ([(orc.DM, 2)], 300),                       # two k-tiles
+    ([(orc.DM, 40)], 17),                       # more stages than fit the register budget of a naive unroll
+    ([(orc.BB, 0), (orc.DM, 7), (orc.NICH, 0), (orc.BNB, 0), (orc.DM, 3), (orc.GP, 0)], 64),
+])
+def test_score_value_plain_and_leave_one_out(gpu_ctx, specs, K):
+    N = 2000
+    feats, z, fs, view, st = _setup(gpu_ctx, specs, N, K, seed=len(specs) * 100 + K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    loo = st.score_value(view, z=zt).cpu().numpy()
+    assert rel_err(loo, oracle_scores(feats, fs, z=z)).max() <= TOL
+    st.set_alpha(0.7)
+    both = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    want = oracle_scores(feats, fs, z=z) + crp_prior_matrix(np.bincount(z, minlength=K), 0.7, z)
+    assert rel_err(both, want).max() <= TOL
+
+
+@pytest.mark.parametrize("family,dim", [(orc.BNB, 0), (orc.DM, 6), (orc.DM, 128)])
+def test_accumulate_commit_and_score_data(gpu_ctx, family, dim):
+    N, K = 3000, 19
+    feats, z, fs, view, st = _setup(gpu_ctx, [(family, dim)], N, K, seed=dim + 3)
+    st.set_hp(0, fs[0][0].hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    rec = st.get_ss(0)
+    want = fs[0][2]
+    for name in rec.dtype.names:
+        if np.issubdtype(rec.dtype[name].base, np.integer):
+            assert np.array_equal(rec[name], want[name]), name        # counts: bit-exact
+        else:
+            assert rel_err(rec[name], fs[0][1][name]).max() <= TOL, name
+    assert np.array_equal(st.get_group_counts(), np.bincount(z, minlength=K))
+    sd = st.score_data().cpu().numpy()[0]
+    assert rel_err(sd, fs[0][0].score_data_all(fs[0][1])).max() <= TOL
+    # subtract half of the rows again: the tables must equal those of the other half alone
+    half = N // 2
+    st.accumulate(view, zt[:half], row0=0, nrows=half, reset=False, subtract=True)
+    rest = orc.Family(family, feats[0]["hp"], dim, "f64").accumulate(K, feats[0]["values"][half:], z[half:])
+    rec = st.get_ss(0)
+    for name in rec.dtype.names:
+        if np.issubdtype(rec.dtype[name].base, np.integer):
+            assert np.array_equal(rec[name], rest[name]), name
+        else:
+            assert np.abs(rec[name] - rest[name]).max() <= 1e-4 * max(1.0, np.abs(rest[name]).max()), name
+
+
+def test_counts_beyond_the_table_take_the_double_path(gpu_ctx):
+    """values >= 1024 (the table cap) are scored by the large-count kernel, plain and leave-one-out"""
+    import common_amd
+    rng = np.random.default_rng(8)
+    N, K = 600, 9
+    fb = make_feature(orc.BNB, N, K, rng)
+    fb["values"][::7] += rng.integers(1024, 200000, len(fb["values"][::7])).astype(np.uint32)
+    fd = make_feature(orc.DM, N, K, rng, 4)
+    fd["values"][::5, 2] += rng.integers(1024, 50000, len(fd["values"][::5])).astype(np.int32)   # category and total
+    fd["values"][1::11, 0] += 600                                                               # total only
+    fd["values"][1::11, 1] += 600
+    feats = [fb, fd]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.BNB, 0), (orc.DM, 4)], K)
+    load_state(st, fs)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    loo = st.score_value(view, z=zt).cpu().numpy()
+    assert rel_err(loo, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
+@pytest.mark.parametrize("name,family", [("bnb", orc.BNB), ("dm", orc.DM)])
+def test_per_value_api_against_the_scipy_golden_vectors(gpu_ctx, name, family):
+    """group::score_value / score_data / add_value / remove_value through msc_value_op_single"""
+    import common_amd
+    for case in load_golden(name):
+        dim = case.get("dim", 0)
+        rec = np.zeros(1, dtype=common_amd.ss_dtype(family, dim))
+        rows = np.asarray(case["rows"]).reshape((-1,) + ((dim,) if dim else ()))
+        for v in rows:
+            gpu_ctx.value_op(family, dim, "add", case["hp"], rec, v)
+        for k, want in case["ss"].items():
+            if np.issubdtype(rec.dtype[k].base, np.integer):
+                assert np.array_equal(rec[k][0], np.asarray(want)), (name, k)
+            else:
+                assert abs(float(rec[k][0]) - want) <= 2e-5 * max(1.0, abs(want)), (name, k)   # float running sum
+        got = [gpu_ctx.value_op(family, dim, "score_value", case["hp"], rec, np.asarray(v)) for v in case["probe"]]
+        slack = 1e-5 if name == "dm" else 0.0     # dm's counts are exact; nothing float enters score_value
+        assert rel_err(got, case["score_value"]).max() <= TOL + slack
+        sd = gpu_ctx.value_op(family, dim, "score_data", case["hp"], rec)
+        assert abs(sd - case["score_data"]) <= 2e-5 * max(1.0, abs(case["score_data"]))
+        if len(rows):
+            gpu_ctx.value_op(family, dim, "remove", case["hp"], rec, rows[-1])
+            gpu_ctx.value_op(family, dim, "add", case["hp"], rec, rows[-1])
+            for k, want in case["ss"].items():
+                if np.issubdtype(rec.dtype[k].base, np.integer):
+                    assert np.array_equal(rec[k][0], np.asarray(want))
+
+
+def test_sweep_with_bnb_and_dm_features_matches_the_oracle(gpu_ctx):
+    from tests.test_gpu_sweep import _check_agreement, _run
+    specs = [(orc.BNB, 0), (orc.DM, 6), (orc.NICH, 0)]
+    got, want, scores, _ = _run(gpu_ctx, specs, 2500, 90, seed=21, sweep_idx=2)
+    _check_agreement(got, want, scores, 21, 2, 0.998)
+
+
+def test_masked_dm_rows_contribute_nothing(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(4)
+    N, K, C = 1500, 11, 5
+    feats = [make_feature(orc.DM, N, K, rng, C), make_feature(orc.NICH, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    rec = recarray_of(feats)
+    mask = np.zeros(N, dtype=[("f0", np.bool_, (C,)), ("f1", np.bool_)])
+    hide = rng.random(N) < 0.2
+    mask["f0"][hide, rng.integers(0, C, hide.sum())] = True        # one masked element hides the whole vector
+    view = common_amd.DataView.from_recarray(gpu_ctx, np.ma.masked_array(rec, mask=mask))
+    keep = ~hide
+    fs_keep = state_from_assignment([dict(feats[0], values=feats[0]["values"][keep])], K, z[keep])
+    fs_all = state_from_assignment([feats[1]], K, z)
+    st = common_amd.State(gpu_ctx, [(orc.DM, C), (orc.NICH, 0)], K)
+    st.set_hp(0, fs_keep[0][0].hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    assert np.array_equal(st.get_ss(0)["counts"], fs_keep[0][2]["counts"])
+    load_state(st, [fs_keep[0], fs_all[0]])
+    got = st.score_value(view).cpu().numpy()
+    dm_part = fs_keep[0][0].score_matrix(fs_keep[0][1], feats[0]["values"])
+    dm_part[hide] = 0.0
+    want = dm_part + fs_all[0][0].score_matrix(fs_all[0][1], feats[1]["values"])
+    assert rel_err(got, want).max() <= TOL

@@ -10,7 +10,7 @@ import pytest
 from oracle import oracle as orc
 from tests.conftest import load_golden
 
-FAMS = {"bb": orc.BB, "gp": orc.GP, "dd": orc.DD, "nich": orc.NICH, "niw": orc.NIW}
+FAMS = {"bb": orc.BB, "gp": orc.GP, "dd": orc.DD, "nich": orc.NICH, "niw": orc.NIW, "bnb": orc.BNB, "dm": orc.DM}
 
 
 def _ss_from_case(fam, case, prec):
