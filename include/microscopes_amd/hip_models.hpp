@@ -113,6 +113,35 @@ struct BetaBernoulliNonConj {
   };
 };
 
+// distributions.hpp:29-36: Shared {alpha, beta, r}, Group {count, sum}
+struct BetaNegativeBinomial {
+  typedef uint32_t Value;
+  struct Shared {
+    float alpha = 1.f, beta = 1.f;
+    uint32_t r = 1;                  // models.pyx:200
+  };
+  struct Group {
+    uint32_t count = 0, sum = 0;     // {count, sum}: the ABI record
+    void init(const Shared &, rng_t &) { count = sum = 0; }
+  };
+};
+
+// tag for the in-tree Dirichlet-Multinomial (include/microscopes/models/dm.hpp:19-170)
+struct DirichletMultinomial {
+  struct Shared {
+    std::vector<float> alphas;       // dm.hpp:168
+    unsigned categories() const { return unsigned(alphas.size()); }
+  };
+  struct Group {
+    std::vector<uint32_t> counts;    // dm.hpp:86-88
+    float ratio = 0.f;
+    void init(const Shared &s, rng_t &) {
+      counts.assign(s.categories(), 0u);
+      ratio = 0.f;
+    }
+  };
+};
+
 }  // namespace distributions
 
 namespace microscopes {
@@ -183,6 +212,44 @@ template <> struct family_traits<GammaPoisson> {
     const uint32_t x = v.get<uint32_t>(0);
     o.resize(4);
     std::memcpy(o.data(), &x, 4);
+  }
+};
+template <> struct family_traits<distributions::BetaNegativeBinomial> {
+  typedef distributions::BetaNegativeBinomial T;
+  enum { family = MSC_BNB };
+  static unsigned dim(const T::Shared &) { return 0; }
+  static common::runtime_type value_type(unsigned) { return common::runtime_type(TYPE_U32); }
+  static void pack_hp(const T::Shared &s, std::vector<float> &o) { o = {s.alpha, s.beta, float(s.r)}; }
+  static void *record(T::Group &g, std::vector<uint8_t> &) { return &g.count; }
+  static void unpack(T::Group &, const std::vector<uint8_t> &) {}
+  static void pack_value(const common::value_accessor &v, std::vector<uint8_t> &o) {
+    const uint32_t x = v.get<uint32_t>(0);
+    o.resize(4);
+    std::memcpy(o.data(), &x, 4);
+  }
+};
+template <> struct family_traits<distributions::DirichletMultinomial> {
+  typedef distributions::DirichletMultinomial T;
+  enum { family = MSC_DM };
+  static unsigned dim(const T::Shared &s) { return s.categories(); }
+  static common::runtime_type value_type(unsigned d) { return common::runtime_type(TYPE_I32, d); }
+  static void pack_hp(const T::Shared &s, std::vector<float> &o) { o = s.alphas; }
+  static void *record(T::Group &g, std::vector<uint8_t> &buf) {          // {u32 counts[d], f32 ratio}
+    buf.resize(4 * (g.counts.size() + 1));
+    std::memcpy(buf.data(), g.counts.data(), 4 * g.counts.size());
+    std::memcpy(buf.data() + 4 * g.counts.size(), &g.ratio, 4);
+    return buf.data();
+  }
+  static void unpack(T::Group &g, const std::vector<uint8_t> &buf) {
+    std::memcpy(g.counts.data(), buf.data(), 4 * g.counts.size());
+    std::memcpy(&g.ratio, buf.data() + 4 * g.counts.size(), 4);
+  }
+  static void pack_value(const common::value_accessor &v, std::vector<uint8_t> &o) {
+    o.resize(4 * v.shape());
+    for (unsigned i = 0; i < v.shape(); i++) {
+      const uint32_t x = v.get<unsigned>(i);                               // dm.cpp:16 reads the counts as unsigned
+      std::memcpy(o.data() + 4 * i, &x, 4);
+    }
   }
 };
 template <> struct family_traits<NormalInverseChiSq> {
@@ -287,7 +354,27 @@ template <> struct field_access<NormalInverseChiSq> {
     throw std::runtime_error("Unknown group SS param key: " + key);
   }
 };
+template <> struct field_access<distributions::BetaNegativeBinomial> {
+  typedef distributions::BetaNegativeBinomial T;
+  static common::value_mutator hp(T::Shared &s, const std::string &key) {
+    MSC_FIELD(s, alpha); MSC_FIELD(s, beta); MSC_FIELD(s, r);
+    throw std::runtime_error("Unknown shared HP param key: " + key);
+  }
+  static common::value_mutator ss(T::Group &g, const std::string &key) {
+    MSC_FIELD(g, count); MSC_FIELD(g, sum);
+    throw std::runtime_error("Unknown group SS param key: " + key);
+  }
+};
 #undef MSC_FIELD
+template <> struct field_access<distributions::DirichletMultinomial> {
+  typedef distributions::DirichletMultinomial T;
+  static common::value_mutator hp(T::Shared &s, const std::string &key) {    // dm.hpp:137-147
+    if (key == "alphas")
+      return common::value_mutator(reinterpret_cast<uint8_t *>(s.alphas.data()), common::runtime_type(TYPE_F32, s.categories()));
+    throw std::runtime_error("unknown key: " + key);
+  }
+  static common::value_mutator ss(T::Group &, const std::string &) { throw std::runtime_error("no mutation allowed"); }  // dm.hpp:68-72
+};
 template <> struct field_access<DD128> {
   static common::value_mutator hp(DD128::Shared &s, const std::string &key) {
     if (key == "alphas")
@@ -323,6 +410,38 @@ template <> struct bag<distributions::BetaBernoulliNonConj> {      // microscope
   static std::string dump(const T::Group &g) { wire::writer w; w.put_float_field(1, g.p); w.put_varint_field(2, g.heads); w.put_varint_field(3, g.tails); return w.str(); }
   static void load(T::Group &g, const std::string &b) {
     for (const auto &f : wire::parse(b)) { if (f.number == 1) g.p = f.f32; if (f.number == 2) g.heads = uint32_t(f.varint); if (f.number == 3) g.tails = uint32_t(f.varint); }
+  }
+};
+template <> struct bag<distributions::BetaNegativeBinomial> {      // distributions' schema: Shared {alpha, beta, r}, Group {count, sum}
+  typedef distributions::BetaNegativeBinomial T;
+  static std::string dump(const T::Shared &s) { wire::writer w; w.put_float_field(1, s.alpha); w.put_float_field(2, s.beta); w.put_varint_field(3, s.r); return w.str(); }
+  static void load(T::Shared &s, const std::string &b) {
+    for (const auto &f : wire::parse(b)) { if (f.number == 1) s.alpha = f.f32; if (f.number == 2) s.beta = f.f32; if (f.number == 3) s.r = uint32_t(f.varint); }
+  }
+  static std::string dump(const T::Group &g) { wire::writer w; w.put_varint_field(1, g.count); w.put_varint_field(2, g.sum); return w.str(); }
+  static void load(T::Group &g, const std::string &b) {
+    for (const auto &f : wire::parse(b)) { if (f.number == 1) g.count = uint32_t(f.varint); if (f.number == 2) g.sum = uint32_t(f.varint); }
+  }
+};
+template <> struct bag<distributions::DirichletMultinomial> {      // microscopes/io/schema.proto:21-30 (in tree: pinned)
+  typedef distributions::DirichletMultinomial T;
+  static std::string dump(const T::Shared &s) { wire::writer w; for (float a : s.alphas) w.put_float_field(1, a); return w.str(); }
+  static void load(T::Shared &s, const std::string &b) {                  // dm.hpp:117-130
+    std::vector<float> a;
+    for (const auto &f : wire::parse(b)) if (f.number == 1) wire::collect_floats(f, a);
+    if (a.size() != s.alphas.size()) throw std::runtime_error("# categories mismatch");
+    for (float x : a) if (!(x > 0.f)) throw std::runtime_error("alphas need to be positive reals");
+    s.alphas = a;
+  }
+  static std::string dump(const T::Group &g) { wire::writer w; for (uint32_t c : g.counts) w.put_varint_field(1, c); w.put_float_field(2, g.ratio); return w.str(); }
+  static void load(T::Group &g, const std::string &b) {                   // dm.hpp:43-55
+    std::vector<uint64_t> c;
+    float ratio = 0.f;
+    for (const auto &f : wire::parse(b)) { if (f.number == 1) wire::collect_varints(f, c); if (f.number == 2) ratio = f.f32; }
+    if (c.size() != g.counts.size()) throw std::runtime_error("# categories mismatch");
+    if (ratio < 0.f) throw std::runtime_error("negative partition");
+    for (std::size_t i = 0; i < c.size(); i++) g.counts[i] = uint32_t(c[i]);
+    g.ratio = ratio;
   }
 };
 template <> struct bag<GammaPoisson> {
@@ -524,6 +643,41 @@ public:
 private:
   unsigned dim_;
 };
+
+// ---- Dirichlet-Multinomial under its reference names (include/microscopes/models/dm.hpp) ------------
+template <>
+class distributions_hypers<distributions::DirichletMultinomial> : public detail::hypers_base<distributions::DirichletMultinomial> {
+public:
+  explicit distributions_hypers(unsigned categories) { this->repr_.alphas.assign(categories, 0.f); }   // dm.hpp:92-93
+  void set_hp(const hypers &m) override {                                                               // dm.hpp:132-139
+    const auto &that = static_cast<const distributions_hypers<distributions::DirichletMultinomial> &>(m);
+    if (that.categories() != categories()) throw std::runtime_error("# categories mismatch");
+    this->repr_ = that.repr_;
+  }
+  void set_hp(const common::hyperparam_bag_t &hp) override { detail::bag<distributions::DirichletMultinomial>::load(this->repr_, hp); }
+  std::size_t categories() const { return this->repr_.alphas.size(); }
+  const std::vector<float> &alphas() const { return this->repr_.alphas; }
+};
+
+template <>
+class distributions_model<distributions::DirichletMultinomial> : public model {
+public:
+  explicit distributions_model(unsigned categories) : categories_(categories) {
+    if (categories < 2) throw std::runtime_error("need at least two outcomes");                       // dm.hpp:174-178
+    if (categories > 128) throw std::runtime_error("dm: more than 128 categories are not built for the HIP backend");
+  }
+  std::shared_ptr<hypers> create_hypers() const override {
+    return std::make_shared<distributions_hypers<distributions::DirichletMultinomial>>(categories_);
+  }
+  common::runtime_type get_runtime_type() const override { return common::runtime_type(TYPE_I32, categories_); }   // dm.hpp:186-190
+  std::size_t categories() const { return categories_; }
+
+private:
+  unsigned categories_;
+};
+typedef distributions_group<distributions::DirichletMultinomial> dm_group;
+typedef distributions_hypers<distributions::DirichletMultinomial> dm_hypers;
+typedef distributions_model<distributions::DirichletMultinomial> dm_model;
 
 // the in-tree non-conjugate model under its reference names (include/microscopes/models/bbnc.hpp:9-73)
 typedef distributions_group<distributions::BetaBernoulliNonConj> bbnc_group;

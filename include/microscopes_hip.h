@@ -136,6 +136,7 @@ int msc_state_shape(const msc_state *st, uint32_t *nfeatures, uint32_t *ngroups)
  * blocks, field order as the reference names them (distributions.hpp:21-56):
  *   bb {alpha, beta}  bbnc {alpha, beta}  gp {alpha, inv_beta}  dd {alphas[dim]}
  *   nich {mu, kappa, sigmasq, nu}  niw {kappa, nu, mu[dim], psi[dim*dim]}
+ *   bnb {alpha, beta, r (integral, carried as a float)}  dm {alphas[dim]} (dm.hpp:168)
  */
 size_t msc_hp_floats(int family, uint32_t dim);
 int msc_state_set_hp(msc_state *st, uint32_t feature, const float *host_hp, size_t nfloats);
@@ -151,6 +152,8 @@ int msc_state_get_hp(const msc_state *st, uint32_t feature, float *host_hp, size
  *   dd   {u32 count_sum, u32 counts[dim]}
  *   nich {u32 count, f32 mean, f32 count_times_variance}
  *   niw  {u32 count, f32 sum_x[dim], f32 sum_xxT[dim*dim]}
+ *   bnb  {u32 count, u32 sum}                (distributions.hpp:34-36)
+ *   dm   {u32 counts[dim], f32 ratio}        (include/microscopes/models/dm.hpp:86-88)
  * Synchronous.
  */
 size_t msc_ss_bytes(int family, uint32_t dim);

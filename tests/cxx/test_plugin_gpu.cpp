@@ -3,6 +3,7 @@
 // Every add / remove / score here is msc_value_op_single -> one launch on the device.
 #include <microscopes/common/recarray/dataview.hpp>
 #include <microscopes/models/distributions.hpp>
+#include <microscopes/models/dm.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -190,8 +191,95 @@ static void test_bbnc() {
   CHECK(g2->score_data(*h, r) == g->score_data(*h, r));
 }
 
+// BetaNegativeBinomial through distributions_model<T> (distributions.hpp:59-64): r is an integer field
+static void test_bnb() {
+  rng_t r(5);
+  models::distributions_model<BetaNegativeBinomial> m;
+  CHECK(m.get_runtime_type() == runtime_type(TYPE_U32));
+  auto h = m.create_hypers();
+  h->get_hp_mutator("alpha").set<float>(2.5f);
+  h->get_hp_mutator("beta").set<float>(1.5f);
+  h->get_hp_mutator("r").set<uint32_t>(3);
+  const float hp[3] = {2.5f, 1.5f, 3.f};
+  auto g = h->create_group(r);
+  struct { uint32_t count, sum; } oss = {0, 0};
+  uint32_t vals[20];
+  for (int i = 0; i < 20; i++) {
+    vals[i] = (uint32_t)std::negative_binomial_distribution<int>(3, 0.4)(r);
+    g->add_value(*h, value_accessor(&vals[i]), r);
+    orc_f64_add_value(ORC_BNB, 0, hp, &oss, &vals[i]);
+  }
+  for (int i = 0; i < 7; i++) {
+    g->remove_value(*h, value_accessor(&vals[i]), r);
+    orc_f64_remove_value(ORC_BNB, 0, hp, &oss, &vals[i]);
+  }
+  CHECK(g->get_ss_mutator("count").accessor().get<uint32_t>(0) == oss.count);
+  CHECK(g->get_ss_mutator("sum").accessor().get<uint32_t>(0) == oss.sum);
+  for (uint32_t probe : {0u, 1u, 9u, 40u, 5000u})
+    CHECK(close(g->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(ORC_BNB, 0, hp, &oss, &probe)));
+  CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_BNB, 0, hp, &oss)));
+  auto h2 = m.create_hypers();
+  h2->set_hp(h->get_hp());                            // bag round trip keeps r
+  CHECK(h2->get_hp_mutator("r").accessor().get<uint32_t>(0) == 3u);
+  auto g2 = h2->create_group(r);
+  g2->set_ss(g->get_ss());
+  const uint32_t probe = 4;
+  CHECK(g2->score_value(*h2, value_accessor(&probe), r) == g->score_value(*h, value_accessor(&probe), r));
+}
+
+// the in-tree Dirichlet-Multinomial under its reference names (dm.hpp:19-200, dm.cpp:10-111)
+static void test_dm() {
+  rng_t r(6);
+  const unsigned C = 5;
+  models::dm_model m(C);
+  CHECK(m.get_runtime_type() == runtime_type(TYPE_I32, C));
+  CHECK(m.categories() == C);
+  bool threw = false;
+  try { models::dm_model bad(1); } catch (const std::runtime_error &) { threw = true; }   // dm.hpp:177
+  CHECK(threw);
+  auto h = m.create_hypers();
+  const float alphas[C] = {0.5f, 1.f, 2.f, 0.25f, 3.f};
+  auto mut = h->get_hp_mutator("alphas");
+  CHECK(mut.shape() == C);
+  for (unsigned i = 0; i < C; i++) mut.set<float>(alphas[i], i);
+  auto g = h->create_group(r);
+  std::vector<uint8_t> oss(orc_f64_ss_size(ORC_DM, C));
+  orc_f64_init(ORC_DM, C, alphas, oss.data());
+  const runtime_type vt(TYPE_I32, C);
+  int32_t rows[12][C];
+  for (int n = 0; n < 12; n++) {
+    for (unsigned i = 0; i < C; i++) rows[n][i] = std::poisson_distribution<int>(2.0 + i)(r);
+    g->add_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(rows[n]), nullptr, vt), r);
+    orc_f64_add_value(ORC_DM, C, alphas, oss.data(), rows[n]);
+  }
+  for (int n = 0; n < 4; n++) {
+    g->remove_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(rows[n]), nullptr, vt), r);
+    orc_f64_remove_value(ORC_DM, C, alphas, oss.data(), rows[n]);
+  }
+  const int32_t probes[3][C] = {{0, 0, 0, 0, 0}, {1, 0, 3, 0, 2}, {40, 2, 0, 7, 1500}};
+  for (const auto &pr : probes)
+    CHECK(close(g->score_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(pr), nullptr, vt), r),
+                orc_f64_score_value(ORC_DM, C, alphas, oss.data(), pr)));
+  CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_DM, C, alphas, oss.data()), 2e-5));   // float `ratio` field
+  // bags are the in-tree schema.proto:21-30 messages
+  auto g2 = h->create_group(r);
+  g2->set_ss(g->get_ss());
+  CHECK(g2->score_data(*h, r) == g->score_data(*h, r));
+  auto h2 = m.create_hypers();
+  h2->set_hp(h->get_hp());
+  CHECK(h2->get_hp_mutator("alphas").accessor().get<float>(4) == 3.f);
+  threw = false;
+  try { g->get_ss_mutator("counts"); } catch (const std::runtime_error &) { threw = true; }   // dm.hpp:68-72
+  CHECK(threw);
+  threw = false;
+  try { models::dm_model(3).create_hypers()->set_hp(h->get_hp()); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);                                       // "# categories mismatch", dm.hpp:121-123
+}
+
 int main() {
   test_bbnc();
+  test_bnb();
+  test_dm();
   {
     models::distributions_model<BetaBernoulli> m;
     run_scalar<BetaBernoulli, bool>(ORC_BB, 0, m, {2.f, 0.5f}, {{"alpha", 2.f}, {"beta", 0.5f}},
