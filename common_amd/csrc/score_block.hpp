@@ -78,39 +78,11 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
 // per category, one for the row total; family_math.hpp).
 MSC_DEV uint32_t nstages_of(const FeatDesc &fd) { return fd.family == MSC_DM ? fd.dim + 1 : 1; }
 
-struct StageTab {
-  uint32_t first_row;   // first row of the stage's block in fd.tab
-  uint32_t vcap;        // entries the block has in fd.tab (count families: counts below this are exact entries);
-                        // dm entries are two rows each (hi, lo)
-  uint32_t nrows_lds;   // rows of it that were copied to LDS
-};
-
-// rows of the stage's table block that go to LDS, and where the block starts in fd.tab
+// rows of a single-stage feature's table block that go to LDS, and where the block starts in fd.tab
 // wg_row0 / wg_rows: the absolute row range the workgroup scores in this chunk; for count tables only
 // the rows up to the largest count in that range are worth copying (the per-128-row maxima
 // were computed once when the column was bound).
-MSC_DEV StageTab stage_tab_of(const FeatDesc &fd, uint32_t sub, uint64_t wg_row0, uint32_t wg_rows) {
-  StageTab t = {0u, 0u, 0u};
-  const uint16_t *cmax = nullptr;
-  switch (fd.family) {
-    case MSC_BB:
-    case MSC_BBNC: t.vcap = 2; break;
-    case MSC_NICH: t.vcap = NICH_ROWS; break;
-    case MSC_DD: t.vcap = fd.dim; break;
-    case MSC_BNB:
-    case MSC_GP:
-      t.first_row = GP_T0;
-      t.vcap = fd.vcap;
-      cmax = fd.chunk_max;
-      break;
-    case MSC_DM:
-      t.first_row = fd.dm_meta[2 * sub];
-      t.vcap = fd.dm_meta[2 * sub + 1];
-      cmax = fd.chunk_max ? fd.chunk_max + (size_t)sub * fd.cm_stride : nullptr;
-      break;
-    default: break;
-  }
-  uint32_t need = t.vcap;
+MSC_DEV uint32_t chunk_need(const uint16_t *cmax, uint32_t need, uint64_t wg_row0, uint32_t wg_rows) {
   if (cmax != nullptr) {
     uint32_t m = 0;
     for (uint64_t c = wg_row0 >> 7; c <= (wg_row0 + wg_rows - 1) >> 7; c++) {
@@ -119,17 +91,40 @@ MSC_DEV StageTab stage_tab_of(const FeatDesc &fd, uint32_t sub, uint64_t wg_row0
     }
     need = m + 1 < need ? m + 1 : need;
   }
-  if (fd.family == MSC_DM) need *= 2;                   // (hi, lo) row pairs
-  t.nrows_lds = need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
-  return t;
+  return need;
+}
+MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row, uint64_t wg_row0, uint32_t wg_rows) {
+  first_row = 0;
+  switch (fd.family) {
+    case MSC_BB: return 2;
+    case MSC_BBNC: return 2;
+    case MSC_NICH: return NICH_ROWS;
+    case MSC_DD: return fd.dim < (uint32_t)kLdsRows ? fd.dim : (uint32_t)kLdsRows;
+    case MSC_BNB:
+    case MSC_GP: {
+      first_row = GP_T0;
+      const uint32_t need = chunk_need(fd.chunk_max, fd.vcap, wg_row0, wg_rows);
+      return need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
+    }
+    default: return 0;
+  }
+}
+// the same for stage `sub` of a dm feature: entries are (hi, lo) row pairs
+MSC_DEV uint32_t dm_lds_rows_of(const FeatDesc &fd, uint32_t sub, uint32_t &first_row, uint64_t wg_row0, uint32_t wg_rows) {
+  first_row = fd.dm_meta[2 * sub];
+  const uint32_t need = 2 * chunk_need(fd.chunk_max ? fd.chunk_max + (size_t)sub * fd.cm_stride : nullptr,
+                                       fd.dm_meta[2 * sub + 1], wg_row0, wg_rows);
+  return need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
 }
 
 // the stage's value of this lane's row, as raw 32 bits (reinterpreted per family)
+template <bool DM>
 MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint32_t sub, uint64_t row, bool has_row) {
   if (!has_row || fd.col == nullptr) return 0u;
   if (fd.family == MSC_BB || fd.family == MSC_BBNC) return (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
   if (fd.family == MSC_NIW || fd.family == MSC_NOOP) return 0u;
   if (fd.family == MSC_DM) {
+    if constexpr (!DM) return 0u;
     const uint32_t tot = fd.dm_tot[row];
     if (tot >= kGpMaxTable) return 0xffffffffu;        // the whole row goes to the large-count kernel
     return sub < fd.dim ? reinterpret_cast<const uint32_t *>(fd.col)[row * fd.dim + sub] : tot;
@@ -139,24 +134,27 @@ MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint32_t sub, uint64_t row, 
 
 // is this lane's row masked for the feature?  (one mask byte per element, runtime_type.hpp:131;
 // a masked value takes no part in scoring or in the suff-stats, as the reference's callers skip it)
+template <bool DM = true>
 MSC_DEV bool load_masked(const FeatDesc &fd, uint64_t row, bool has_row) {
   if (!has_row || fd.mask == nullptr) return false;
-  if (fd.family != MSC_NIW && fd.family != MSC_DM) return fd.mask[row] != 0;
+  if (fd.family != MSC_NIW && !(DM && fd.family == MSC_DM)) return fd.mask[row] != 0;
   bool m = false;
   for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
   return m;
 }
 
-// issue the async copy of the stage's table block for this k-tile into buf (no wait)
-template <int W>
-MSC_DEV StageTab stage_table(const FeatDesc &fd, uint32_t sub, uint32_t kpad, uint32_t ktile, float4 *buf,
+// issue the async copy of the stage's table block for this k-tile into buf (no wait); returns the rows copied
+template <int W, bool DM>
+MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t sub, uint32_t kpad, uint32_t ktile, float4 *buf,
                              uint64_t wg_row0, uint32_t wg_rows) {
-  const StageTab t = stage_tab_of(fd, sub, wg_row0, wg_rows);
-  const float *tile = fd.tab + (size_t)t.first_row * kpad + (size_t)ktile * kGroupTile;
+  uint32_t first_row;
+  const uint32_t nrows_lds = (DM && fd.family == MSC_DM) ? dm_lds_rows_of(fd, sub, first_row, wg_row0, wg_rows)
+                                                         : lds_rows_of(fd, first_row, wg_row0, wg_rows);
+  const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t row = wave; row < t.nrows_lds; row += W)        // one 1 KiB table row per wave instruction
+  for (uint32_t row = wave; row < nrows_lds; row += W)          // one 1 KiB table row per wave instruction
     glds16(tile + (size_t)row * kpad + 4 * lane, buf + row * 64);
-  return t;
+  return nrows_lds;
 }
 
 // one stage's contribution to the R rows of this wave (tables already in `buf`)
@@ -222,20 +220,17 @@ template <int R, bool MASKED>
 MSC_DEV void add_dm_stage(const FeatDesc &fd, uint32_t sub, const float4 *__restrict__ buf, const uint32_t nrows_lds,
                           uint32_t kpad, uint32_t kb, int lane, uint32_t raw, unsigned long long mbits,
                           float4 (&hi)[R], float4 (&lo)[R]) {
-  StageTab t;
-  t.first_row = fd.dm_meta[2 * sub];
-  t.vcap = fd.dm_meta[2 * sub + 1];
-  t.nrows_lds = nrows_lds;
+  const uint32_t first_row = fd.dm_meta[2 * sub], vcap = fd.dm_meta[2 * sub + 1];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     if (MASKED && ((mbits >> r) & 1ull)) continue;
     const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
-    if (vr >= t.vcap) continue;                       // rows beyond the tables: k_gp_large_fix
-    if (2 * vr + 1 < t.nrows_lds) {
+    if (vr >= vcap) continue;                         // rows beyond the tables: k_gp_large_fix
+    if (2 * vr + 1 < nrows_lds) {
       add4(hi[r], buf[(2 * vr) * 64 + lane]);
       add4(lo[r], buf[(2 * vr + 1) * 64 + lane]);
     } else {
-      const float *p = fd.tab + (size_t)(t.first_row + 2 * vr) * kpad + kb;
+      const float *p = fd.tab + (size_t)(first_row + 2 * vr) * kpad + kb;
       add4(hi[r], ld4(p));
       add4(lo[r], ld4(p + kpad));
     }
@@ -260,11 +255,33 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
   const bool has_row = lane < nr;
   const uint64_t myrow = row_abs0 + lane;
   __syncthreads();                                      // the previous chunk's readers are done
-  uint32_t raw = load_raw_value(feats[0], 0, myrow, has_row);
-  unsigned long long mbits = __builtin_amdgcn_ballot_w64(load_masked(feats[0], myrow, has_row));
-  uint32_t nrows_lds = stage_table<W>(feats[0], 0, kpad, ktile, lds, wg_row0, wg_rows).nrows_lds;
+  uint32_t raw = load_raw_value<DM>(feats[0], 0, myrow, has_row);
+  unsigned long long mbits = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[0], myrow, has_row));
+  uint32_t nrows_lds = stage_table<W, DM>(feats[0], 0, kpad, ktile, lds, wg_row0, wg_rows);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (!DM) {
+    // every feature is one stage: the plain software pipeline over the feature list
+    for (int f = 0; f < nfeat; f++) {
+      const FeatDesc fd = feats[f];
+      const float4 *buf = lds + (size_t)(f & 1) * kLdsRows * 64;
+      uint32_t raw_next = 0, nrows_next = 0;
+      unsigned long long mbits_next = 0ull;
+      if (f + 1 < nfeat) {
+        raw_next = load_raw_value<DM>(feats[f + 1], 0, myrow, has_row);
+        mbits_next = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[f + 1], myrow, has_row));
+        nrows_next = stage_table<W, DM>(feats[f + 1], 0, kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
+      }
+      if (mbits == 0ull) add_feature<R, false>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
+      else add_feature<R, true>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // table f+1 has landed (this wave's share)
+      __syncthreads();                                    // ... everyone's share; buffer f&1 is free again
+      raw = raw_next;
+      mbits = mbits_next;
+      nrows_lds = nrows_next;
+    }
+    return;
+  }
   // advance the pipeline by one stage: prefetch (value, mask, table) of the stage after (f, sub)
   // into the other buffer, run `body` on the current one, wait, barrier, rotate
   int f = 0;
@@ -280,9 +297,9 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
     uint32_t raw_next = 0, nrows_next = 0;
     unsigned long long mbits_next = mbits;              // the stages of one feature share its mask
     if (nf < nfeat) {
-      raw_next = load_raw_value(feats[nf], nsub, myrow, has_row);
-      if (nf != f) mbits_next = __builtin_amdgcn_ballot_w64(load_masked(feats[nf], myrow, has_row));
-      nrows_next = stage_table<W>(feats[nf], nsub, kpad, ktile, lds + (size_t)(parity ^ 1u) * kLdsRows * 64, wg_row0, wg_rows).nrows_lds;
+      raw_next = load_raw_value<DM>(feats[nf], nsub, myrow, has_row);
+      if (nf != f) mbits_next = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[nf], myrow, has_row));
+      nrows_next = stage_table<W, DM>(feats[nf], nsub, kpad, ktile, lds + (size_t)(parity ^ 1u) * kLdsRows * 64, wg_row0, wg_rows);
     }
     body(buf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next table has landed (this wave's share)
