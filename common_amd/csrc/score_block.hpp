@@ -161,6 +161,28 @@ MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t sub, uint32_t kpad, ui
 template <int R, bool MASKED>
 MSC_DEV void add_feature(const FeatDesc &fd, const float4 *__restrict__ buf, const uint32_t nrows_lds, uint32_t kpad,
                          uint32_t kb, int lane, uint32_t raw, unsigned long long mbits, float4 (&acc)[R]) {
+  // Lookup families, common case: no masked row and every row's table entry is in the LDS block
+  // (wave-uniform test).  Branch-free, so the R reads go out back to back: one ds_read_b128 and
+  // four adds per row.
+  if (!MASKED && fd.family != MSC_NICH) {
+    uint32_t idx = raw;
+    if (fd.family == MSC_DD) {
+      const int v = (int)raw;
+      idx = (uint32_t)(v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v));   // keep the gather in bounds
+    }
+    const bool lookup = fd.family == MSC_BB || fd.family == MSC_BBNC || fd.family == MSC_DD || is_count_family(fd.family);
+    if (lookup && __builtin_amdgcn_ballot_w64(idx >= nrows_lds) == 0ull) {
+#pragma unroll
+      for (int r0 = 0; r0 < R; r0 += 4) {
+        float4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[j] = buf[(uint32_t)lane_bcast((int)idx, r0 + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++) add4(acc[r0 + j], t[j]);
+      }
+      return;
+    }
+  }
   switch (fd.family) {
     case MSC_BBNC:
     case MSC_BB: {
