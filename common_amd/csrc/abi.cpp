@@ -827,7 +827,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
 extern "C" int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *cols,
                                uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags,
                                float *out_dev, uint64_t ld_out) {
-  MSC_REQUIRE(st && out_dev, "null argument");
+  MSC_REQUIRE(st && (out_dev || nrows == 0), "null argument");    // an empty row range has no output to point at
   MSC_REQUIRE(ld_out >= st->K, "ld_out %llu < ngroups %u", (unsigned long long)ld_out, st->K);
   MSC_REQUIRE((flags & ~(MSC_SCORE_CRP_PRIOR | MSC_SCORE_NIW_F32)) == 0, "unknown flags 0x%x", flags);
   MSC_HIP(hipSetDevice(st->ctx->device));
@@ -848,7 +848,7 @@ static int commit(msc_state *st) {
 
 extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols,
                               uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags) {
-  MSC_REQUIRE(st && z_dev, "null argument");
+  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
   MSC_REQUIRE((flags & ~(MSC_ACC_RESET | MSC_ACC_SUBTRACT | MSC_ACC_NO_COMMIT)) == 0, "unknown flags 0x%x", flags);
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
@@ -909,7 +909,7 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
 extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *cols,
                                 uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z_dev,
                                 uint64_t seed, uint64_t sweep) {
-  MSC_REQUIRE(st && z_dev, "null argument");
+  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
   if (nrows == 0) return MSC_OK;

@@ -36,7 +36,7 @@ def make_feature(family, N, K, rng, dim=0, hp=None):
     elif family == orc.DM:
         th = rng.dirichlet(np.ones(dim) * 0.7, K)
         tot = rng.integers(0, 40, N)
-        vals = np.stack([rng.multinomial(t, th[g]) for t, g in zip(tot, z_true)]).astype(np.int32).reshape(N, dim)
+        vals = np.array([rng.multinomial(t, th[g]) for t, g in zip(tot, z_true)], dtype=np.int32).reshape(N, dim)
         hp = hp or dict(alphas=list(rng.uniform(0.3, 2.0, dim).astype(np.float32)))
         dt = np.dtype((np.int32, (dim,)))
     elif family == orc.DD:

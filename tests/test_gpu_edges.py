@@ -1,0 +1,122 @@
+"""GPU: degenerate shapes and error behaviour of the C ABI (through common_amd.runtime):
+empty and one-row views, one group, row counts that straddle every tile boundary, bad arguments."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import TOL, load_state, make_feature, oracle_scores, recarray_of, rel_err, state_from_assignment
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu_ctx, specs, N, K, seed):
+    import common_amd
+    rng = np.random.default_rng(seed)
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    return feats, z, fs, view, st
+
+
+@pytest.mark.parametrize("specs", [[(orc.NICH, 0)], [(orc.BB, 0), (orc.GP, 0), (orc.DD, 4)], [(orc.NIW, 3)], [(orc.DM, 3)]])
+def test_empty_view_is_a_no_op(gpu_ctx, specs):
+    import common_amd
+    K = 5
+    rng = np.random.default_rng(0)
+    feats = [make_feature(f, 0, K, rng, d) for f, d in specs]
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    assert view.nrows == 0
+    st = common_amd.State(gpu_ctx, specs, K)
+    out = st.score_value(view)
+    assert tuple(out.shape) == (0, K)
+    z = torch.empty(0, dtype=torch.int32, device=gpu_ctx.torch_device)
+    st.accumulate(view, z)
+    assert np.array_equal(st.get_group_counts(), np.zeros(K, dtype=np.uint32))
+    st.sweep_assign(view, z, seed=1, sweep=0)
+    sd = st.score_data().cpu().numpy()
+    assert np.all(np.abs(sd) < 1e-6)          # empty groups: marginal likelihood of no data
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1025])
+def test_row_counts_across_every_tile_boundary(gpu_ctx, N):
+    for specs, K in (([(orc.NICH, 0)], 3), ([(orc.BB, 0), (orc.NICH, 0), (orc.GP, 0)], 5), ([(orc.DM, 3), (orc.BNB, 0)], 4)):
+        feats, z, fs, view, st = _setup(gpu_ctx, specs, N, K, seed=N)
+        got = st.score_value(view).cpu().numpy()
+        assert got.shape == (N, K)
+        assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+        zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+        loo = st.score_value(view, z=zt).cpu().numpy()
+        assert rel_err(loo, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
+@pytest.mark.parametrize("K", [1, 2, 255, 256, 257, 1024, 1025])
+def test_group_counts_across_every_tile_boundary(gpu_ctx, K):
+    feats, z, fs, view, st = _setup(gpu_ctx, [(orc.NICH, 0)], 300, K, seed=K)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.set_alpha(2.0)
+    st.sweep_assign(view, zt, seed=3, sweep=1)
+    znew = zt.cpu().numpy()
+    assert znew.min() >= 0 and znew.max() < K
+    if K == 1:
+        assert np.all(znew == 0)
+
+
+def test_one_group_one_row_one_feature(gpu_ctx):
+    feats, z, fs, view, st = _setup(gpu_ctx, [(orc.GP, 0)], 1, 1, seed=5)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    loo = st.score_value(view, z=zt).cpu().numpy()     # the only row leaves the only group: prior predictive
+    F = orc.Family(orc.GP, feats[0]["hp"], 0, "f64")
+    assert rel_err(loo[0, 0], F.score_value(F.new_groups(1), 0, feats[0]["values"][0])) <= TOL
+
+
+def test_unassigned_rows_are_ignored_by_accumulate_and_scored_without_removal(gpu_ctx):
+    import common_amd
+    rng = np.random.default_rng(2)
+    N, K = 500, 6
+    feats = [make_feature(orc.NICH, N, K, rng), make_feature(orc.DD, N, K, rng, 5)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[::3] = -1                                                   # not assigned (entity_state.hpp:57-72 callers)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.DD, 5)], K)
+    for i, (F, _, _) in enumerate(fs):
+        st.set_hp(i, F.hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    assert np.array_equal(st.get_group_counts(), np.bincount(z[z >= 0], minlength=K))
+    assert np.array_equal(st.get_ss(1)["counts"], fs[1][2]["counts"])
+    loo = st.score_value(view, z=zt).cpu().numpy()
+    assert rel_err(loo, oracle_scores(feats, fs, z=z)).max() <= TOL
+
+
+def test_bad_arguments_are_refused_with_a_message(gpu_ctx):
+    import common_amd
+    from common_amd._lib import MicroscopesHipError
+    rng = np.random.default_rng(1)
+    feats = [make_feature(orc.NICH, 10, 2, rng)]
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    with pytest.raises(MicroscopesHipError):
+        common_amd.State(gpu_ctx, [(orc.DD, 0)], 3)              # dd needs 1..128 categories
+    with pytest.raises(MicroscopesHipError):
+        common_amd.State(gpu_ctx, [(orc.NIW, 33)], 3)            # one 32x32 tile
+    with pytest.raises(MicroscopesHipError):
+        common_amd.State(gpu_ctx, [(99, 0)], 3)                  # unknown family
+    with pytest.raises(MicroscopesHipError):
+        common_amd.State(gpu_ctx, [(orc.NICH, 0)], 0)            # no groups
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], 2)
+    with pytest.raises(MicroscopesHipError):
+        st.score_value(view, row0=5, nrows=10)                   # rows outside the view
+    with pytest.raises(MicroscopesHipError):
+        st.set_hp(0, np.zeros(3, dtype=np.float32))              # wrong hp block size
+    st2 = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.BB, 0)], 2)
+    with pytest.raises(MicroscopesHipError):
+        st2.score_value(view)                                    # the view has one column, the state two features
