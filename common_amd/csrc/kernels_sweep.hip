@@ -63,7 +63,8 @@ MSC_DEV float wave_incl_scan(float v, int) {
 // s[j] = -inf for k >= K.  Mirrors scores_to_probs + sample_discrete: subtract the max,
 // exponentiate, and return the first k whose running sum reaches dart * total; K-1 if
 // rounding lets the dart fall off the end (util.hpp:155).
-template <int G>
+// LOG2: the scores are already in units of log2 (the caller folded log2(e) into its constants).
+template <int G, bool LOG2 = false>
 MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_t K) {
   float m = s[0];
 #pragma unroll
@@ -72,22 +73,26 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
   float p[G], sum = 0.f;
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    p[j] = __builtin_amdgcn_exp2f((s[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
+    p[j] = __builtin_amdgcn_exp2f(LOG2 ? s[j] - m : (s[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
     sum += p[j];
   }
   const float incl = wave_incl_scan(sum, lane);
   const float total = lane_bcast(incl, 63);
   const float dart = u01 * total;
+  // the running sum is monotone, so the first entry that reaches the dart is found by counting the
+  // entries that do not; entries with k >= K have p = 0 and cannot be the first
   float c = incl - sum;
-  int idx = -1;
+  int nmiss = 0;
 #pragma unroll
   for (int j = 0; j < G; j++) {
     c += p[j];
-    if (idx < 0 && c >= dart && (uint32_t)(G * lane + j) < K) idx = G * lane + j;
+    nmiss += c < dart ? 1 : 0;
   }
-  const unsigned long long hit = __builtin_amdgcn_ballot_w64(idx >= 0);
+  const unsigned long long hit = __builtin_amdgcn_ballot_w64(nmiss < G);
   if (hit == 0ull) return (int)K - 1;
-  return lane_bcast(idx, (int)__builtin_ctzll(hit));
+  const int l = (int)__builtin_ctzll(hit);
+  const int k = G * l + lane_bcast(nmiss, l);
+  return k < (int)K ? k : (int)K - 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -122,6 +127,18 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     lc[j] = g.x; lc[j + 1] = g.y; lc[j + 2] = g.z; lc[j + 3] = g.w;
   }
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  // Sampling only needs the scores up to what exp2 sees, so everything is moved to log2 units once
+  // per lane: c0' = (c0 + log count) log2e (or -inf beyond K), c1 ln2 log2e = c1, c1' = c1 log2e, and
+  // the prior of an empty group enters as emp * e with emp = log2e there and 0 elsewhere.
+  constexpr float kLog2e = 1.44269504088896340736f;
+  float c0s[G], c1s[G], emp[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    const bool empty = __builtin_isinf(lc[j]);
+    c0s[j] = (kb + j >= K) ? -INFINITY : (c0[j] + (empty ? 0.f : lc[j])) * kLog2e;
+    c1s[j] = c1[j] * kLog2e;
+    emp[j] = empty ? kLog2e : 0.f;
+  }
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
   const uint64_t nchunks = (nrows + 63) / 64;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -138,23 +155,30 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     float sloo = 0.f, erow = le0;
     if (gz >= 0) {
       erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
-      sloo = own[rb + lane];      // leave-one-out score + prior of the own group (k_loo_own)
+      sloo = own[rb + lane] * kLog2e;      // leave-one-out score + prior of the own group (k_loo_own)
     }
     int znew = gz;
     for (int r = 0; r < nr; r++) {
-      const float x = lane_bcast(xv, r), e = lane_bcast(erow, r), sl = lane_bcast(sloo, r);
+      const float x = lane_bcast(xv, r), e_raw = lane_bcast(erow, r), sl = lane_bcast(sloo, r);
+      // log(alpha / n_empty) is -inf when no group is empty; then no emp[j] is set either, and 0 * inf must not happen
+      const float e = __builtin_isinf(e_raw) ? 0.f : e_raw;
       const int g = lane_bcast(gz, r);
-      const bool masked = (mbits >> r) & 1ull;          // masked value: only the prior speaks
       float s[G];
+      if ((mbits >> r) & 1ull) {                          // masked value: only the prior speaks
 #pragma unroll
-      for (int j = 0; j < G; j++) {
-        const float prior = __builtin_isinf(lc[j]) ? e : lc[j];
-        float v = (masked ? 0.f : nich_eval(x, mh[j], ml[j], c0[j], c1l[j], c1[j], c2[j])) + prior;
-        if ((int)(kb + j) == g) v = sl;
-        if (kb + j >= K) v = -INFINITY;
-        s[j] = v;
+        for (int j = 0; j < G; j++)
+          s[j] = (kb + j >= K) ? -INFINITY : (__builtin_isinf(lc[j]) ? e_raw : lc[j]) * kLog2e;
+      } else {
+#pragma unroll
+        for (int j = 0; j < G; j++)
+          s[j] = fmaf(emp[j], e, nich_eval(x, mh[j], ml[j], c0s[j], c1[j], c1s[j], c2[j]));
       }
-      const int pick = sample_from_scores<G>(s, lane_bcast(u01, r), lane, K);
+      if (g >= 0 && lane == g / G) {                       // the own group: its leave-one-out value
+#pragma unroll
+        for (int j = 0; j < G; j++)
+          if (j == g % G) s[j] = sl;
+      }
+      const int pick = sample_from_scores<G, true>(s, lane_bcast(u01, r), lane, K);
       if (lane == r) znew = pick;
     }
     if (has_row) z[rb + lane] = znew;
