@@ -300,7 +300,45 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
   }
 }
 
+// Pack consecutive features into groups whose table blocks fit the LDS slot of the tile kernels
+// (score_block.hpp, score_tile): greedy, at most kGrpRows rows per group.
+static void plan_groups(msc_state *st) {
+  auto rows_of = [](const FeatDesc &d) -> uint32_t {
+    switch (d.family) {
+      case MSC_BB:
+      case MSC_BBNC: return 2;
+      case MSC_NICH: return 6;
+      case MSC_DD: return std::min<uint32_t>(d.dim, 64);
+      case MSC_GP:
+      case MSC_BNB: return std::min<uint32_t>(d.vcap, 64);
+      default: return 0;
+    }
+  };
+  uint32_t f = 0;
+  while (f < st->nfeat) {
+    uint32_t used = 0, g = f;
+    while (g < st->nfeat && used + rows_of(st->desc_host[g]) <= (uint32_t)kGrpRows) {
+      st->desc_host[g].grp_off = used;
+      st->desc_host[g].grp_rows = rows_of(st->desc_host[g]);
+      used += rows_of(st->desc_host[g]);
+      g++;
+    }
+    for (uint32_t i = f; i < g; i++) st->desc_host[i].grp_end = g;
+    f = g;
+  }
+  // unmasked lookup features take the tight inner loop (runs of them never leave it)
+  for (uint32_t i = 0; i < st->nfeat; i++) {
+    FeatDesc &d = st->desc_host[i];
+    d.kind = MSC_KIND_GENERIC;
+    if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
+    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8;
+    else if (d.family == MSC_GP || d.family == MSC_BNB) d.kind = MSC_KIND_LOOKUP_U32;
+    else if (d.family == MSC_DD) d.kind = MSC_KIND_LOOKUP_I32;
+  }
+}
+
 static int upload_desc(msc_state *st) {
+  plan_groups(st);
   MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat,
                          hipMemcpyHostToDevice, st->ctx->stream));
   return MSC_OK;
@@ -309,7 +347,7 @@ static int upload_desc(msc_state *st) {
 extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *features,
                                 uint32_t nfeatures, uint32_t ngroups, msc_state **out) {
   MSC_REQUIRE(ctx && features && out, "null argument");
-  MSC_REQUIRE(nfeatures > 0, "a state needs at least one feature");
+  MSC_REQUIRE(nfeatures > 0 && nfeatures <= 65535, "a state needs 1..65535 features (got %u)", nfeatures);
   MSC_REQUIRE(ngroups > 0 && ngroups <= (1u << 20), "ngroups %u out of range", ngroups);
   *out = nullptr;
   MSC_HIP(hipSetDevice(ctx->device));

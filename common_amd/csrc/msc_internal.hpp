@@ -18,6 +18,7 @@ namespace msc {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kGroupTile = 256;    // groups per k-tile: lane <-> 4 consecutive groups
 constexpr unsigned kMaxDDDim = 128;
+constexpr int kGrpRows = 128;   // table rows the LDS slot of the tile kernels holds (128 KiB): one feature group
 constexpr unsigned kGpMaxTable = 1024;   // gp counts below this are exact table entries
 
 // ---- error plumbing --------------------------------------------------------
@@ -99,7 +100,14 @@ struct FeatDesc {
   const uint32_t *dm_meta;    // dm: [dim+1][2] = {first table row, counts covered} of every stage (device);
                               //     count v of a stage occupies table rows first + 2v (hi) and first + 2v + 1 (lo)
   const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)
+  // tile kernels, group plan (abi.cpp plan_groups): consecutive features share the LDS slot
+  // (32-bit fields: the kernels read them with scalar loads; a 16-bit field costs a vector load and a full wait)
+  uint32_t grp_off;           // first row of this feature's table block inside the slot
+  uint32_t grp_rows;          // rows of the block staged in LDS (entries beyond are read from global)
+  uint32_t grp_end;           // one past the last feature of this feature's group
+  uint32_t kind;              // MSC_KIND_*: which inner loop of the tile kernel scores this feature
 };
+enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 
 // families whose score is a lookup of the row's count in an exact per-group table
 __host__ __device__ inline bool is_count_family(int family) { return family == MSC_GP || family == MSC_BNB; }

@@ -260,6 +260,80 @@ MSC_DEV void add_dm_stage(const FeatDesc &fd, uint32_t sub, const float4 *__rest
 }
 
 // ---------------------------------------------------------------------------
+// States without a dm feature.  The host packs consecutive features into groups whose table blocks
+// fit the 128 KiB LDS slot together (FeatDesc::grp_*, abi.cpp plan_groups); the workgroup copies a
+// whole group, synchronises once, and then every wave runs through the group's features on its
+// own: value of its rows, lookups / evaluations, next feature.  Inside a group the waves drift
+// apart, so one wave's load latency sits under another's arithmetic; per (feature, 128-row chunk)
+// this costs ~1000 cycles where a barrier per feature cost ~2500 (profiles/r01_c3_stage_costs.txt).
+// ---------------------------------------------------------------------------
+template <int R, int W>
+MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
+                               int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t kb = ktile * kGroupTile + lane * 4;
+  const bool has_row = lane < nr;
+  const uint64_t myrow = row_abs0 + lane;
+  int f0 = 0;
+  while (f0 < nfeat) {
+    const int f1 = (int)feats[f0].grp_end;
+    __syncthreads();                                    // the slot's previous readers are done
+    for (int f = f0; f < f1; f++) {
+      const FeatDesc &fd = feats[f];
+      const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
+      const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
+      float4 *dst = lds + (size_t)fd.grp_off * 64;
+      for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)   // one 1 KiB table row per wave instruction
+        glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my share of the group's tables has landed
+    __syncthreads();                                    // ... everyone's
+    int f = f0;
+    while (f < f1) {
+      // runs of unmasked lookup features (bb, gp, bnb, dd) stay in this loop: nothing but the value load,
+      // eight ds_read_b128 and the adds; it is left for a feature of another kind or when a row's entry is
+      // not in the staged block
+      while (f < f1) {
+        const FeatDesc &fd = feats[f];
+        const uint32_t kind = fd.kind;
+        if (kind == MSC_KIND_GENERIC) break;
+        uint32_t idx = 0;
+        if (has_row) {
+          if (kind == MSC_KIND_LOOKUP_U8) idx = (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[myrow] != 0);
+          else idx = reinterpret_cast<const uint32_t *>(fd.col)[myrow];
+        }
+        if (kind == MSC_KIND_LOOKUP_I32) {
+          const int v = (int)idx;
+          idx = (uint32_t)(v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v));     // keep the gather in bounds
+        }
+        if (__builtin_amdgcn_ballot_w64(idx >= fd.grp_rows) != 0ull) break;
+        const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 4) {
+          float4 t[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) t[j] = buf[(uint32_t)lane_bcast((int)idx, r0 + j) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; j++) add4(acc[r0 + j], t[j]);
+          __builtin_amdgcn_sched_barrier(0);            // four reads in flight, not eight: 16 fewer live registers
+        }
+        f++;
+      }
+      if (f >= f1) break;
+      const FeatDesc &fd = feats[f];
+      const uint32_t raw = load_raw_value<false>(fd, 0, myrow, has_row);
+      const unsigned long long mbits =
+          fd.mask == nullptr ? 0ull : __builtin_amdgcn_ballot_w64(load_masked<false>(fd, myrow, has_row));
+      const float4 *buf = lds + (size_t)fd.grp_off * 64;
+      if (mbits == 0ull) add_feature<R, false>(fd, buf, fd.grp_rows, kpad, kb, lane, raw, mbits, acc);
+      else add_feature<R, true>(fd, buf, fd.grp_rows, kpad, kb, lane, raw, mbits, acc);
+      f++;
+    }
+    f0 = f1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // acc[r] (+)= sum over features of score_value(row rb+r, groups kb..kb+3).
 // All W waves of the workgroup must call this together (it contains barriers); a wave whose
 // rows are out of range passes nr = 0.  lds: two buffers of kLdsRows * 64 float4.
@@ -273,6 +347,10 @@ template <int R, int W, bool DM>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                         int lane, uint64_t row_abs0, int nr, uint64_t wg_row0, uint32_t wg_rows,
                         float4 *__restrict__ lds, float4 (&acc)[R]) {
+  if constexpr (!DM) {
+    score_tile_groups<R, W>(feats, nfeat, kpad, ktile, lane, row_abs0, nr, lds, acc);
+    return;
+  }
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
   const uint64_t myrow = row_abs0 + lane;
@@ -282,28 +360,7 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t 
   uint32_t nrows_lds = stage_table<W, DM>(feats[0], 0, kpad, ktile, lds, wg_row0, wg_rows);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr (!DM) {
-    // every feature is one stage: the plain software pipeline over the feature list
-    for (int f = 0; f < nfeat; f++) {
-      const FeatDesc fd = feats[f];
-      const float4 *buf = lds + (size_t)(f & 1) * kLdsRows * 64;
-      uint32_t raw_next = 0, nrows_next = 0;
-      unsigned long long mbits_next = 0ull;
-      if (f + 1 < nfeat) {
-        raw_next = load_raw_value<DM>(feats[f + 1], 0, myrow, has_row);
-        mbits_next = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[f + 1], myrow, has_row));
-        nrows_next = stage_table<W, DM>(feats[f + 1], 0, kpad, ktile, lds + (size_t)((f + 1) & 1) * kLdsRows * 64, wg_row0, wg_rows);
-      }
-      if (mbits == 0ull) add_feature<R, false>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
-      else add_feature<R, true>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // table f+1 has landed (this wave's share)
-      __syncthreads();                                    // ... everyone's share; buffer f&1 is free again
-      raw = raw_next;
-      mbits = mbits_next;
-      nrows_lds = nrows_next;
-    }
-    return;
-  }
+  if constexpr (!DM) return;                          // (states without a dm feature take score_tile_groups)
   // advance the pipeline by one stage: prefetch (value, mask, table) of the stage after (f, sub)
   // into the other buffer, run `body` on the current one, wait, barrier, rotate
   int f = 0;
