@@ -326,14 +326,20 @@ static void plan_groups(msc_state *st) {
     for (uint32_t i = f; i < g; i++) st->desc_host[i].grp_end = g;
     f = g;
   }
-  // unmasked lookup features take the tight inner loop (runs of them never leave it)
+  // Unmasked lookup features whose whole table is staged (so that no row can miss it) take the tight inner
+  // loop of the tile kernel; run_end lets a wave stay in it for a whole run of them.
   for (uint32_t i = 0; i < st->nfeat; i++) {
     FeatDesc &d = st->desc_host[i];
     d.kind = MSC_KIND_GENERIC;
     if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
     if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8;
-    else if (d.family == MSC_GP || d.family == MSC_BNB) d.kind = MSC_KIND_LOOKUP_U32;
-    else if (d.family == MSC_DD) d.kind = MSC_KIND_LOOKUP_I32;
+    else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32;
+    else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32;
+  }
+  for (uint32_t i = st->nfeat; i-- > 0;) {
+    FeatDesc &d = st->desc_host[i];
+    if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
+    else d.run_end = (i + 1 < d.grp_end && st->desc_host[i + 1].kind != MSC_KIND_GENERIC) ? st->desc_host[i + 1].run_end : i + 1;
   }
 }
 

@@ -106,6 +106,9 @@ struct FeatDesc {
   uint32_t grp_rows;          // rows of the block staged in LDS (entries beyond are read from global)
   uint32_t grp_end;           // one past the last feature of this feature's group
   uint32_t kind;              // MSC_KIND_*: which inner loop of the tile kernel scores this feature
+  uint32_t run_end;           // lookup kinds: one past the last feature of the run of lookup features this one
+                              // belongs to (within its group); generic: its own index
+  uint32_t pad3;
 };
 enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 

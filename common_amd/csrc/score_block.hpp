@@ -290,13 +290,13 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
     __syncthreads();                                    // ... everyone's
     int f = f0;
     while (f < f1) {
-      // runs of unmasked lookup features (bb, gp, bnb, dd) stay in this loop: nothing but the value load,
-      // eight ds_read_b128 and the adds; it is left for a feature of another kind or when a row's entry is
-      // not in the staged block
-      while (f < f1) {
+      // A run of unmasked lookup features (bb, gp, bnb, dd with their whole table staged; the host marks them
+      // and the run's end): nothing but the value load, eight ds_read_b128 and the adds.  One entry, one exit,
+      // so the accumulators stay where they are.
+      const int fe = (int)feats[f].run_end;
+      for (; f < fe; f++) {
         const FeatDesc &fd = feats[f];
         const uint32_t kind = fd.kind;
-        if (kind == MSC_KIND_GENERIC) break;
         uint32_t idx = 0;
         if (has_row) {
           if (kind == MSC_KIND_LOOKUP_U8) idx = (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[myrow] != 0);
@@ -305,8 +305,9 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         if (kind == MSC_KIND_LOOKUP_I32) {
           const int v = (int)idx;
           idx = (uint32_t)(v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v));     // keep the gather in bounds
+        } else if (kind == MSC_KIND_LOOKUP_U32) {
+          idx = idx < fd.grp_rows ? idx : fd.grp_rows - 1;                              // (never taken: rows cover the column's maximum)
         }
-        if (__builtin_amdgcn_ballot_w64(idx >= fd.grp_rows) != 0ull) break;
         const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 4) {
@@ -317,10 +318,10 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
           for (int j = 0; j < 4; j++) add4(acc[r0 + j], t[j]);
           __builtin_amdgcn_sched_barrier(0);            // four reads in flight, not eight: 16 fewer live registers
         }
-        f++;
       }
       if (f >= f1) break;
       const FeatDesc &fd = feats[f];
+      if (fd.kind != MSC_KIND_GENERIC) continue;        // the next run starts here
       const uint32_t raw = load_raw_value<false>(fd, 0, myrow, has_row);
       const unsigned long long mbits =
           fd.mask == nullptr ? 0ull : __builtin_amdgcn_ballot_w64(load_masked<false>(fd, myrow, has_row));
