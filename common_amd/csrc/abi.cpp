@@ -921,11 +921,21 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
                                      (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->red_i64);
     if (rc == -2) return fail(MSC_EUNSUPPORTED, "accumulate tables for %u groups exceed LDS", st->K);
     if (rc) return fail(MSC_EHIP, "k_accumulate launch failed: %s", hipGetErrorString(hipGetLastError()));
-    for (uint32_t f = 0; f < st->nfeat; f++)
-      if (st->feats[f].family == MSC_NIW &&
-          launch_niw_accumulate(s, st->ctx->num_cus, st->desc_dev, f, st->K, row0, nrows, z_dev,
-                                (flags & MSC_ACC_SUBTRACT) ? -1 : 1))
-        return fail(MSC_EHIP, "k_niw_accumulate launch failed");
+    for (uint32_t f = 0; f < st->nfeat; f++) {
+      if (st->feats[f].family != MSC_NIW) continue;
+      MSC_REQUIRE(nrows < (1ull << 32), "niw accumulate takes at most 2^32 - 1 rows per call");
+      const size_t need = 2 * (size_t)st->K + 1 + (size_t)nrows;
+      if (st->niw_scratch_len < need) {
+        void *p = nullptr;
+        MSC_HIP(hipMalloc(&p, need * sizeof(uint32_t)));
+        st->owned.push_back(p);
+        st->niw_scratch = static_cast<uint32_t *>(p);
+        st->niw_scratch_len = need;
+      }
+      if (launch_niw_accumulate(s, st->ctx->num_cus, st->desc_dev, f, st->K, row0, nrows, z_dev,
+                                (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->niw_scratch))
+        return fail(MSC_EHIP, "niw accumulate launch failed");
+    }
   }
   for (auto &h : st->feats) h.raw_valid = false;
   if (!(flags & MSC_ACC_NO_COMMIT)) MSC_TRY(commit(st));

@@ -14,7 +14,7 @@
 //                   (v_mfma_f64_16x16x4_f64).  In float the score error is c1 * eps(q) with
 //                   c1 >= dim/2, which breaks the 1e-6 gate for small groups at dim 32; the f32
 //                   kernel stays available behind MSC_SCORE_NIW_F32 at twice the matrix rate.
-//   k_niw_accumulate  sum_x, sum_xxT by group (double atomics, 256-B contiguous per instruction)
+//   k_niw_bucket_*, k_niw_group_sums   sum_x, sum_xxT by group: rows bucketed by group, summed in registers
 //
 // Leave-one-out needs no second factorisation: with u = x - mu_n, t = u^T Psi_n^-1 u,
 // c = kappa_n/(kappa_n-1):  Psi' = Psi_n - c u u^T,  det Psi' = det Psi_n (1 - c t),
@@ -415,35 +415,142 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// accumulate: wave per row; lanes sweep the d + d*d additive slots of the row's group
+// accumulate: sum_x and sum_xxT by group.  Rows are first bucketed by group (histogram, scan,
+// scatter of row indices: three small integer kernels), then every group's rows are summed by a few
+// workgroups in registers -- lane (i, half) keeps sum_xxT[i][16 half .. 16 half + 15] in sixteen
+// doubles and lane (i, 0) sum_x[i]; products of two floats are exact in double -- and each
+// workgroup adds its 1056 partial sums once.  (First version: one double atomic per row and
+// element, 2.7e8 of them on C4: 1.9 ms; this one: see DESIGN.md section 5.)
+// scratch (uint32): [0, K] offsets | [K+1, 2K+1) cursors | [2K+1, 2K+1+nrows) row indices
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_niw_accumulate(const FeatDesc *__restrict__ feats, uint32_t f,
-                                                         uint32_t K, uint64_t row0, uint64_t nrows,
-                                                         const int32_t *__restrict__ z, int sign) {
+MSC_DEV bool niw_row_counts(const FeatDesc &fd, uint32_t K, uint64_t row, int g) {
+  if (g < 0 || (uint32_t)g >= K) return false;
+  if (fd.mask != nullptr)
+    for (uint32_t e = 0; e < fd.dim; e++)
+      if (fd.mask[row * fd.dim + e] != 0) return false;       // a masked vector is not part of the group
+  return true;
+}
+// LDS: per-workgroup histogram first (the groups are few and every row would otherwise hit one of K global
+// words); K beyond the LDS budget goes straight to global atomics.
+constexpr uint32_t kBucketLdsGroups = 8192;
+__global__ __launch_bounds__(256) void k_niw_bucket_count(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                           uint64_t row0, uint64_t nrows,
+                                                           const int32_t *__restrict__ z, uint32_t *__restrict__ scratch) {
+  extern __shared__ uint32_t hist[];
   const FeatDesc fd = feats[f];
-  const uint32_t d = fd.dim;
-  const int lane = threadIdx.x & 63;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-  const float *X = reinterpret_cast<const float *>(fd.col);
-  const size_t stride = d + (size_t)d * d;
-  for (uint64_t n = wave_id; n < nrows; n += nwaves) {
-    const int g = z[n];
-    if (g < 0 || (uint32_t)g >= K) continue;
-    if (fd.mask != nullptr) {
-      bool m = false;
-      for (uint32_t e = lane; e < d; e += 64) m |= fd.mask[(row0 + n) * d + e] != 0;
-      if (__builtin_amdgcn_ballot_w64(m) != 0ull) continue;
+  const bool lds = K <= kBucketLdsGroups;
+  if (lds) {
+    for (uint32_t k = threadIdx.x; k < K; k += 256) hist[k] = 0u;
+    __syncthreads();
+  }
+  const uint64_t per = (nrows + gridDim.x - 1) / gridDim.x, lo = (uint64_t)blockIdx.x * per;
+  const uint64_t hi = lo + per < nrows ? lo + per : nrows;
+  for (uint64_t n = lo + threadIdx.x; n < hi; n += 256)
+    if (niw_row_counts(fd, K, row0 + n, z[n])) atomicAdd(lds ? &hist[z[n]] : &scratch[K + 1 + z[n]], 1u);   // counts, in the cursor slots
+  if (lds) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < K; k += 256)
+      if (hist[k]) atomicAdd(&scratch[K + 1 + k], hist[k]);
+  }
+}
+// one block: offsets[k] = sum of counts before k, offsets[K] = total; cursors := 0
+__global__ __launch_bounds__(1024) void k_niw_bucket_scan(uint32_t K, uint32_t *__restrict__ scratch) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (K + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < K ? lo + per : K;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; k++) s += scratch[K + 1 + k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t c = scratch[K + 1 + k];
+    scratch[k] = run;
+    scratch[K + 1 + k] = 0u;
+    run += c;
+  }
+  if (threadIdx.x == 1023) scratch[K] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_niw_bucket_scatter(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                             uint64_t row0, uint64_t nrows,
+                                                             const int32_t *__restrict__ z, uint32_t *__restrict__ scratch) {
+  extern __shared__ uint32_t sh[];                   // [K] counts of this workgroup's slab, [K] where its share starts
+  const FeatDesc fd = feats[f];
+  uint32_t *idx = scratch + 2 * (size_t)K + 1;
+  const uint64_t per = (nrows + gridDim.x - 1) / gridDim.x, lo = (uint64_t)blockIdx.x * per;
+  const uint64_t hi = lo + per < nrows ? lo + per : nrows;
+  if (K > kBucketLdsGroups) {
+    for (uint64_t n = lo + threadIdx.x; n < hi; n += 256) {
+      const int g = z[n];
+      if (niw_row_counts(fd, K, row0 + n, g)) idx[scratch[g] + atomicAdd(&scratch[K + 1 + g], 1u)] = (uint32_t)n;
     }
-    const float *x = X + (row0 + n) * d;
-    double *dst = fd.acc_f64 + (size_t)g * stride;
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[g]), (unsigned long long)(long long)sign);
-    for (uint32_t i = lane; i < d; i += 64) atomicAdd(&dst[i], (double)sign * (double)x[i]);
-    for (uint32_t idx = lane; idx < d * d; idx += 64) {
-      const uint32_t i = idx / d, j = idx - i * d;
-      atomicAdd(&dst[d + idx], (double)sign * (double)x[i] * (double)x[j]);
+    return;
+  }
+  uint32_t *cnt = sh, *base = sh + K;
+  for (uint32_t k = threadIdx.x; k < K; k += 256) cnt[k] = 0u;
+  __syncthreads();
+  for (uint64_t n = lo + threadIdx.x; n < hi; n += 256)
+    if (niw_row_counts(fd, K, row0 + n, z[n])) atomicAdd(&cnt[z[n]], 1u);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < K; k += 256) {   // reserve this workgroup's share of every group's range
+    base[k] = cnt[k] ? scratch[k] + atomicAdd(&scratch[K + 1 + k], cnt[k]) : 0u;
+    cnt[k] = 0u;
+  }
+  __syncthreads();
+  for (uint64_t n = lo + threadIdx.x; n < hi; n += 256) {
+    const int g = z[n];
+    if (niw_row_counts(fd, K, row0 + n, g)) idx[base[g] + atomicAdd(&cnt[g], 1u)] = (uint32_t)n;
+  }
+}
+// grid (K, splits); the 4 waves of a block take the group's rows round-robin
+__global__ __launch_bounds__(256) void k_niw_group_sums(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                         uint64_t row0, const uint32_t *__restrict__ scratch, int sign) {
+  __shared__ float xs[4][32];
+  __shared__ double red[4][17][64];
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim, k = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t i = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;
+  const uint32_t beg = scratch[k], end = scratch[k + 1];
+  const uint32_t *idx = scratch + 2 * (size_t)K + 1;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  double sxx[16], sx = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) sxx[j] = 0.0;
+  for (uint32_t p = beg + blockIdx.y * 4 + wave; p < end; p += gridDim.y * 4) {
+    const float *x = X + (row0 + idx[p]) * d;
+    xs[wave][lane & 31] = ((uint32_t)(lane & 31) < d) ? x[lane & 31] : 0.f;      // (both halves write the same value)
+    const double xi = (double)xs[wave][i];
+    if (half == 0) sx += xi;
+#pragma unroll
+    for (int j = 0; j < 16; j++) sxx[j] = fma(xi, (double)xs[wave][half * 16 + j], sxx[j]);
+  }
+  // the four waves' partial sums, then one atomic per element and block
+#pragma unroll
+  for (int j = 0; j < 16; j++) red[wave][j][lane] = sxx[j];
+  red[wave][16][lane] = sx;
+  __syncthreads();
+  if (end == beg) return;
+  const size_t stride = d + (size_t)d * d;
+  double *dst = fd.acc_f64 + (size_t)k * stride;
+  for (uint32_t e = threadIdx.x; e < 17 * 64; e += 256) {
+    const uint32_t j = e >> 6, l = e & 63, ii = l >> 1, hh = l & 1u;
+    const double v = red[0][j][l] + red[1][j][l] + red[2][j][l] + red[3][j][l];
+    if (ii >= d) continue;
+    if (j == 16) {
+      if (hh == 0 && v != 0.0) atomicAdd(&dst[ii], (double)sign * v);
+    } else {
+      const uint32_t col = hh * 16 + j;
+      if (col < d && v != 0.0) atomicAdd(&dst[d + (size_t)ii * d + col], (double)sign * v);
     }
   }
+  if (blockIdx.y == 0 && threadIdx.x == 0)
+    atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[k]), (unsigned long long)((long long)sign * (long long)(end - beg)));
 }
 
 // additive <-> raw for one niw feature (thread per element of the group-major block)
@@ -502,13 +609,24 @@ int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// scratch_dev: 2 K + 1 + nrows uint32 (see k_niw_bucket_*)
 int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
-                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign) {
-  uint64_t gx = (nrows + 3) / 4;
+                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign, uint32_t *scratch_dev) {
+  if (nrows == 0) return 0;
+  if (hipMemsetAsync(scratch_dev, 0, sizeof(uint32_t) * (2 * (size_t)K + 1), stream) != hipSuccess) return -1;
+  uint64_t gx = (nrows + 255) / 256;
   const uint64_t cap = (uint64_t)num_cus * 8;
   if (gx > cap) gx = cap;
-  if (gx == 0) gx = 1;
-  hipLaunchKernelGGL(k_niw_accumulate, dim3((unsigned)gx), dim3(256), 0, stream, feats_dev, f, K, row0, nrows, z, sign);
+  const size_t lds1 = K <= kBucketLdsGroups ? sizeof(uint32_t) * K : 0, lds2 = 2 * lds1;
+  hipLaunchKernelGGL(k_niw_bucket_count, dim3((unsigned)gx), dim3(256), lds1, stream, feats_dev, f, K, row0, nrows, z, scratch_dev);
+  hipLaunchKernelGGL(k_niw_bucket_scan, dim3(1), dim3(1024), 0, stream, K, scratch_dev);
+  hipLaunchKernelGGL(k_niw_bucket_scatter, dim3((unsigned)gx), dim3(256), lds2, stream, feats_dev, f, K, row0, nrows, z, scratch_dev);
+  uint32_t splits = (uint32_t)(((uint64_t)num_cus * 4 + K - 1) / K);      // about four workgroups per CU over all groups
+  const uint64_t by_rows = (nrows / K + 63) / 64;                           // ... but at least ~64 rows per workgroup
+  if (splits > by_rows) splits = (uint32_t)(by_rows ? by_rows : 1);
+  if (splits == 0) splits = 1;
+  if (splits > 65535u) splits = 65535u;
+  hipLaunchKernelGGL(k_niw_group_sums, dim3(K, splits), dim3(256), 0, stream, feats_dev, f, K, row0, scratch_dev, sign);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

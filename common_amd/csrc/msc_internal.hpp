@@ -259,4 +259,6 @@ struct msc_state {
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;
   size_t scratch_floats = 0;
+  uint32_t *niw_scratch = nullptr;   // row bucketing for niw accumulate: 2 K + 1 + rows uint32
+  size_t niw_scratch_len = 0;
 };
