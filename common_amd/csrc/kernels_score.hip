@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
       for (uint32_t v = 0; v < fd.vcap; v++)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
+      if (fd.loo64 != nullptr) gp_loo_prepare(fd.hp, cnt, fd.loo64 + k, kpad);
     } break;
     case MSC_BNB: {
       const double cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       nich_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k], o);
 #pragma unroll
       for (int i = 0; i < NICH_ROWS; i++) fd.tab[(size_t)i * kpad + k] = o[i];
+      if (fd.loo64 != nullptr) nich_loo_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.loo64 + k, kpad);
     } break;
     default: break;
   }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         s += log(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? (double)fd.raw_f32[g] : 1.0 - (double)fd.raw_f32[g]);
         break;
       case MSC_GP:
-        s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);
+        s += gp_loo_tab(fd.hp, fd.loo64 + g, kpad, fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);
         break;
       case MSC_BNB:
         s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0,
@@ -164,8 +166,8 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         s += dd_loo(fd.hp[v], fd.raw_u32[(size_t)(1 + v) * kpad + g], fd.aux, fd.raw_u32[g]);
       } break;
       case MSC_NICH:
-        s += nich_loo(fd.hp, fd.raw_u32[g], fd.raw_f32[g], fd.raw_f32[kpad + g],
-                      reinterpret_cast<const float *>(fd.col)[row]);
+        s += nich_loo_tab(fd.hp, fd.loo64 + g, kpad, fd.raw_f32[g], fd.raw_f32[kpad + g],
+                          reinterpret_cast<const float *>(fd.col)[row]);
         break;
       default: break;
     }

@@ -109,6 +109,7 @@ struct FeatDesc {
   uint32_t run_end;           // lookup kinds: one past the last feature of the run of lookup features this one
                               // belongs to (within its group); generic: its own index
   uint32_t pad3;
+  double *loo64;              // nich, gp: per-group constants of the leave-one-out pass, [loo_rows][kpad] (family_math.hpp)
 };
 enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 
@@ -128,6 +129,7 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
     default: return 0;
   }
 }
+inline uint32_t loo_rows(int family) { return family == MSC_NICH ? 11u : family == MSC_GP ? 2u : 0u; }
 inline uint32_t raw_u32_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
@@ -224,6 +226,7 @@ struct msc_feature_host {
   uint32_t *raw_u32 = nullptr;
   float *raw_f32 = nullptr;
   float *niw_raw = nullptr;     // [K][d + d*d] float
+  double *loo64 = nullptr;      // nich, gp: leave-one-out constants
   float *niw_w = nullptr, *niw_b = nullptr;
   double *niw_w64 = nullptr, *niw_mu64 = nullptr, *niw_c64 = nullptr;
   size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
