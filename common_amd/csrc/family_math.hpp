@@ -176,12 +176,6 @@ MSC_DEV float gp_eval_large(double v, double rowc, double a, double b, double ns
   return (float)(rowc + nse_a - 0.5 * log1p(v / a) + stirling_tail(a + v) - a * (u - log1p(u)) -
                  v * (w - log1p(w)));
 }
-// remove_value then score_value: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
-//   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b')
-MSC_DEV double gp_loo(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
-  const double a = (double)hp[0] + (double)sum, b1 = (double)hp[1] + (double)count - 1.0;
-  return lgamma_drop(a, v) - log_factorial(v) + (a - (double)v) * log(b1) - a * log1p(b1);
-}
 MSC_DEV double gp_score_data(const float *hp, uint32_t count, uint32_t sum, double log_prod) {
   const double al = hp[0], ib = hp[1];
   const double a = al + (double)sum, b = ib + (double)count;
@@ -317,21 +311,10 @@ MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1l
   log1p_parts(a * a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
 }
-// remove_value (Welford downdate) then score_value, all in double
-MSC_DEV double nich_loo(const float *hp, uint32_t count, float mean_f, float ctv_f, float xf) {
-  const double x = xf, mean = mean_f, ctv = ctv_f;
-  const double total = mean * (double)count, delta = x - mean;
-  const double n = (double)count - 1.0;
-  const double m2 = (count <= 1) ? 0.0 : (total - x) / n;
-  const double v2 = (n <= 1.0) ? 0.0 : ctv - delta * (x - m2);
-  const NichPost p = nich_posterior(hp, n, m2, v2);
-  const double lambda = p.kappa / ((p.kappa + 1.0) * p.sigmasq);        // nich_coeffs with the branch-free lgamma
-  const double c0 = lgamma_pos(0.5 * p.nu + 0.5) - lgamma_pos(0.5 * p.nu) + 0.5 * log(lambda / (kPi * p.nu));
-  const double c1 = 0.5 * p.nu + 0.5, c2 = lambda / p.nu;
-  const double d = x - p.mu;
-  return c0 - c1 * log1p(c2 * d * d);
-}
-// The same through per-group constants (k_prepare fills them; rows of FeatDesc::loo64): what depends on
+// Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:
+//   n = count - 1, m2 = (mean count - x) / n, v2 = ctv - (x - mean)(x - m2), then the posterior and the
+//   Student-t of the section header with (n, m2, v2).
+// It runs through per-group constants (k_prepare fills them; rows of FeatDesc::loo64): what depends on
 // the group alone -- reciprocals, the lgamma difference, logs -- is computed once per group, the row
 // keeps ~15 fma, one division, one log and one log1p.
 enum { NLOO_TOTAL = 0, NLOO_INV_N, NLOO_HAS_V2, NLOO_KMU, NLOO_N_INV_KN, NLOO_NUSIG, NLOO_INV_NUN, NLOO_NKK,
@@ -361,6 +344,8 @@ MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, flo
   const double dd = x - mun;
   return t[NLOO_C0G * stride] - 0.5 * log(sig) - t[NLOO_C1 * stride] * log1p(t[NLOO_K2G * stride] * dd * dd / sig);
 }
+// gp: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
+//   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b'),  the two logs per group
 enum { GLOO_LB = 0, GLOO_L1B, GLOO_ROWS };
 MSC_DEV void gp_loo_prepare(const float *hp, uint32_t count, double *out, size_t stride) {
   const double b1 = (double)hp[1] + (double)count - 1.0;
