@@ -79,6 +79,8 @@ _SIGS = {
     "msc_state_commit_reduce": (C.c_int, [C.c_void_p]),
     "msc_value_op_single": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "msc_relation_blocks": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_void_p]),
 }
 
 EXPORTS = tuple(sorted(_SIGS))

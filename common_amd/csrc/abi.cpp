@@ -1029,6 +1029,27 @@ extern "C" int msc_state_commit_reduce(msc_state *st) {
   return commit(st);
 }
 
+extern "C" int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64_t *shape,
+                                   const int32_t *const *z_dev, const uint32_t *ngroups,
+                                   const uint32_t *positions_dev, uint64_t ncells, int32_t *z_cell_dev) {
+  MSC_REQUIRE(ctx && shape && z_dev && ngroups, "null argument");
+  MSC_REQUIRE(ndim >= 1 && ndim <= 8, "a relation has 1..8 dimensions (got %u)", ndim);
+  MSC_REQUIRE(z_cell_dev || ncells == 0, "null output");
+  unsigned long long total = 1, blocks = 1;
+  for (uint32_t d = 0; d < ndim; d++) {
+    MSC_REQUIRE(shape[d] > 0 && z_dev[d] && ngroups[d] > 0, "dimension %u: empty shape, null assignment or no groups", d);
+    total *= shape[d];
+    blocks *= ngroups[d];
+    MSC_REQUIRE(blocks <= (1ull << 31) - 1, "more than 2^31 - 1 blocks");
+  }
+  MSC_REQUIRE(positions_dev || ncells == total, "a dense relation of this shape has %llu cells, not %llu", total,
+              (unsigned long long)ncells);
+  MSC_HIP(hipSetDevice(ctx->device));
+  if (launch_relation_blocks(ctx->stream, ndim, shape, z_dev, ngroups, positions_dev, ncells, z_cell_dev))
+    return fail(MSC_EHIP, "k_relation_blocks launch failed");
+  return MSC_OK;
+}
+
 extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, int op,
                                    const float *host_hp, void *host_ss, const void *host_value,
                                    float *score) {

@@ -411,9 +411,53 @@ __global__ __launch_bounds__(128) void k_dm_stats(const uint32_t *__restrict__ c
   if (i < n) rowtot[i] = tot;
 }
 
+// cell -> block index of a relation (msc_relation_blocks): one thread per cell
+struct RelArgs {
+  uint32_t ndim;
+  uint64_t shape[8];
+  const int32_t *z[8];
+  uint32_t ngroups[8];
+};
+__global__ __launch_bounds__(256) void k_relation_blocks(RelArgs a, const uint32_t *__restrict__ positions,
+                                                          uint64_t ncells, int32_t *__restrict__ out) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  uint64_t rem = c;
+  long long block = 0, mult = 1;
+  bool ok = true;
+  for (int d = (int)a.ndim - 1; d >= 0; d--) {        // last dimension fastest, in the cell order and in the block index
+    uint64_t idx;
+    if (positions != nullptr) idx = positions[c * a.ndim + d];
+    else {
+      idx = rem % a.shape[d];
+      rem /= a.shape[d];
+    }
+    const int g = idx < a.shape[d] ? a.z[d][idx] : -1;
+    ok &= g >= 0 && (uint32_t)g < a.ngroups[d];
+    block += (long long)g * mult;
+    mult *= a.ngroups[d];
+  }
+  out[c] = ok ? (int32_t)block : -1;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int launch_relation_blocks(hipStream_t stream, uint32_t ndim, const uint64_t *shape, const int32_t *const *z_dev,
+                           const uint32_t *ngroups, const uint32_t *positions_dev, uint64_t ncells, int32_t *out_dev) {
+  if (ncells == 0) return 0;
+  RelArgs a;
+  a.ndim = ndim;
+  for (uint32_t d = 0; d < 8; d++) {
+    a.shape[d] = d < ndim ? shape[d] : 1;
+    a.z[d] = d < ndim ? z_dev[d] : nullptr;
+    a.ngroups[d] = d < ndim ? ngroups[d] : 1;
+  }
+  hipLaunchKernelGGL(k_relation_blocks, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, stream, a, positions_dev,
+                     ncells, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint16_t *out_dev,
                     uint32_t *colmax_dev, uint32_t *rowtot_dev) {
   if (n == 0) return 0;

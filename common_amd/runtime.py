@@ -393,3 +393,39 @@ def _alias_tensor(ptr, n, dtype, device):
     typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4",
                torch.int32: "<i4"}[dtype]
     return torch.as_tensor(_CudaArrayView(ptr, n, typestr), device=device)
+
+
+class RelationView(object):
+    """A relation (numpy N-d array, optionally masked) on the device: a one-feature DataView whose rows
+    are the relation's cells in row-major order (microscopes/common/relation/dataview.pyx numpy_dataview).
+    `blocks(zs, ngroups)` maps per-dimension cluster assignments to the cell's block (= group) index."""
+
+    def __init__(self, ctx, array):
+        if array is None or array.ndim < 1:
+            raise ValueError("need an N-d array")
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in array.shape)
+        data = np.ascontiguousarray(np.ma.getdata(array)).reshape(-1)
+        rec = np.zeros(data.shape[0], dtype=[("f0", data.dtype)])
+        rec["f0"] = data
+        if hasattr(array, "mask"):
+            m = np.zeros(data.shape[0], dtype=[("f0", np.bool_)])
+            m["f0"] = np.ascontiguousarray(np.ma.getmaskarray(array)).reshape(-1)
+            rec = np.ma.masked_array(rec, mask=m)
+        self.cells = DataView.from_recarray(ctx, rec)
+
+    def blocks(self, zs, ngroups):
+        """zs: one int32 device tensor per dimension; ngroups: clusters per dimension -> int32 [ncells]"""
+        if len(zs) != len(self.shape) or len(ngroups) != len(self.shape):
+            raise ValueError("one assignment vector and one cluster count per dimension")
+        for z, n in zip(zs, self.shape):
+            if z.dtype != torch.int32 or z.numel() != n or not z.is_contiguous():
+                raise ValueError("assignments must be contiguous int32 tensors of the dimension's length")
+        nd = len(self.shape)
+        out = torch.empty(self.cells.nrows, dtype=torch.int32, device=self.ctx.torch_device)
+        shape = (C.c_uint64 * nd)(*self.shape)
+        zp = (C.c_void_p * nd)(*[z.data_ptr() for z in zs])
+        kg = (C.c_uint32 * nd)(*[int(k) for k in ngroups])
+        L.check(self.ctx.lib.msc_relation_blocks(self.ctx._h, nd, shape, zp, kg, None, self.cells.nrows,
+                                                 C.c_void_p(out.data_ptr())))
+        return out

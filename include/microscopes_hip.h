@@ -240,6 +240,20 @@ typedef enum msc_value_op {
 int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, int op, const float *host_hp,
                         void *host_ss, const void *host_value, float *score);
 
+/* ---- relations (irm's per-cell data; relation/dataview.hpp:25-578) ------ */
+/*
+ * A relation reaches the kernels as a one-feature dataview whose rows are its
+ * cells (dense: row-major order; compressed: the stored entries).  This turns the
+ * per-dimension cluster assignments into the cell's block (= group) index:
+ *   z_cell[c] = sum_d z_dev[d][index_d(c)] * prod_{e > d} ngroups[e]
+ * (-1 when one of the cell's entities is unassigned).  positions_dev: null for a
+ * dense relation, else uint32 [ncells][ndim] index tuples.  z_dev[d]: device int32
+ * [shape[d]].  Asynchronous on the context's stream.
+ */
+int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64_t *shape,
+                        const int32_t *const *z_dev, const uint32_t *ngroups,
+                        const uint32_t *positions_dev, uint64_t ncells, int32_t *z_cell_dev);
+
 #ifdef __cplusplus
 }
 #endif

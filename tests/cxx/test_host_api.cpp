@@ -2,6 +2,7 @@
 // type system, the packed-record accessors, the CRP group manager and the wire format.
 // Data of the first three blocks is the data the reference's own tests hold
 // (test/test_dataview.py:31-75, test/cxx/test_group_manager.cpp:22-66).
+#include <microscopes/common/relation/dataview.hpp>
 #include <microscopes/common/group_manager.hpp>
 #include <microscopes/common/recarray/dataview.hpp>
 #include <microscopes/models/noop.hpp>
@@ -162,7 +163,98 @@ static void test_noop_model_and_wire() {
   CHECK(fs.size() == 3 && fs[0].f32 == 2.5f && fs[1].varint == 300 && fs[2].bytes == "abc");
 }
 
+// the checks of test/cxx/test_relation.cpp:19-70, 120-190: every slice shows exactly the present cells of that
+// row / column / plane with their values and positions
+static void check_2d(const std::vector<int32_t> &data, const std::vector<uint8_t> &mask, size_t n, size_t m,
+                     const relation::dataview &d) {
+  CHECK(d.dims() == 2 && d.shape()[0] == n && d.shape()[1] == m);
+  for (size_t i = 0; i < n; i++) {
+    std::vector<bool> seen(m, false);
+    for (const auto &p : d.slice(0, i)) {
+      CHECK(p.first.size() == 2 && p.first[0] == i && p.first[1] < m);
+      CHECK(!mask[i * m + p.first[1]] && !seen[p.first[1]]);
+      CHECK(p.second.get<int32_t>(0) == data[i * m + p.first[1]]);
+      seen[p.first[1]] = true;
+    }
+    for (size_t j = 0; j < m; j++) CHECK(seen[j] == !mask[i * m + j]);
+  }
+  for (size_t j = 0; j < m; j++) {
+    std::vector<bool> seen(n, false);
+    for (const auto &p : d.slice(1, j)) {
+      CHECK(p.first[1] == j && p.first[0] < n && !mask[p.first[0] * m + j] && !seen[p.first[0]]);
+      CHECK(p.second.get<int32_t>(0) == data[p.first[0] * m + j]);
+      seen[p.first[0]] = true;
+    }
+    for (size_t i = 0; i < n; i++) CHECK(seen[i] == !mask[i * m + j]);
+  }
+}
+
+static void test_relation_dataviews() {
+  using namespace relation;
+  std::mt19937 r(7);
+  const size_t n = 5, m = 7;
+  std::vector<int32_t> data(n * m);
+  std::vector<uint8_t> mask(n * m);
+  for (size_t i = 0; i < n * m; i++) {
+    data[i] = int32_t(r() % 100) + 1;
+    mask[i] = (r() % 10) < 3;
+  }
+  mask[0] = 0;
+  static_assert(sizeof(bool) == 1, "bool masks");
+  row_major_dense_dataview dense(reinterpret_cast<const uint8_t *>(data.data()), reinterpret_cast<const bool *>(mask.data()),
+                                 {n, m}, runtime_type(TYPE_I32));
+  check_2d(data, mask, n, m, dense);
+  CHECK(dense.get({0, 0}).get<int32_t>(0) == data[0] && !dense.get({0, 0}).anymasked());
+  bool threw = false;
+  try { dense.get({n, 0}); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  // everything masked but one cell (test_relation.cpp:99-117)
+  std::vector<uint8_t> one(n * m, 1);
+  one[0] = 0;
+  row_major_dense_dataview lonely(reinterpret_cast<const uint8_t *>(data.data()), reinterpret_cast<const bool *>(one.data()),
+                                  {n, m}, runtime_type(TYPE_I32));
+  check_2d(data, one, n, m, lonely);
+  // the same matrix as csr + csc: absent entries are missing, not zero
+  std::vector<int32_t> csr_d, csc_d;
+  std::vector<uint32_t> csr_i, csr_p(1, 0), csc_i, csc_p(1, 0);
+  for (size_t i = 0; i < n; i++) {
+    for (size_t j = 0; j < m; j++)
+      if (!mask[i * m + j]) { csr_d.push_back(data[i * m + j]); csr_i.push_back(uint32_t(j)); }
+    csr_p.push_back(uint32_t(csr_i.size()));
+  }
+  for (size_t j = 0; j < m; j++) {
+    for (size_t i = 0; i < n; i++)
+      if (!mask[i * m + j]) { csc_d.push_back(data[i * m + j]); csc_i.push_back(uint32_t(i)); }
+    csc_p.push_back(uint32_t(csc_i.size()));
+  }
+  compressed_2darray sparse(reinterpret_cast<const uint8_t *>(csr_d.data()), csr_i.data(), csr_p.data(),
+                            reinterpret_cast<const uint8_t *>(csc_d.data()), csc_i.data(), csc_p.data(), n, m,
+                            runtime_type(TYPE_I32));
+  check_2d(data, mask, n, m, sparse);
+  CHECK(sparse.nnz() == csr_d.size());
+  // three dimensions: a slice is a plane, positions enumerate the other two indices
+  const size_t a = 3, b = 4, c = 2;
+  std::vector<float> cube(a * b * c);
+  for (size_t i = 0; i < cube.size(); i++) cube[i] = float(i);
+  row_major_dense_dataview d3(reinterpret_cast<const uint8_t *>(cube.data()), nullptr, {a, b, c}, runtime_type(TYPE_F32));
+  for (size_t dim = 0; dim < 3; dim++)
+    for (size_t idx = 0; idx < d3.shape()[dim]; idx++) {
+      size_t count = 0;
+      for (const auto &p : d3.slice(dim, idx)) {
+        CHECK(p.first[dim] == idx);
+        CHECK(p.second.get<float>(0) == cube[(p.first[0] * b + p.first[1]) * c + p.first[2]]);
+        count++;
+      }
+      CHECK(count == a * b * c / d3.shape()[dim]);
+    }
+  threw = false;
+  try { row_major_dense_dataview bad(reinterpret_cast<const uint8_t *>(cube.data()), nullptr, {}, runtime_type(TYPE_F32)); }
+  catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+}
+
 int main() {
+  test_relation_dataviews();
   test_types_and_offsets();
   test_row_accessor_over_reference_rows();
   test_group_manager_bookkeeping_and_serialization();

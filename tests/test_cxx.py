@@ -81,6 +81,13 @@ def test_plugin_api_on_device_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_relation_dataviews_on_device():
+    exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_relation_gpu.cpp"), "test_relation_gpu",
+               ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"] + LINK)
+    assert "test_relation_gpu ok" in subprocess.check_output([exe]).decode()
+
+
+@pytest.mark.gpu
 def test_perf_group_harness_runs():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bin")])
     out = subprocess.check_output([os.path.join(ROOT, "bin", "perf_group_hip"), "64", "2"]).decode()
