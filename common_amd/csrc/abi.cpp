@@ -862,8 +862,15 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   }
   for (uint32_t f = 0; f < st->nfeat; f++) {
     if (st->feats[f].family != MSC_NIW) continue;
+    if (z_dev && st->niw_qown_cap < nrows) {            // leave-one-out: the score kernel parks q of the own group here
+      void *p = nullptr;
+      MSC_HIP(hipMalloc(&p, nrows * sizeof(double)));
+      st->owned.push_back(p);
+      st->niw_qown = static_cast<double *>(p);
+      st->niw_qown_cap = nrows;
+    }
     if (launch_niw_score(s, st->ctx->num_cus, st->desc_dev, f, st->K, st->kpad, row0, nrows, z_dev, written,
-                         niw_f32, out_dev, ld_out))
+                         niw_f32, st->niw_qown, out_dev, ld_out))
       return fail(MSC_EHIP, "k_score_niw launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
   }

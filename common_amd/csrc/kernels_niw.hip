@@ -303,7 +303,7 @@ template <int JB, bool LOO, bool ACCUM>
 __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict__ feats, uint32_t f,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
-                                                      float *__restrict__ out, uint64_t ld) {
+                                                      double *__restrict__ qown, float *__restrict__ out, uint64_t ld) {
   const FeatDesc fd = feats[f];
   const uint32_t d = fd.dim;
   const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
@@ -384,8 +384,13 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 #pragma unroll
           for (int jb = 0; jb < JB; jb++) {
             const double q = valid ? qkeep[jb][i] : 0.0;
-            double sc = c0 - c1 * log1p(q);
-            if (LOO && valid && gz[jb] == (int)kg) sc = c64[2] + c64[3] * log1p(-fmin(c64[4] * q, 1.0 - 1e-15));
+            // q is accurate (f64 contraction); its logarithm only has to be relatively accurate, and the
+            // compensated float log1p is (1e-7 of a term of the score's own size) at a tenth of the double routine
+            double sc = c0 - c1 * (double)log1p_acc((float)q);
+            if (LOO && valid && gz[jb] == (int)kg) {       // the own group: its value comes from k_niw_loo_patch
+              qown[rb + 16 * jb + c] = q;
+              sc = 0.0;
+            }
             if (msk[jb]) sc = 0.0;
             const float scf = (float)sc;
             if (i == 0) pend[jb].x = scf;
@@ -412,6 +417,24 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
       }
     }
   }
+}
+
+// leave-one-out value of every row's own group (closed form in the file header) from the q the score kernel
+// left in qown; the score kernel wrote 0 there, so this adds.  One thread per row.
+__global__ __launch_bounds__(256) void k_niw_loo_patch(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                        uint64_t row0, uint64_t nrows, const int32_t *__restrict__ z,
+                                                        const double *__restrict__ qown, float *__restrict__ out,
+                                                        uint64_t ld) {
+  const FeatDesc fd = feats[f];
+  const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nrows) return;
+  const int g = z[n];
+  if (g < 0 || (uint32_t)g >= K) return;
+  if (fd.mask != nullptr)
+    for (uint32_t e = 0; e < fd.dim; e++)
+      if (fd.mask[(row0 + n) * fd.dim + e] != 0) return;
+  const double *c64 = fd.niw_c64 + (size_t)g * 8;
+  out[n * ld + g] += (float)(c64[2] + c64[3] * log1p(-fmin(c64[4] * qown[n], 1.0 - 1e-15)));
 }
 
 // ---------------------------------------------------------------------------
@@ -586,7 +609,7 @@ int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_
 template <bool LOO, bool ACCUM>
 static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, const FeatDesc *feats_dev,
                                uint32_t f, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
-                               const int32_t *z, float *out, uint64_t ld) {
+                               const int32_t *z, double *qown, float *out, uint64_t ld) {
   constexpr int kRowsPerWave = 64;             // 2 tiles of 32 (f32) or 4 blocks of 16 (f64)
   const uint64_t nblocks = (nrows + kRowsPerWave - 1) / kRowsPerWave;
   uint64_t gx = (nblocks + 3) / 4;
@@ -595,17 +618,21 @@ static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, c
   const dim3 grid((unsigned)(gx ? gx : 1)), block(256);
   if (f32_fast)
     hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
-  else
-    hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+  else {
+    hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    if (LOO)
+      hipLaunchKernelGGL(k_niw_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, f, K, row0,
+                         nrows, z, qown, out, ld);
+  }
 }
 
 int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
                      uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
-                     float *out, uint64_t ld) {
-  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
-  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
-  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
-  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+                     double *qown, float *out, uint64_t ld) {
+  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

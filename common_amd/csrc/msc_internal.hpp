@@ -262,6 +262,8 @@ struct msc_state {
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;
   size_t scratch_floats = 0;
+  double *niw_qown = nullptr;        // q of every row's own group (niw leave-one-out), [niw_qown_cap]
+  size_t niw_qown_cap = 0;
   uint32_t *niw_scratch = nullptr;   // row bucketing for niw accumulate: 2 K + 1 + rows uint32
   size_t niw_scratch_len = 0;
 };
