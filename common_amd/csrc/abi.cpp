@@ -174,7 +174,6 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
     v->types.push_back(msc_runtime_type{uf[i].dst_type, types[i].count});
   }
   v->col_max.assign(ntypes, -1);
-  v->chunk_max.assign(ntypes, nullptr);
   v->dm_max.assign(ntypes, std::vector<uint32_t>());
   v->dm_tot.assign(ntypes, nullptr);
   if (nrows > 0) {
@@ -218,7 +217,6 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
     v->masks.push_back(dev_masks ? dev_masks[i] : nullptr);
   }
   v->col_max.assign(ntypes, -1);
-  v->chunk_max.assign(ntypes, nullptr);
   v->dm_max.assign(ntypes, std::vector<uint32_t>());
   v->dm_tot.assign(ntypes, nullptr);
   *out = v.release();
@@ -666,13 +664,10 @@ static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, u
   FeatDesc &d = st->desc_host[f];
   const uint32_t nst = h.dim + 1;
   hipStream_t s = st->ctx->stream;
-  const size_t nchunks = (size_t)((view->nrows + 127) / 128);
   if (view->dm_max[c].empty()) {
     std::vector<uint32_t> mx(nst, 0u);
     if (view->nrows > 0) {
-      void *cm = nullptr, *tmp = nullptr, *tot = nullptr;
-      MSC_HIP(hipMalloc(&cm, sizeof(uint16_t) * (nchunks * nst + 1)));
-      view->owned_lazy.push_back(cm);
+      void *tmp = nullptr, *tot = nullptr;
       MSC_HIP(hipMalloc(&tmp, sizeof(uint32_t) * nst));
       view->owned_lazy.push_back(tmp);
       MSC_HIP(hipMalloc(&tot, sizeof(uint32_t) * view->nrows));
@@ -680,16 +675,13 @@ static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, u
       view->dm_tot[c] = static_cast<uint32_t *>(tot);
       MSC_HIP(hipMemsetAsync(tmp, 0, sizeof(uint32_t) * nst, s));
       if (launch_dm_stats(s, static_cast<const uint32_t *>(view->cols[c]), view->nrows, h.dim,
-                          static_cast<uint16_t *>(cm), static_cast<uint32_t *>(tmp), view->dm_tot[c]))
+                          static_cast<uint32_t *>(tmp), view->dm_tot[c]))
         return fail(MSC_EHIP, "k_dm_stats launch failed");
       MSC_HIP(hipMemcpyAsync(mx.data(), tmp, sizeof(uint32_t) * nst, hipMemcpyDeviceToHost, s));
       MSC_HIP(hipStreamSynchronize(s));
-      view->chunk_max[c] = static_cast<uint16_t *>(cm);
     }
     view->dm_max[c] = mx;
   }
-  d.chunk_max = view->chunk_max[c];
-  d.cm_stride = (uint32_t)nchunks;
   d.dm_tot = view->dm_tot[c];
   std::vector<uint32_t> meta(2 * (size_t)nst);
   uint32_t rows = 0;
@@ -709,7 +701,7 @@ static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, u
     }
     h.dm_meta = meta;
     MSC_HIP(hipMemcpyAsync(h.dm_meta_dev, h.dm_meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, s));
-    MSC_HIP(hipStreamSynchronize(s));                  // meta is a local the copy reads from
+    MSC_HIP(hipStreamSynchronize(s));
     d.dm_meta = h.dm_meta_dev;
     h.derived_valid = false;
   }
@@ -760,16 +752,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
           MSC_HIP(hipStreamSynchronize(st->ctx->stream));
         }
         view->col_max[c] = (long long)mx;
-        if (view->nrows > 0) {
-          void *cm = nullptr;
-          MSC_HIP(hipMalloc(&cm, sizeof(uint16_t) * ((view->nrows + 127) / 128 + 1)));
-          view->owned_lazy.push_back(cm);
-          view->chunk_max[c] = static_cast<uint16_t *>(cm);
-          if (launch_chunk_max_u32(st->ctx->stream, static_cast<const uint32_t *>(view->cols[c]), view->nrows, view->chunk_max[c]))
-            return fail(MSC_EHIP, "k_chunk_max_u32 launch failed");
-        }
       }
-      st->desc_host[f].chunk_max = view->chunk_max[c];
       const uint32_t vcap = (uint32_t)std::min<long long>(view->col_max[c] + 1, (long long)kGpMaxTable);
       if (vcap != st->desc_host[f].vcap) {
         st->desc_host[f].vcap = vcap;

@@ -360,33 +360,11 @@ __global__ __launch_bounds__(256) void k_col_max_u32(const uint32_t *__restrict_
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// per 128-row chunk maximum of a uint32 column, saturated to 16 bits (sizes the gp table copies)
-__global__ __launch_bounds__(128) void k_chunk_max_u32(const uint32_t *__restrict__ col, uint64_t n,
-                                                        uint16_t *__restrict__ out) {
-  __shared__ uint32_t part[2];
-  const uint64_t i = (uint64_t)blockIdx.x * 128 + threadIdx.x;
-  uint32_t m = i < n ? col[i] : 0u;
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
-    m = o > m ? o : m;
-  }
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t mm = part[0] > part[1] ? part[0] : part[1];
-    out[blockIdx.x] = (uint16_t)(mm > 65535u ? 65535u : mm);
-  }
-}
-
-// dm column (uint32 [n][dim]): for every 128-row chunk the maximum of each category and of the row
-// totals (out[(stage) * nchunks + chunk], saturated to 16 bits), and the column-wide maxima
-// (colmax[dim + 1], atomicMax; zeroed by the caller), and every row's total (tot[n]).
-// One block per chunk, one thread per row.
-__global__ __launch_bounds__(128) void k_dm_stats(const uint32_t *__restrict__ col, uint64_t n, uint32_t dim,
-                                                   uint16_t *__restrict__ out, uint32_t *__restrict__ colmax,
-                                                   uint32_t *__restrict__ rowtot) {
-  __shared__ uint32_t part[2];
-  const uint64_t i = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+// dm column (uint32 [n][dim]): the column-wide maxima of each category and of the row totals
+// (colmax[dim + 1], atomicMax; zeroed by the caller), and every row's total (rowtot[n]).  One thread per row.
+__global__ __launch_bounds__(256) void k_dm_stats(const uint32_t *__restrict__ col, uint64_t n, uint32_t dim,
+                                                   uint32_t *__restrict__ colmax, uint32_t *__restrict__ rowtot) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t *x = col + i * dim;
   uint32_t tot = 0;
   for (uint32_t s = 0; s <= dim; s++) {
@@ -399,14 +377,7 @@ __global__ __launch_bounds__(128) void k_dm_stats(const uint32_t *__restrict__ c
       const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64);
       m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t mm = part[0] > part[1] ? part[0] : part[1];
-      out[(size_t)s * gridDim.x + blockIdx.x] = (uint16_t)(mm > 65535u ? 65535u : mm);
-      atomicMax(&colmax[s], mm);
-    }
-    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&colmax[s], m);
   }
   if (i < n) rowtot[i] = tot;
 }
@@ -458,17 +429,10 @@ int launch_relation_blocks(hipStream_t stream, uint32_t ndim, const uint64_t *sh
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint16_t *out_dev,
-                    uint32_t *colmax_dev, uint32_t *rowtot_dev) {
+int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint32_t *colmax_dev,
+                    uint32_t *rowtot_dev) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_dm_stats, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, col, n, dim, out_dev,
-                     colmax_dev, rowtot_dev);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(k_chunk_max_u32, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, col, n, out_dev);
+  hipLaunchKernelGGL(k_dm_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, col, n, dim, colmax_dev, rowtot_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

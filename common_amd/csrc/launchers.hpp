@@ -73,9 +73,8 @@ int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, 
                       uint32_t kpad, float *out);
 int launch_relation_blocks(hipStream_t stream, uint32_t ndim, const uint64_t *shape, const int32_t *const *z_dev,
                            const uint32_t *ngroups, const uint32_t *positions_dev, uint64_t ncells, int32_t *out_dev);
-int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint16_t *out_dev,
-                    uint32_t *colmax_dev, uint32_t *rowtot_dev);
-int launch_chunk_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint16_t *out_dev);
+int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint32_t *colmax_dev,
+                    uint32_t *rowtot_dev);
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
                   uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);

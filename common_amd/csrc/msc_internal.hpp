@@ -94,10 +94,8 @@ struct FeatDesc {
   double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
   double aux;              // dd: sum of the alphas
   uint32_t vcap;           // gp, bnb: rows of the exact table (min(column max + 1, kGpMaxTable))
-  uint32_t cm_stride;      // dm: entries per stage in chunk_max (= 128-row chunks of the bound view)
-  const uint16_t *chunk_max;  // gp, bnb: max count of every 128-row chunk of the bound column (null: unknown)
-                              // dm: [dim+1][cm_stride], one row per category and one for the row totals
-  const uint32_t *dm_meta;    // dm: [dim+1][2] = {first table row, counts covered} of every stage (device);
+  uint32_t pad1;
+  const uint32_t *dm_meta;    // dm: [dim+1][2] per stage (device): {first table row, entries in the table};
                               //     count v of a stage occupies table rows first + 2v (hi) and first + 2v + 1 (lo)
   const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)
   // tile kernels, group plan (abi.cpp plan_groups): consecutive features share the LDS slot
@@ -211,7 +209,6 @@ struct msc_dataview {
   std::vector<void *> masks;             // device mask columns or null
   std::vector<void *> owned;             // allocations to free
   mutable std::vector<long long> col_max;  // lazily computed maximum of uint32 columns (-1 = unknown)
-  mutable std::vector<uint16_t *> chunk_max;  // and of every 128-row chunk of them (device, owned)
   mutable std::vector<std::vector<uint32_t>> dm_max;  // dm columns: maxima of each category and of the row totals (lazy)
   mutable std::vector<uint32_t *> dm_tot;             // dm columns: row totals (device, owned)
   mutable std::vector<void *> owned_lazy;
@@ -232,7 +229,7 @@ struct msc_feature_host {
   size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
   size_t f64_off = 0, f64_len = 0;
   size_t tab_rows_cap = 0;      // dm: rows (+4) the table buffer holds; it is (re)sized when a column is bound
-  uint32_t *dm_meta_dev = nullptr;   // dm: [dim+1][2] stage table offsets / sizes
+  uint32_t *dm_meta_dev = nullptr;   // dm: [dim+1][2] stage tables (FeatDesc::dm_meta)
   std::vector<uint32_t> dm_meta;     // host copy
   bool raw_valid = true;        // raw tables hold the truth
   bool additive_valid = false;  // additive tables are in sync with raw

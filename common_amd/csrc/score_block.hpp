@@ -73,51 +73,9 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
   }
 }
 
-// A feature is scored in one or more *stages*, each one table block staged through LDS and one
-// value per row: every family has a single stage except dm, which has dim + 1 (one count lookup
-// per category, one for the row total; family_math.hpp).
-MSC_DEV uint32_t nstages_of(const FeatDesc &fd) { return fd.family == MSC_DM ? fd.dim + 1 : 1; }
-
-// rows of a single-stage feature's table block that go to LDS, and where the block starts in fd.tab
-// wg_row0 / wg_rows: the absolute row range the workgroup scores in this chunk; for count tables only
-// the rows up to the largest count in that range are worth copying (the per-128-row maxima
-// were computed once when the column was bound).
-MSC_DEV uint32_t chunk_need(const uint16_t *cmax, uint32_t need, uint64_t wg_row0, uint32_t wg_rows) {
-  if (cmax != nullptr) {
-    uint32_t m = 0;
-    for (uint64_t c = wg_row0 >> 7; c <= (wg_row0 + wg_rows - 1) >> 7; c++) {
-      const uint32_t v = cmax[c];
-      m = v > m ? v : m;
-    }
-    need = m + 1 < need ? m + 1 : need;
-  }
-  return need;
-}
-MSC_DEV uint32_t lds_rows_of(const FeatDesc &fd, uint32_t &first_row, uint64_t wg_row0, uint32_t wg_rows) {
-  first_row = 0;
-  switch (fd.family) {
-    case MSC_BB: return 2;
-    case MSC_BBNC: return 2;
-    case MSC_NICH: return NICH_ROWS;
-    case MSC_DD: return fd.dim < (uint32_t)kLdsRows ? fd.dim : (uint32_t)kLdsRows;
-    case MSC_BNB:
-    case MSC_GP: {
-      first_row = GP_T0;
-      const uint32_t need = chunk_need(fd.chunk_max, fd.vcap, wg_row0, wg_rows);
-      return need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
-    }
-    default: return 0;
-  }
-}
-// the same for stage `sub` of a dm feature: entries are (hi, lo) row pairs
-MSC_DEV uint32_t dm_lds_rows_of(const FeatDesc &fd, uint32_t sub, uint32_t &first_row, uint64_t wg_row0, uint32_t wg_rows) {
-  first_row = fd.dm_meta[2 * sub];
-  const uint32_t need = 2 * chunk_need(fd.chunk_max ? fd.chunk_max + (size_t)sub * fd.cm_stride : nullptr,
-                                       fd.dm_meta[2 * sub + 1], wg_row0, wg_rows);
-  return need < (uint32_t)kLdsRows ? need : (uint32_t)kLdsRows;
-}
-
-// the stage's value of this lane's row, as raw 32 bits (reinterpreted per family)
+// The feature's value of this lane's row, as raw 32 bits (reinterpreted per family).  A dm feature is
+// scored in dim + 1 *stages* (one count lookup per category, one for the row total; family_math.hpp),
+// `sub` selects the stage.
 template <bool DM>
 MSC_DEV uint32_t load_raw_value(const FeatDesc &fd, uint32_t sub, uint64_t row, bool has_row) {
   if (!has_row || fd.col == nullptr) return 0u;
@@ -141,20 +99,6 @@ MSC_DEV bool load_masked(const FeatDesc &fd, uint64_t row, bool has_row) {
   bool m = false;
   for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
   return m;
-}
-
-// issue the async copy of the stage's table block for this k-tile into buf (no wait); returns the rows copied
-template <int W, bool DM>
-MSC_DEV uint32_t stage_table(const FeatDesc &fd, uint32_t sub, uint32_t kpad, uint32_t ktile, float4 *buf,
-                             uint64_t wg_row0, uint32_t wg_rows) {
-  uint32_t first_row;
-  const uint32_t nrows_lds = (DM && fd.family == MSC_DM) ? dm_lds_rows_of(fd, sub, first_row, wg_row0, wg_rows)
-                                                         : lds_rows_of(fd, first_row, wg_row0, wg_rows);
-  const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t row = wave; row < nrows_lds; row += W)          // one 1 KiB table row per wave instruction
-    glds16(tile + (size_t)row * kpad + 4 * lane, buf + row * 64);
-  return nrows_lds;
 }
 
 // one stage's contribution to the R rows of this wave (tables already in `buf`)
@@ -237,25 +181,56 @@ MSC_DEV void add_feature(const FeatDesc &fd, const float4 *__restrict__ buf, con
   }
 }
 
-// one dm stage: the exact (hi) and remainder (lo) parts are summed separately (family_math.hpp)
-template <int R, bool MASKED>
-MSC_DEV void add_dm_stage(const FeatDesc &fd, uint32_t sub, const float4 *__restrict__ buf, const uint32_t nrows_lds,
-                          uint32_t kpad, uint32_t kb, int lane, uint32_t raw, unsigned long long mbits,
-                          float4 (&hi)[R], float4 (&lo)[R]) {
-  const uint32_t first_row = fd.dm_meta[2 * sub], vcap = fd.dm_meta[2 * sub + 1];
+// ---------------------------------------------------------------------------
+// One Dirichlet-Multinomial feature: dim + 1 count lookups per row (one per category, one for the row
+// total; family_math.hpp), each a (hi, lo) pair of table rows, the exact hi sums and the lo sums kept
+// apart.  The tables are read straight from L2: a stage's block has 2 x (largest count + 1) rows and a
+// workgroup's rows use each of them about once, so staging it in LDS moves more bytes than the
+// lookups themselves (measured: 3.46 ms staged, 2.72 ms direct for 4 x dm(4) on 1M rows).  Entry 0 of
+// every table is exactly zero (an absent category adds nothing) and is skipped.
+// dm_meta per stage: {first table row, entries in the table}
+// ---------------------------------------------------------------------------
+constexpr int kDmBatch = 8;       // stages whose row values are fetched together
+template <int R>
+MSC_DEV void score_dm_feature(const FeatDesc &fd, uint32_t kpad, uint32_t kb, int lane, uint64_t myrow, bool has_row,
+                              float4 (&acc)[R]) {
+  const uint32_t nst = fd.dim + 1;
+  const unsigned long long mbits = fd.mask == nullptr ? 0ull : __builtin_amdgcn_ballot_w64(load_masked<true>(fd, myrow, has_row));
+  float4 hi[R], lo[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) hi[r] = lo[r] = make_float4(0, 0, 0, 0);
+  // this lane's row: its total decides whether the tables apply at all (else k_gp_large_fix scores the row)
+  const uint32_t *xrow = reinterpret_cast<const uint32_t *>(fd.col) + myrow * fd.dim;
+  const uint32_t tot = (has_row && fd.col != nullptr) ? fd.dm_tot[myrow] : 0u;
+  const bool tabled = has_row && fd.col != nullptr && tot < kGpMaxTable;
+  for (uint32_t s0 = 0; s0 < nst; s0 += kDmBatch) {
+    uint32_t vals[kDmBatch];                            // one memory latency per batch of stages, not per stage
+#pragma unroll
+    for (int j = 0; j < kDmBatch; j++) {
+      const uint32_t st = s0 + j;
+      vals[j] = 0u;                                     // entry 0: contributes nothing
+      if (st < nst && tabled) vals[j] = st < fd.dim ? xrow[st] : tot;
+    }
+#pragma unroll
+    for (int j = 0; j < kDmBatch; j++) {
+      const uint32_t st = s0 + j;
+      if (st >= nst) break;
+      const uint32_t first_row = fd.dm_meta[2 * st], vcap = fd.dm_meta[2 * st + 1];
+      const float *tab = fd.tab + (size_t)first_row * kpad + kb;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t vr = (uint32_t)lane_bcast((int)vals[j], r);
+        if (vr == 0u || vr >= vcap || ((mbits >> r) & 1ull)) continue;   // (beyond the table: k_gp_large_fix took the whole row)
+        const float *p = tab + (size_t)(2 * vr) * kpad;
+        add4(hi[r], ld4(p));
+        add4(lo[r], ld4(p + kpad));
+      }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    if (MASKED && ((mbits >> r) & 1ull)) continue;
-    const uint32_t vr = (uint32_t)lane_bcast((int)raw, r);
-    if (vr >= vcap) continue;                         // rows beyond the tables: k_gp_large_fix
-    if (2 * vr + 1 < nrows_lds) {
-      add4(hi[r], buf[(2 * vr) * 64 + lane]);
-      add4(lo[r], buf[(2 * vr + 1) * 64 + lane]);
-    } else {
-      const float *p = fd.tab + (size_t)(first_row + 2 * vr) * kpad + kb;
-      add4(hi[r], ld4(p));
-      add4(lo[r], ld4(p + kpad));
-    }
+    add4(hi[r], lo[r]);
+    add4(acc[r], hi[r]);
   }
 }
 
@@ -267,7 +242,7 @@ MSC_DEV void add_dm_stage(const FeatDesc &fd, uint32_t sub, const float4 *__rest
 // apart, so one wave's load latency sits under another's arithmetic; per (feature, 128-row chunk)
 // this costs ~1000 cycles where a barrier per feature cost ~2500 (profiles/r01_c3_stage_costs.txt).
 // ---------------------------------------------------------------------------
-template <int R, int W>
+template <int R, int W, bool DM>
 MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                                int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -322,6 +297,11 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
       if (f >= f1) break;
       const FeatDesc &fd = feats[f];
       if (fd.kind != MSC_KIND_GENERIC) continue;        // the next run starts here
+      if (DM && fd.family == MSC_DM) {
+        if (fd.dm_meta != nullptr) score_dm_feature<R>(fd, kpad, kb, lane, myrow, has_row, acc);
+        f++;
+        continue;
+      }
       const uint32_t raw = load_raw_value<false>(fd, 0, myrow, has_row);
       const unsigned long long mbits =
           fd.mask == nullptr ? 0ull : __builtin_amdgcn_ballot_w64(load_masked<false>(fd, myrow, has_row));
@@ -348,71 +328,9 @@ template <int R, int W, bool DM>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                         int lane, uint64_t row_abs0, int nr, uint64_t wg_row0, uint32_t wg_rows,
                         float4 *__restrict__ lds, float4 (&acc)[R]) {
-  if constexpr (!DM) {
-    score_tile_groups<R, W>(feats, nfeat, kpad, ktile, lane, row_abs0, nr, lds, acc);
-    return;
-  }
-  const uint32_t kb = ktile * kGroupTile + lane * 4;
-  const bool has_row = lane < nr;
-  const uint64_t myrow = row_abs0 + lane;
-  __syncthreads();                                      // the previous chunk's readers are done
-  uint32_t raw = load_raw_value<DM>(feats[0], 0, myrow, has_row);
-  unsigned long long mbits = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[0], myrow, has_row));
-  uint32_t nrows_lds = stage_table<W, DM>(feats[0], 0, kpad, ktile, lds, wg_row0, wg_rows);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if constexpr (!DM) return;                          // (states without a dm feature take score_tile_groups)
-  // advance the pipeline by one stage: prefetch (value, mask, table) of the stage after (f, sub)
-  // into the other buffer, run `body` on the current one, wait, barrier, rotate
-  int f = 0;
-  uint32_t parity = 0;
-  auto step = [&](const FeatDesc &fd, uint32_t sub, auto &&body) {
-    const float4 *buf = lds + (size_t)parity * kLdsRows * 64;
-    int nf = f;
-    uint32_t nsub = sub + 1;
-    if (nsub >= nstages_of(fd)) {
-      nf = f + 1;
-      nsub = 0;
-    }
-    uint32_t raw_next = 0, nrows_next = 0;
-    unsigned long long mbits_next = mbits;              // the stages of one feature share its mask
-    if (nf < nfeat) {
-      raw_next = load_raw_value<DM>(feats[nf], nsub, myrow, has_row);
-      if (nf != f) mbits_next = __builtin_amdgcn_ballot_w64(load_masked<DM>(feats[nf], myrow, has_row));
-      nrows_next = stage_table<W, DM>(feats[nf], nsub, kpad, ktile, lds + (size_t)(parity ^ 1u) * kLdsRows * 64, wg_row0, wg_rows);
-    }
-    body(buf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next table has landed (this wave's share)
-    __syncthreads();                                    // ... everyone's share; this buffer is free again
-    raw = raw_next;
-    mbits = mbits_next;
-    nrows_lds = nrows_next;
-    parity ^= 1u;
-  };
-  while (f < nfeat) {
-    const FeatDesc fd = feats[f];
-    if (DM && fd.family == MSC_DM) {
-      float4 hi[R], lo[R];                              // live only across this feature's stages
-#pragma unroll
-      for (int r = 0; r < R; r++) hi[r] = lo[r] = make_float4(0, 0, 0, 0);
-      for (uint32_t sub = 0; sub <= fd.dim; sub++)
-        step(fd, sub, [&](const float4 *buf) {
-          if (mbits == 0ull) add_dm_stage<R, false>(fd, sub, buf, nrows_lds, kpad, kb, lane, raw, mbits, hi, lo);
-          else add_dm_stage<R, true>(fd, sub, buf, nrows_lds, kpad, kb, lane, raw, mbits, hi, lo);
-        });
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        add4(hi[r], lo[r]);
-        add4(acc[r], hi[r]);
-      }
-    } else if (fd.family != MSC_DM) {
-      step(fd, 0, [&](const float4 *buf) {
-        if (mbits == 0ull) add_feature<R, false>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
-        else add_feature<R, true>(fd, buf, nrows_lds, kpad, kb, lane, raw, mbits, acc);
-      });
-    }
-    f++;
-  }
+  (void)wg_row0;
+  (void)wg_rows;
+  score_tile_groups<R, W, DM>(feats, nfeat, kpad, ktile, lane, row_abs0, nr, lds, acc);
 }
 
 }  // namespace msc
