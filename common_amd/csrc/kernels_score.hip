@@ -4,8 +4,8 @@
 //   k_loo_own       per row: score of the row against its own group with the row removed
 //                   (remove_value then score_value), summed over features, in double
 //   k_score_nich1   one NICH feature, [nrows x K] scores, constants in VGPRs, streaming stores
-//   k_score_tile    any feature list; per-feature tables copied to LDS per workgroup by async
-//                   global_load_lds, double-buffered (score_block.hpp); scores summed over
+//   k_score_tile    any feature list; the tables of a host-planned group of features are copied to LDS by
+//                   global_load_lds, one barrier per group (score_block.hpp); scores summed over
 //                   features in registers, one store per row
 //   k_dm_prepare    the dim+1 exact count tables of a Dirichlet-Multinomial feature
 //   k_gp_large_fix  gp / bnb / dm counts beyond the exact tables, in double (gp: Loader's saddle-point form)
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
                                                                  const float *__restrict__ own,
                                                                  const float *__restrict__ crp,
                                                                  float *__restrict__ out, uint64_t ld) {
-  __shared__ float4 lds[2 * kLdsRows * 64];
+  __shared__ float4 lds[kGrpRows * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -306,9 +306,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
       if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
       else acc[r] = make_float4(0, 0, 0, 0);
     }
-    const uint64_t wg0 = chunk * rows_per_wg;
-    const uint32_t wgn = (uint32_t)((nrows - wg0) < rows_per_wg ? (nrows - wg0) : rows_per_wg);
-    score_tile<R, W, DM>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
                                                                  const float *__restrict__ own,
                                                                  const float *__restrict__ crp, uint64_t seed,
                                                                  uint64_t sweep) {
-  __shared__ float4 lds[2 * kLdsRows * 64];
+  __shared__ float4 lds[kGrpRows * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = lane * 4;            // single k-tile: K <= 256
   const float4 logcnt = ld4(crp + kb);
@@ -218,9 +218,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
     float4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    const uint64_t wg0 = chunk * rows_per_wg;
-    const uint32_t wgn = (uint32_t)((nrows - wg0) < rows_per_wg ? (nrows - wg0) : rows_per_wg);
-    score_tile<R, W, DM>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, row0 + wg0, wgn, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll

@@ -1,20 +1,19 @@
 // score_block.hpp -- the workgroup-tile scorer shared by the batched score kernel and the
 // fused sweep kernel.
 //
-// A workgroup owns a block of consecutive rows and one tile of groups.  Features are processed
-// one after the other: the feature's per-group table for the tile (bb: 2 rows, nich: 6
-// constants, dd: one row per category, gp: one row per count) is copied into LDS once per
-// workgroup with global_load_lds (double-buffered: the copy of feature f+1 runs under the
-// arithmetic of feature f), then every wave adds that feature's scores for its rows into
-// registers with conflict-free ds_read_b128 (lane <-> 4 groups of a 256-group tile, 1 KiB
-// table rows, 128 rows per workgroup).  Table bytes moved per evaluation are
-// table_rows * 4 B / rows_per_workgroup and the global->LDS path moves ~10 B/clk/CU, which is
-// what bounds a table-heavy state (config C3); a lane <-> 1 group tiling (512 rows per
-// workgroup, 4x fewer table bytes) was measured 2x slower: it triples the per-evaluation
-// instruction count of the lookups.
+// A workgroup owns a block of consecutive rows (128) and one tile of 256 groups.  The host packs
+// consecutive features into groups whose per-group tables for the tile (bb: 2 rows, nich: 6
+// constants, dd: one row per category, gp / bnb: one row per count) fit one 128 KiB LDS slot
+// together; the workgroup copies a group with global_load_lds, synchronises once, and every wave
+// then adds the group's features for its rows into registers on its own: conflict-free
+// ds_read_b128 (lane <-> 4 groups, 1 KiB table rows), runs of plain lookup features in a loop of
+// their own.  What bounds it is the instruction count per (row, feature), not the copies
+// (profiles/r01_c3_stage_costs.txt); a lane <-> 1 group tiling (512 rows per workgroup, 4x fewer
+// table bytes) was measured 2x slower for that reason.
 // Nothing in here evaluates a transcendental in double: leave-one-out terms arrive precomputed
-// per row (k_loo_own), gp counts beyond the table are patched afterwards (k_gp_large_fix).
-// Table rows beyond the 64 that fit an LDS buffer are gathered from L2.
+// per row (k_loo_own), counts beyond the tables are patched afterwards (k_gp_large_fix).
+// Table rows beyond the 64 a feature may stage are gathered from L2; Dirichlet-Multinomial tables
+// always are.
 #pragma once
 
 #include "family_math.hpp"
@@ -30,7 +29,6 @@ MSC_DEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kLdsRows = 64;                  // table rows staged per feature and buffer (64 KiB)
 
 // 16-byte global -> LDS copy that bypasses the VGPRs (global_load_lds_dwordx4): every lane
 // supplies its own source address, the destination is lds_wave_base + lane * 16.
@@ -317,19 +315,11 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
 // ---------------------------------------------------------------------------
 // acc[r] (+)= sum over features of score_value(row rb+r, groups kb..kb+3).
 // All W waves of the workgroup must call this together (it contains barriers); a wave whose
-// rows are out of range passes nr = 0.  lds: two buffers of kLdsRows * 64 float4.
-// Pipeline per stage s: issue the value load and the table copy of s+1 (buffer (s+1)&1),
-// compute s from buffer s&1, wait for the copies, one barrier.  The value load is issued
-// *before* the table copy because vmcnt retires in order.
+// rows are out of range passes nr = 0.  lds: the kGrpRows * 64 float4 slot.
 // ---------------------------------------------------------------------------
-// DM: the state holds a Dirichlet-Multinomial feature (their hi/lo accumulators cost 2 R float4 of
-// registers, so states without one run the kernel compiled without that branch).
 template <int R, int W, bool DM>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
-                        int lane, uint64_t row_abs0, int nr, uint64_t wg_row0, uint32_t wg_rows,
-                        float4 *__restrict__ lds, float4 (&acc)[R]) {
-  (void)wg_row0;
-  (void)wg_rows;
+                        int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
   score_tile_groups<R, W, DM>(feats, nfeat, kpad, ktile, lane, row_abs0, nr, lds, acc);
 }
 
