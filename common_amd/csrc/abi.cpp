@@ -298,8 +298,11 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
   }
 }
 
-// Pack consecutive features into groups whose table blocks fit the LDS slot of the tile kernels
-// (score_block.hpp, score_tile): greedy, at most kGrpRows rows per group.
+// The plan of the tile kernels (score_block.hpp).  They walk a reordered copy of the descriptors: first every
+// feature except the unmasked nich ones, in the caller's order, then the unmasked nich features, which get a phase
+// (and an inner loop) of their own.  (Float addition order follows this plan, not the caller's feature order.)
+// Consecutive features are packed into groups whose table blocks fit the LDS slot together: greedy, at most
+// kGrpRows rows per group, never across the two phases.
 static void plan_groups(msc_state *st) {
   auto rows_of = [](const FeatDesc &d) -> uint32_t {
     switch (d.family) {
@@ -312,32 +315,40 @@ static void plan_groups(msc_state *st) {
       default: return 0;
     }
   };
+  auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
+  std::vector<FeatDesc> &t = st->desc_tile_host;
+  t.clear();
+  for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
+  st->tile_split = (uint32_t)t.size();
+  for (const FeatDesc &d : st->desc_host) if (nich_tail(d)) t.push_back(d);
+  const uint32_t n = st->nfeat, split = st->tile_split;
   uint32_t f = 0;
-  while (f < st->nfeat) {
+  while (f < n) {
+    const uint32_t limit = f < split ? split : n;
     uint32_t used = 0, g = f;
-    while (g < st->nfeat && used + rows_of(st->desc_host[g]) <= (uint32_t)kGrpRows) {
-      st->desc_host[g].grp_off = used;
-      st->desc_host[g].grp_rows = rows_of(st->desc_host[g]);
-      used += rows_of(st->desc_host[g]);
+    while (g < limit && used + rows_of(t[g]) <= (uint32_t)kGrpRows) {
+      t[g].grp_off = used;
+      t[g].grp_rows = rows_of(t[g]);
+      used += rows_of(t[g]);
       g++;
     }
-    for (uint32_t i = f; i < g; i++) st->desc_host[i].grp_end = g;
+    for (uint32_t i = f; i < g; i++) t[i].grp_end = g;
     f = g;
   }
   // Unmasked lookup features whose whole table is staged (so that no row can miss it) take the tight inner
-  // loop of the tile kernel; run_end lets a wave stay in it for a whole run of them.
-  for (uint32_t i = 0; i < st->nfeat; i++) {
-    FeatDesc &d = st->desc_host[i];
+  // loop of the first phase; run_end lets a wave stay in it for a whole run of them.
+  for (uint32_t i = 0; i < n; i++) {
+    FeatDesc &d = t[i];
     d.kind = MSC_KIND_GENERIC;
     if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
     if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8;
     else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32;
     else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32;
   }
-  for (uint32_t i = st->nfeat; i-- > 0;) {
-    FeatDesc &d = st->desc_host[i];
+  for (uint32_t i = n; i-- > 0;) {
+    FeatDesc &d = t[i];
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
-    else d.run_end = (i + 1 < d.grp_end && st->desc_host[i + 1].kind != MSC_KIND_GENERIC) ? st->desc_host[i + 1].run_end : i + 1;
+    else d.run_end = (i + 1 < d.grp_end && t[i + 1].kind != MSC_KIND_GENERIC) ? t[i + 1].run_end : i + 1;
   }
 }
 
@@ -345,6 +356,9 @@ static int upload_desc(msc_state *st) {
   plan_groups(st);
   MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat,
                          hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipMemcpyAsync(st->desc_tile_dev, st->desc_tile_host.data(), sizeof(FeatDesc) * st->nfeat,
+                         hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(st->ctx->stream));     // (the tile copy is rebuilt by the next call)
   return MSC_OK;
 }
 
@@ -394,6 +408,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->cnt_u32, kpad))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->logpc, 2 * kpad + 4))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
     msc_feature_host &h = st->feats[f];
@@ -485,8 +500,7 @@ extern "C" int msc_state_set_hp(msc_state *st, uint32_t feature, const float *ho
     double asum = 0;
     for (float a : h.hp) asum += (double)a;
     st->desc_host[feature].aux = asum;
-    MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat, hipMemcpyHostToDevice, st->ctx->stream));
-    MSC_HIP(hipStreamSynchronize(st->ctx->stream));
+    MSC_TRY(upload_desc(st));
   }
   return MSC_OK;
 }
@@ -834,7 +848,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     bool has_dm = false;
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : MSC_PATH_TILE;
-    if (launch_score(s, st->ctx->num_cus, path, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
+    if (launch_score(s, st->ctx->num_cus, path, path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows,
                      z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
@@ -976,7 +990,7 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
     if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
     if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
-    else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
+    else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
   }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
 // ---------------------------------------------------------------------------
 template <int R, int W, bool LOO, bool CRP, bool DM>
 __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const FeatDesc *__restrict__ feats,
-                                                                 int nfeat, uint32_t K, uint32_t kpad,
+                                                                 int nfeat, int nsplit, uint32_t K, uint32_t kpad,
                                                                  uint64_t row0, uint64_t nrows,
                                                                  const int32_t *__restrict__ z,
                                                                  const float *__restrict__ own,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
       if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
       else acc[r] = make_float4(0, 0, 0, 0);
     }
-    score_tile<R, W, DM>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {
@@ -410,7 +410,7 @@ int tile_rows_per_wave() {
 
 template <bool LOO, bool CRP>
 static void launch_score_t(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev,
-                           int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                           int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (path == MSC_PATH_NICH1) {
@@ -439,26 +439,26 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Feat
     if (gx == 0) gx = 1;
     const dim3 grid((unsigned)gx, ktiles);
     if (path == MSC_PATH_TILE_DM)
-      hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (R == 16)
-      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else
-      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
   }
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)
-int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat,
+int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;
-  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (loo) launch_score_t<true, false>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (pri) launch_score_t<false, true>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else launch_score_t<false, false>(stream, num_cus, path, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (loo) launch_score_t<true, false>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (pri) launch_score_t<false, true>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else launch_score_t<false, false>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

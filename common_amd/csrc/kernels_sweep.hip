@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
 // any feature list, K <= 256: the workgroup tile of score_block.hpp, sampled from registers
 // ---------------------------------------------------------------------------
 template <int R, int W, bool DM>
-__global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const FeatDesc *__restrict__ feats, int nfeat,
+__global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                  uint32_t K, uint32_t kpad, uint64_t row0,
                                                                  uint64_t nrows, uint64_t row_id0,
                                                                  int32_t *__restrict__ z,
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
     float4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile<R, W, DM>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll
@@ -295,7 +295,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
   if (K > 256) return -2;
@@ -306,13 +306,13 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatD
   if (gx > cap) gx = cap;
   const dim3 grid((unsigned)(gx ? gx : 1));
   if (has_dm)
-    hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, seed, sweep);
   else if (R == 16)
-    hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, seed, sweep);
   else
-    hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, seed, sweep);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

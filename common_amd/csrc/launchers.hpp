@@ -34,7 +34,7 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);
 // which scoring kernel a state takes (abi.cpp decides from its feature list)
 enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2 };
-int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat,
+int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
 
@@ -42,7 +42,7 @@ int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feat
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep);
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, uint64_t seed, uint64_t sweep);
 int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,

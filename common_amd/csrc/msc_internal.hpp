@@ -250,6 +250,11 @@ struct msc_state {
   bool crp_valid = false;
   msc::FeatDesc *desc_dev = nullptr;
   std::vector<msc::FeatDesc> desc_host;
+  // the same descriptors in the order the tile kernels walk them (abi.cpp plan_groups): every feature but the
+  // unmasked nich ones, in the caller's order, then the unmasked nich features (from index tile_split on)
+  msc::FeatDesc *desc_tile_dev = nullptr;
+  std::vector<msc::FeatDesc> desc_tile_host;
+  uint32_t tile_split = 0;
   const msc_dataview *bound_view = nullptr;
   uint64_t bound_serial = 0;
   std::vector<uint32_t> bound_cols;

@@ -240,6 +240,51 @@ MSC_DEV void score_dm_feature(const FeatDesc &fd, uint32_t kpad, uint32_t kb, in
 // apart, so one wave's load latency sits under another's arithmetic; per (feature, 128-row chunk)
 // this costs ~1000 cycles where a barrier per feature cost ~2500 (profiles/r01_c3_stage_costs.txt).
 // ---------------------------------------------------------------------------
+// copy the table blocks of the feature group [f0, f1) into the slot and wait for them (two barriers)
+template <int W>
+MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uint32_t kpad, uint32_t ktile, int lane,
+                         int wave, float4 *__restrict__ lds) {
+  __syncthreads();                                      // the slot's previous readers are done
+  for (int f = f0; f < f1; f++) {
+    const FeatDesc &fd = feats[f];
+    const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
+    const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
+    float4 *dst = lds + (size_t)fd.grp_off * 64;
+    for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)     // one 1 KiB table row per wave instruction
+      glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the group's tables has landed
+  __syncthreads();                                      // ... everyone's
+}
+
+// second phase: the unmasked nich features (the host puts them last, abi.cpp plan_groups), group by group,
+// in a loop that holds nothing else
+template <int R, int W>
+MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t ktile,
+                                  int lane, int wave, uint64_t myrow, bool has_row, float4 *__restrict__ lds,
+                                  float4 (&acc)[R]) {
+  while (f0 < nfeat) {
+    const int f1 = (int)feats[f0].grp_end;
+    stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
+    for (int f = f0; f < f1; f++) {
+      const FeatDesc &fd = feats[f];
+      const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
+      const float xv = has_row ? reinterpret_cast<const float *>(fd.col)[myrow] : 0.f;
+      const float4 mh = buf[NICH_MU_HI * 64], ml = buf[NICH_MU_LO * 64], c0 = buf[NICH_C0 * 64],
+                   c1l = buf[NICH_C1LN2 * 64], c1 = buf[NICH_C1 * 64], c2 = buf[NICH_C2 * 64];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const float x = lane_bcast(xv, r);
+        acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+        acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+        acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+        acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+      }
+    }
+    f0 = f1;
+  }
+}
+
 template <int R, int W, bool DM>
 MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                                int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
@@ -250,17 +295,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
   int f0 = 0;
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].grp_end;
-    __syncthreads();                                    // the slot's previous readers are done
-    for (int f = f0; f < f1; f++) {
-      const FeatDesc &fd = feats[f];
-      const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
-      const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
-      float4 *dst = lds + (size_t)fd.grp_off * 64;
-      for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)   // one 1 KiB table row per wave instruction
-        glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my share of the group's tables has landed
-    __syncthreads();                                    // ... everyone's
+    stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
     int f = f0;
     while (f < f1) {
       // A run of unmasked lookup features (bb, gp, bnb, dd with their whole table staged; the host marks them
@@ -318,9 +353,13 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
 // rows are out of range passes nr = 0.  lds: the kGrpRows * 64 float4 slot.
 // ---------------------------------------------------------------------------
 template <int R, int W, bool DM>
-MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
+MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nsplit, uint32_t kpad, uint32_t ktile,
                         int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
-  score_tile_groups<R, W, DM>(feats, nfeat, kpad, ktile, lane, row_abs0, nr, lds, acc);
+  score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, lds, acc);
+  if (nsplit < nfeat) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
+  }
 }
 
 }  // namespace msc
