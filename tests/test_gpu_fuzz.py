@@ -1,0 +1,117 @@
+"""GPU: seeded random feature lists against the oracle.  The tile kernels walk a host-made plan (feature groups
+sharing the LDS slot, runs of lookup features, a nich tail phase, masked features on the generic path, tables
+larger than a feature may stage); random mixtures of families, dimensions, masks, group counts and row counts
+exercise the planner's corner cases, which hand-picked cases tend to miss."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.gpu_helpers import TOL, crp_prior_matrix, load_state, make_feature, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FAMS = [orc.BB, orc.BBNC, orc.GP, orc.BNB, orc.DD, orc.NICH, orc.NIW, orc.DM]
+
+
+def _random_spec(rng):
+    nf = int(rng.integers(1, 24))
+    spec = []
+    for _ in range(nf):
+        fam = FAMS[int(rng.integers(0, len(FAMS)))]
+        if fam == orc.NIW and rng.random() < 0.7:
+            fam = orc.NICH                                   # keep niw rare (it owns a separate kernel)
+        dim = 0
+        if fam == orc.DD:
+            dim = int(rng.choice([2, 3, 17, 64, 65, 100, 128]))   # 65+: more categories than a feature may stage
+        elif fam == orc.NIW:
+            dim = int(rng.integers(1, 6))
+        elif fam == orc.DM:
+            dim = int(rng.integers(2, 9))
+        spec.append((fam, dim))
+    return spec
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MSC_FUZZ_SEEDS", "32"))))
+def test_random_feature_lists_match_the_oracle(gpu_ctx, seed):
+    import common_amd
+    rng = np.random.default_rng(1000 + seed)
+    spec = _random_spec(rng)
+    N = int(rng.choice([1, 5, 64, 127, 129, 300, 777]))
+    K = int(rng.choice([1, 3, 16, 255, 256, 257, 300]))
+    feats = [make_feature(f, N, K, rng, d) for f, d in spec]
+    if rng.random() < 0.3:                                       # gp counts beyond what a feature stages / tables hold
+        for f in feats:
+            if f["family"] == orc.GP and N > 2:
+                f["values"][rng.integers(0, N, 2)] += np.uint32(rng.choice([70, 2000]))
+    z = rng.integers(0, K, N).astype(np.int32)
+    # masks on a random subset of the features
+    masked = [rng.random() < 0.25 for _ in feats]
+    dt = np.dtype([("f%d" % i, f["np_dtype"]) for i, f in enumerate(feats)])
+    data = np.zeros(N, dtype=dt)
+    mask = np.zeros(N, dtype=[("f%d" % i, np.bool_, np.dtype(f["np_dtype"]).shape) for i, f in enumerate(feats)])
+    rowmask = []
+    for i, f in enumerate(feats):
+        data["f%d" % i] = f["values"]
+        m = (rng.random(N) < 0.3) if masked[i] else np.zeros(N, dtype=bool)
+        rowmask.append(m)
+        mask["f%d" % i] = m if np.dtype(f["np_dtype"]).shape == () else np.repeat(m[:, None], f["dim"], 1)
+    arr = np.ma.masked_array(data, mask=mask) if any(masked) else data
+    view = common_amd.DataView.from_recarray(gpu_ctx, arr)
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    # suff-stats the oracle's way (a masked row is not part of the feature's groups)
+    fs, total, total_loo = [], None, None
+    for f, m in zip(feats, rowmask):
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        init = None
+        if f["family"] == orc.BBNC:
+            init = np.zeros(K, dtype=orc.ss_dtype(orc.BBNC, 0, "f64"))
+            init["p"] = np.random.default_rng(K).uniform(0.05, 0.95, K).astype(np.float32)
+        zz = np.where(m, -1, z).astype(np.int32)
+        ss64 = F.accumulate(K, f["values"], zz, ss_init=init)
+        ss32 = orc.narrow_ss(f["family"], ss64, f["dim"])
+        ss64 = orc.widen_ss(f["family"], ss32, f["dim"])
+        fs.append((F, ss64, ss32))
+        a = F.score_matrix(ss64, f["values"])
+        b = F.score_matrix(ss64, f["values"], zz)
+        a[m] = 0.0
+        b[m] = 0.0
+        total = a if total is None else total + a
+        total_loo = b if total_loo is None else total_loo + b
+    load_state(st, fs)
+    cnt = np.bincount(z, minlength=K).astype(np.uint32)
+    st.set_group_counts(cnt)
+    tol = TOL * (4 if any(f["family"] == orc.NIW for f in feats) else 1) * max(1, len(feats) // 8)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, total).max() <= tol, (seed, spec, N, K)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.set_alpha(1.7)
+    both = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    want = total_loo + crp_prior_matrix(cnt, 1.7, z)
+    assert rel_err(both, want).max() <= tol, (seed, spec, N, K)
+    # and the integer suff-stats of a device-side accumulate
+    st2 = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, (F, _, ss32) in enumerate(fs):
+        st2.set_hp(i, F.hp)
+        if F.family == orc.BBNC:
+            e = np.zeros(K, dtype=common_amd.ss_dtype(orc.BBNC))
+            e["p"] = ss32["p"]
+            st2.set_ss(i, e)
+    st2.accumulate(view, zt)
+    for i, (F, _, ss32) in enumerate(fs):
+        rec = st2.get_ss(i)
+        for name in rec.dtype.names:
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(rec[name], ss32[name]), (seed, i, name)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MSC_FUZZ_SWEEP_SEEDS", "12"))))
+def test_random_sweeps_draw_the_oracles_assignments(gpu_ctx, seed):
+    """fused tile sweep (K <= 256), fused nich sweep, and the materialising path (K > 256, niw), unmasked"""
+    from tests.test_gpu_sweep import _check_agreement, _run
+    rng = np.random.default_rng(5000 + seed)
+    spec = _random_spec(rng)
+    N = int(rng.choice([64, 300, 1000]))
+    K = int(rng.choice([2, 17, 256, 300]))
+    got, want, scores, _ = _run(gpu_ctx, spec, N, K, seed=300 + seed, sweep_idx=seed % 5, alpha=0.9, empty=min(2, K - 1))
+    _check_agreement(got, want, scores, 300 + seed, seed % 5, 0.98)
