@@ -420,6 +420,8 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
                                             : (size_t)raw_f32_rows(h.family) * kpad;
     if ((rc = dev_alloc(st->owned, &h.raw_f32, nf32))) return bail(rc);
     if (loo_rows(h.family) && (rc = dev_alloc(st->owned, &h.loo64, (size_t)loo_rows(h.family) * kpad))) return bail(rc);
+    if (loo_tab_rows(h.family, h.dim) &&
+        (rc = dev_alloc(st->owned, &h.loo_tab, (size_t)loo_tab_rows(h.family, h.dim) * kpad))) return bail(rc);
     if (h.family == MSC_DM) {
       if ((rc = dev_alloc(st->owned, &h.dm_meta_dev, 2 * ((size_t)h.dim + 1)))) return bail(rc);
       h.dm_meta.assign(2 * ((size_t)h.dim + 1), 0u);
@@ -457,6 +459,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
     d.vcap = 32;
     d.dm_meta = nullptr;       // set when a column is bound
     d.loo64 = h.loo64;
+    d.loo_tab = h.loo_tab;
     d.aux = 0.0;
     for (float a : h.hp) d.aux += h.family == MSC_DD || h.family == MSC_DM ? (double)a : 0.0;
   }

@@ -344,17 +344,11 @@ MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, flo
   const double dd = x - mun;
   return t[NLOO_C0G * stride] - 0.5 * log(sig) - t[NLOO_C1 * stride] * log1p(t[NLOO_K2G * stride] * dd * dd / sig);
 }
-// gp: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
-//   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b'),  the two logs per group
-enum { GLOO_LB = 0, GLOO_L1B, GLOO_ROWS };
-MSC_DEV void gp_loo_prepare(const float *hp, uint32_t count, double *out, size_t stride) {
-  const double b1 = (double)hp[1] + (double)count - 1.0;
-  out[GLOO_LB * stride] = log(b1);
-  out[GLOO_L1B * stride] = log1p(b1);
-}
-MSC_DEV double gp_loo_tab(const float *hp, const double *t, size_t stride, uint32_t sum, uint32_t v) {
-  const double a = (double)hp[0] + (double)sum;
-  return lgamma_drop(a, v) - log_factorial(v) + (a - (double)v) * t[GLOO_LB * stride] - a * t[GLOO_L1B * stride];
+// gp leave-one-out: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
+//   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b')
+MSC_DEV double gp_loo(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {
+  const double a = (double)hp[0] + (double)sum, b1 = (double)hp[1] + (double)count - 1.0;
+  return lgamma_drop(a, v) - log_factorial(v) + (a - (double)v) * log(b1) - a * log1p(b1);
 }
 MSC_DEV double nich_score_data(const float *hp, uint32_t count, float mean, float ctv) {
   const NichPost p = nich_posterior(hp, (double)count, (double)mean, (double)ctv);

@@ -37,6 +37,11 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       bb_prepare(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], s0, s1);
       fd.tab[k] = s0;
       fd.tab[kpad + k] = s1;
+      if (fd.loo_tab != nullptr) {          // (an entry is only read for a row that is in the group with that value)
+        const uint32_t h = fd.raw_u32[k], t = fd.raw_u32[kpad + k];
+        fd.loo_tab[k] = t ? (float)bb_loo(fd.hp, h, t, false) : 0.f;
+        fd.loo_tab[kpad + k] = h ? (float)bb_loo(fd.hp, h, t, true) : 0.f;
+      }
     } break;
     case MSC_BBNC: {
       float s0, s1;
@@ -49,18 +54,28 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
       gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
       for (uint32_t v = 0; v < fd.vcap; v++)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
-      if (fd.loo64 != nullptr) gp_loo_prepare(fd.hp, cnt, fd.loo64 + k, kpad);
+      if (fd.loo_tab != nullptr)
+        for (uint32_t v = 0; v < fd.vcap; v++)
+          fd.loo_tab[(size_t)v * kpad + k] = (cnt >= 1 && sum >= v) ? (float)gp_loo(fd.hp, cnt, sum, v) : 0.f;
     } break;
     case MSC_BNB: {
       const double cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
       for (uint32_t v = 0; v < fd.vcap; v++)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = (float)bnb_score(fd.hp, cnt, sum, (double)v);
+      if (fd.loo_tab != nullptr)
+        for (uint32_t v = 0; v < fd.vcap; v++)
+          fd.loo_tab[(size_t)v * kpad + k] = (cnt >= 1.0 && sum >= (double)v) ? (float)bnb_score(fd.hp, cnt - 1.0, sum - (double)v, (double)v) : 0.f;
     } break;
     case MSC_DD: {
       const uint32_t csum = fd.raw_u32[k];
       for (uint32_t i = 0; i < fd.dim; i++)
         fd.tab[(size_t)i * kpad + k] =
             dd_prepare_entry(fd.hp[i], fd.raw_u32[(size_t)(1 + i) * kpad + k], fd.aux, csum);
+      if (fd.loo_tab != nullptr)
+        for (uint32_t i = 0; i < fd.dim; i++) {
+          const uint32_t c = fd.raw_u32[(size_t)(1 + i) * kpad + k];
+          fd.loo_tab[(size_t)i * kpad + k] = c ? (float)dd_loo(fd.hp[i], c, fd.aux, csum) : 0.f;
+        }
     } break;
     case MSC_NICH: {
       float o[NICH_ROWS];
@@ -142,20 +157,21 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
     const FeatDesc fd = feats[f];
     if (fd.family != MSC_NIW && load_masked(fd, row, true)) continue;
     switch (fd.family) {
-      case MSC_BB:
-        s += bb_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], reinterpret_cast<const uint8_t *>(fd.col)[row] != 0);
+      case MSC_BB:       // lookup families: the table k_prepare made of "this value against the group minus one of it"
+        s += (double)fd.loo_tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
         break;
       case MSC_BBNC:     // p does not move when a row leaves
         s += log(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? (double)fd.raw_f32[g] : 1.0 - (double)fd.raw_f32[g]);
         break;
-      case MSC_GP:
-        s += gp_loo_tab(fd.hp, fd.loo64 + g, kpad, fd.raw_u32[kpad + g], reinterpret_cast<const uint32_t *>(fd.col)[row]);
-        break;
-      case MSC_BNB:
-        s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0,
-                       (double)fd.raw_u32[kpad + g] - (double)reinterpret_cast<const uint32_t *>(fd.col)[row],
-                       (double)reinterpret_cast<const uint32_t *>(fd.col)[row]);
-        break;
+      case MSC_GP: {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+        s += v < fd.vcap ? (double)fd.loo_tab[(size_t)v * kpad + g] : gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], v);
+      } break;
+      case MSC_BNB: {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+        s += v < fd.vcap ? (double)fd.loo_tab[(size_t)v * kpad + g]
+                         : bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
+      } break;
       case MSC_DM:
         s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad,
                              reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim, true);
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
       case MSC_DD: {
         int v = reinterpret_cast<const int32_t *>(fd.col)[row];
         v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
-        s += dd_loo(fd.hp[v], fd.raw_u32[(size_t)(1 + v) * kpad + g], fd.aux, fd.raw_u32[g]);
+        s += (double)fd.loo_tab[(size_t)v * kpad + g];
       } break;
       case MSC_NICH:
         s += nich_loo_tab(fd.hp, fd.loo64 + g, kpad, fd.raw_f32[g], fd.raw_f32[kpad + g],

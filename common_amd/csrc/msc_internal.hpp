@@ -107,7 +107,9 @@ struct FeatDesc {
   uint32_t run_end;           // lookup kinds: one past the last feature of the run of lookup features this one
                               // belongs to (within its group); generic: its own index
   uint32_t pad3;
-  double *loo64;              // nich, gp: per-group constants of the leave-one-out pass, [loo_rows][kpad] (family_math.hpp)
+  double *loo64;              // nich: per-group constants of the leave-one-out pass, [loo_rows][kpad] (family_math.hpp)
+  float *loo_tab;             // bb, gp, bnb, dd: score of value v against the group with one such value removed,
+                              // [v][kpad] (k_prepare); the leave-one-out pass is a lookup for these families
 };
 enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 
@@ -127,7 +129,10 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
     default: return 0;
   }
 }
-inline uint32_t loo_rows(int family) { return family == MSC_NICH ? 11u : family == MSC_GP ? 2u : 0u; }
+inline uint32_t loo_rows(int family) { return family == MSC_NICH ? 11u : 0u; }
+inline uint32_t loo_tab_rows(int family, uint32_t dim) {
+  return family == MSC_BB ? 2u : (family == MSC_GP || family == MSC_BNB) ? kGpMaxTable : family == MSC_DD ? dim : 0u;
+}
 inline uint32_t raw_u32_rows(int family, uint32_t dim) {
   switch (family) {
     case MSC_BB: return 2;
@@ -223,7 +228,8 @@ struct msc_feature_host {
   uint32_t *raw_u32 = nullptr;
   float *raw_f32 = nullptr;
   float *niw_raw = nullptr;     // [K][d + d*d] float
-  double *loo64 = nullptr;      // nich, gp: leave-one-out constants
+  double *loo64 = nullptr;      // nich: leave-one-out constants
+  float *loo_tab = nullptr;     // bb, gp, bnb, dd: leave-one-out tables
   float *niw_w = nullptr, *niw_b = nullptr;
   double *niw_w64 = nullptr, *niw_mu64 = nullptr, *niw_c64 = nullptr;
   size_t i64_off = 0, i64_len = 0;   // slices of the state's reduce buffers (elements)
