@@ -998,7 +998,11 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;
-    uint64_t chunk = (64ull << 20) / (ld * sizeof(float));   // 64 MiB of scores stays in the Infinity Cache
+    // 64 MiB of scores stays in the Infinity Cache between the two kernels; a state with niw features is bound
+    // by its MFMA kernel instead, which wants >= 4 waves per SIMD: 256k rows per launch
+    bool has_niw = false;
+    for (auto &h : st->feats) has_niw |= h.family == MSC_NIW;
+    uint64_t chunk = ((has_niw ? 256ull : 64ull) << 20) / (ld * sizeof(float));
     if (chunk == 0) chunk = 1;
     if (chunk > nrows) chunk = nrows;
     if (st->scratch_floats < chunk * ld) {

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
             const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
             atomicAdd(&u32[g], 1u);
             atomicAdd(&u64[g], (unsigned long long)v);
-            atomicAdd(&f64[g], lgamma((double)v + 1.0));
+            atomicAdd(&f64[g], log_factorial(v));        // ln Gamma(v + 1)
           } break;
           case MSC_BNB: {
             const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
