@@ -76,15 +76,9 @@ MSC_DEV double lgamma_drop(double a, uint32_t v) {
   }
   return lgamma_pos(a) - lgamma_pos(a - (double)v);
 }
-// log(v!)
-MSC_DEV double log_factorial(uint32_t v) {
-  if (v <= 12u) {
-    double prod = 1.0;
-    for (uint32_t i = 2; i <= v; i++) prod *= (double)i;
-    return log(prod);
-  }
-  return lgamma_pos((double)v + 1.0);
-}
+// log(v!): a table for the counts that occur, Stirling beyond
+__device__ const double kLogFactorial[32] = {0, 0, 0.69314718055994495, 1.7917594692280554, 3.1780538303479449, 4.7874917427820467, 6.5792512120101021, 8.5251613610654147, 10.604602902745249, 12.801827480081467, 15.104412573075514, 17.502307845873887, 19.987214495661885, 22.552163853123421, 25.191221182738683, 27.89927138384089, 30.671860106080672, 33.505073450136891, 36.395445208033053, 39.339884187199495, 42.335616460753485, 45.380138898476908, 48.47118135183522, 51.606675567764377, 54.784729398112319, 58.003605222980518, 61.261701761002008, 64.557538627006338, 67.889743137181526, 71.257038967168, 74.658236348830172, 78.092223553315307};
+MSC_DEV double log_factorial(uint32_t v) { return v < 32u ? kLogFactorial[v] : lgamma_pos((double)v + 1.0); }
 
 MSC_DEV void split_hi_lo(double v, float &hi, float &lo) {
   hi = (float)v;
