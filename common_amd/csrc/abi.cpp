@@ -989,9 +989,11 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
   }
   int rc = -2;
   if (fused_ok && (nich1 ? st->K <= 1024 : st->K <= 256)) {
-    MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
-      return fail(MSC_EHIP, "k_loo_own launch failed");
+    if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
+      MSC_TRY(ensure_own(st, nrows));
+      if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+        return fail(MSC_EHIP, "k_loo_own launch failed");
+    }
     if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
     else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
   }

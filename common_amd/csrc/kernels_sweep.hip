@@ -154,8 +154,15 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
         __builtin_amdgcn_ballot_w64(fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0);
     float sloo = 0.f, erow = le0;
     if (gz >= 0) {
-      erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
-      sloo = own[rb + lane] * kLog2e;      // leave-one-out score + prior of the own group (k_loo_own)
+      // leave-one-out score + prior of the row's own group, in double (what k_loo_own does for the other
+      // kernels; here every lane has a row of its own, so it costs ~2 % on top of the 64 x K evaluations)
+      const float lm1 = crp[kpad + gz];
+      const bool empties = __builtin_isinf(lm1);              // the row is its group's only member
+      erow = empties ? le1 : le0;
+      double s = empties ? (double)le1 : (double)lm1;
+      if (!((mbits >> lane) & 1ull))
+        s += nich_loo_tab(fd.hp, fd.loo64 + gz, kpad, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
+      sloo = (float)s * kLog2e;
     }
     int znew = gz;
     for (int r = 0; r < nr; r++) {
