@@ -430,14 +430,16 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Feat
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (path == MSC_PATH_NICH1) {
-    // One 4-row quad per wave and non-temporal stores measured best on C2 and on the C5 shard
-    // (profiles/r01_nich1_variants.txt, second table): 5.8-6.0 TB/s vs 5.4-5.6 for 32-row chunks per wave.
-    // A wave only loops when the grid would otherwise exceed the launch limit.
+    // Two 4-row quads per wave (the second one half the matrix further on) and non-temporal stores: the best
+    // choice that is good on every box measured (profiles/r01_nich1_variants.txt, third table).  How many
+    // quads a wave takes decides how many write fronts sweep the matrix at once, and which count is best
+    // depends on the box (1 quad: 5.7-6.0 TB/s everywhere; 2: 5.5-6.4; 4: 5.3 on one box, 6.6 on another).
     constexpr int kQuad = 4;
     const uint64_t nquads = (nrows + kQuad - 1) / kQuad;
     const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
-    const uint64_t iters = (nquads + max_slots - 1) / max_slots;
-    uint64_t nslots = iters ? (nquads + iters - 1) / iters : 1;
+    uint64_t iters = (nquads + max_slots - 1) / max_slots;
+    if (iters < 2) iters = 2;
+    uint64_t nslots = (nquads + iters - 1) / iters;
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
     hipLaunchKernelGGL((k_score_nich1<LOO, CRP, kQuad, true>), dim3((unsigned)gx), dim3(256), 0, stream,
