@@ -425,7 +425,7 @@ int tile_rows_per_wave() {
 }
 
 template <bool LOO, bool CRP>
-static void launch_score_t(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev,
+static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_quads, const FeatDesc *feats_dev,
                            int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
@@ -438,7 +438,8 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Feat
     const uint64_t nquads = (nrows + kQuad - 1) / kQuad;
     const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
     uint64_t iters = (nquads + max_slots - 1) / max_slots;
-    if (iters < 2) iters = 2;
+    const uint64_t want = nich1_quads > 0 ? (uint64_t)nich1_quads : 2;      // (abi.cpp tunes it per box at first use)
+    if (iters < want) iters = want;
     uint64_t nslots = (nquads + iters - 1) / iters;
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
@@ -469,14 +470,14 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Feat
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)
-int launch_score(hipStream_t stream, int num_cus, int path, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_score(hipStream_t stream, int num_cus, int path, int nich1_quads, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;
-  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (loo) launch_score_t<true, false>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (pri) launch_score_t<false, true>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else launch_score_t<false, false>(stream, num_cus, path, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (loo) launch_score_t<true, false>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (pri) launch_score_t<false, true>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else launch_score_t<false, false>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
