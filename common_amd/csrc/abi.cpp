@@ -852,40 +852,43 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
-    auto launch = [&](int quads) {
-      return launch_score(s, st->ctx->num_cus, path, quads, descs, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
+    auto launch = [&](int shape) {
+      return launch_score(s, st->ctx->num_cus, path, shape, descs, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
                           nrows, z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out);
     };
-    // The single-nich pass is bound by the HBM write stream, and how many write fronts (quads per wave) suit it
-    // differs from box to box by more than 10 % (profiles/r01_nich1_variants.txt).  Settle it on this box the
-    // first time a pass is large enough to time: eight shapes, six launches each (~10 ms once), timed on the caller's own
-    // buffers (every run writes the same values; the best shape also depends on where the buffer landed).
-    if (path == MSC_PATH_NICH1 && st->ctx->nich1_quads == 0 && nrows * (uint64_t)st->K >= (64ull << 20)) {
-      static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_QUADS"); return e ? std::atoi(e) : 0; }();
-      if (fixed > 0) st->ctx->nich1_quads = fixed;
+    // The single-nich pass is bound by the HBM write stream, and which launch shape (rows per visit, visits per
+    // wave = write fronts) suits it differs by up to 20 % from box to box and with where the score buffer landed
+    // (profiles/r01_nich1_variants.txt).  Settle it the first time a context sees a pass large enough to time:
+    // every shape of kNich1Shapes, six launches each on the caller's own buffers (~10 ms once; every run writes
+    // the same values).  MSC_NICH1_SHAPE fixes it.
+    int shape = st->ctx->nich1_shape;
+    if (path == MSC_PATH_NICH1 && shape < 0 && nrows * (uint64_t)st->K >= (64ull << 20)) {
+      static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_SHAPE"); return e ? std::atoi(e) : -1; }();
+      if (fixed >= 0 && fixed < kNich1NumShapes) shape = fixed;
       else {
         hipEvent_t e0, e1;
         MSC_HIP(hipEventCreate(&e0));
         MSC_HIP(hipEventCreate(&e1));
         float best = 0.f;
-        for (int quads : {1, 2, 3, 4, 5, 6, 8, 12}) {
-          if (launch(quads)) return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        for (int cand = 0; cand < kNich1NumShapes; cand++) {
+          if (launch(cand)) return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
           MSC_HIP(hipEventRecord(e0, s));
-          for (int r = 0; r < 6; r++) (void)launch(quads);
+          for (int r = 0; r < 6; r++) (void)launch(cand);
           MSC_HIP(hipEventRecord(e1, s));
           MSC_HIP(hipEventSynchronize(e1));
           float ms = 0.f;
           MSC_HIP(hipEventElapsedTime(&ms, e0, e1));
-          if (st->ctx->nich1_quads == 0 || ms < best) {
+          if (shape < 0 || ms < best) {
             best = ms;
-            st->ctx->nich1_quads = quads;
+            shape = cand;
           }
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
       }
+      st->ctx->nich1_shape = shape;
     }
-    if (launch(st->ctx->nich1_quads))
+    if (launch(shape < 0 ? 0 : shape))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
     for (uint32_t f = 0; f < st->nfeat; f++)

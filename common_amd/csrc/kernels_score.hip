@@ -229,31 +229,40 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const bool tile_full = (kt + 1) * kGroupTile <= K;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
-  for (uint64_t rb = slot * Q; rb < nrows; rb += nslots * Q) {
+  // everything the wave's rows need, fetched at once: lane i holds row r = i % Q of visit k = i / Q
+  const uint32_t nvis = (uint32_t)(((nrows + Q - 1) / Q + nslots - 1) / nslots);      // <= 64 / Q (launcher)
+  const uint32_t vk = (uint32_t)lane / Q, vr = (uint32_t)lane % Q;
+  const uint64_t myrow = (slot + (uint64_t)vk * nslots) * Q + vr;
+  const bool mine = vk < nvis && myrow < nrows;
+  const float xv = mine ? xcol[myrow] : 0.0f;
+  const unsigned long long mbits_all =
+      __builtin_amdgcn_ballot_w64(fd.mask != nullptr && mine && fd.mask[row0 + myrow] != 0);
+  int gz = -1;
+  float sloo = 0, erow = le0;
+  if (LOO && mine) {
+    gz = z[myrow];
+    sloo = own[myrow];
+    if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+  }
+  for (uint32_t k = 0; k < nvis; k++) {
+    const uint64_t rb = (slot + (uint64_t)k * nslots) * Q;
+    if (rb >= nrows) break;
     const int nr = (int)((nrows - rb) < (uint64_t)Q ? (nrows - rb) : (uint64_t)Q);
-    const float xv = lane < nr ? xcol[rb + lane] : 0.0f;
-    const unsigned long long mbits =
-        __builtin_amdgcn_ballot_w64(fd.mask != nullptr && lane < nr && fd.mask[row0 + rb + lane] != 0);
-    int gz = -1;
-    float sloo = 0, erow = le0;
-    if (LOO && lane < nr) {
-      gz = z[rb + lane];
-      sloo = own[rb + lane];
-      if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
-    }
+    const int l0 = (int)(k * Q);                              // first lane of this visit's values
+    const unsigned long long mbits = (mbits_all >> l0) & ((1ull << Q) - 1ull);
     if (nr == Q && mbits == 0ull && vec_ok && tile_full) {     // straight-line: no per-row branches
 #pragma unroll
       for (int r = 0; r < Q; r++) {
-        const float x = lane_bcast(xv, r);
+        const float x = lane_bcast(xv, l0 + r);
         float4 s;
         s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
         s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
         s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
         s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
+        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
         if (LOO) {
-          const int g = lane_bcast(gz, r);
-          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
+          const int g = lane_bcast(gz, l0 + r);
+          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, l0 + r));
         }
         const f32x4 v = {s.x, s.y, s.z, s.w};
         f32x4 *p = reinterpret_cast<f32x4 *>(out + (rb + r) * ld + kb);
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
       }
     } else {
       for (int r = 0; r < nr; r++) {
-        const float x = lane_bcast(xv, r);
+        const float x = lane_bcast(xv, l0 + r);
         float4 s = make_float4(0, 0, 0, 0);
         if (!((mbits >> r) & 1ull)) {
           s.x = nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
@@ -270,10 +279,10 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
           s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
           s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
         }
-        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0));
+        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
         if (LOO) {
-          const int g = lane_bcast(gz, r);
-          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
+          const int g = lane_bcast(gz, l0 + r);
+          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, l0 + r));
         }
         store_row<NT>(out, ld, rb + r, kb, K, s, vec_ok);
       }
@@ -424,26 +433,30 @@ int tile_rows_per_wave() {
   return r;
 }
 
+// (blocks of one row, like a memset's, lose in this kernel although they win as a bare fill: a wave that visits only a few
+// rows does not pay for loading the group constants, and with many visits the fronts are too many)
+const Nich1Shape kNich1Shapes[kNich1NumShapes] = {{4, 2}, {4, 1}, {4, 4}, {4, 6}, {4, 3}, {4, 8}, {4, 5}, {4, 12}};
+
 template <bool LOO, bool CRP>
-static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_quads, const FeatDesc *feats_dev,
+static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_shape, const FeatDesc *feats_dev,
                            int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
   if (path == MSC_PATH_NICH1) {
-    // Two 4-row quads per wave (the second one half the matrix further on) and non-temporal stores: the best
-    // choice that is good on every box measured (profiles/r01_nich1_variants.txt, third table).  How many
-    // quads a wave takes decides how many write fronts sweep the matrix at once, and which count is best
-    // depends on the box (1 quad: 5.7-6.0 TB/s everywhere; 2: 5.5-6.4; 4: 5.3 on one box, 6.6 on another).
-    constexpr int kQuad = 4;
-    const uint64_t nquads = (nrows + kQuad - 1) / kQuad;
+    // A wave visits `visits` blocks of Q consecutive rows, nslots * Q rows apart; waves are numbered
+    // tile-fastest, so the waves resident at one moment write `visits` dense fronts that sweep the matrix.
+    // Which (Q, visits) suits the HBM write stream depends on the box and on where the score buffer landed
+    // (profiles/r01_nich1_variants.txt); abi.cpp run_score times the shapes of kNich1Shapes at the first large
+    // pass of a context and passes the winner's index here (0 = the default).
+    const Nich1Shape sh = kNich1Shapes[nich1_shape >= 0 && nich1_shape < kNich1NumShapes ? nich1_shape : 0];
+    const uint64_t nvisits_all = (nrows + sh.q - 1) / sh.q;
     const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
-    uint64_t iters = (nquads + max_slots - 1) / max_slots;
-    const uint64_t want = nich1_quads > 0 ? (uint64_t)nich1_quads : 2;      // (abi.cpp tunes it per box at first use)
-    if (iters < want) iters = want;
-    uint64_t nslots = (nquads + iters - 1) / iters;
+    uint64_t visits = sh.visits;
+    while ((nvisits_all + visits - 1) / visits > max_slots && visits * sh.q < 64) visits++;
+    uint64_t nslots = (nvisits_all + visits - 1) / visits;
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
-    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, kQuad, true>), dim3((unsigned)gx), dim3(256), 0, stream,
+    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), dim3((unsigned)gx), dim3(256), 0, stream,
                        feats_dev, K, kpad, row0, nrows, nslots, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
@@ -470,14 +483,14 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)
-int launch_score(hipStream_t stream, int num_cus, int path, int nich1_quads, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_score(hipStream_t stream, int num_cus, int path, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;
-  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (loo) launch_score_t<true, false>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else if (pri) launch_score_t<false, true>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
-  else launch_score_t<false, false>(stream, num_cus, path, nich1_quads, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  if (loo && pri) launch_score_t<true, true>(stream, num_cus, path, nich1_shape, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (loo) launch_score_t<true, false>(stream, num_cus, path, nich1_shape, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else if (pri) launch_score_t<false, true>(stream, num_cus, path, nich1_shape, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+  else launch_score_t<false, false>(stream, num_cus, path, nich1_shape, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

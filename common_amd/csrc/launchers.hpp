@@ -34,8 +34,11 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);
 // which scoring kernel a state takes (abi.cpp decides from its feature list)
 enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2 };
-// nich1_quads: 4-row quads per wave of k_score_nich1 (0 = default)
-int launch_score(hipStream_t stream, int num_cus, int path, int nich1_quads, const FeatDesc *feats_dev, int nfeat, int nsplit,
+// k_score_nich1 launch shapes: a wave visits `visits` blocks of q consecutive rows (index 0 = the default)
+struct Nich1Shape { int q, visits; };
+constexpr int kNich1NumShapes = 8;
+extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
+int launch_score(hipStream_t stream, int num_cus, int path, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
 

@@ -199,7 +199,7 @@ struct msc_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int num_cus = 256;
-  int nich1_quads = 0;     // k_score_nich1 launch shape chosen for this box at first use (0 = not tuned yet)
+  int nich1_shape = -1;    // k_score_nich1 launch shape (index into kNich1Shapes) chosen at first use (-1 = not yet)
   // pinned, device-mapped mailbox for msc_value_op_single
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;
