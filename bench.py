@@ -117,6 +117,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # one-off setup outside warmup and timing: derived tables, and the launch-shape selection the library does at the
+    # first large pass of a context (abi.cpp run_score; ~10 ms)
+    st.score_value(view, out=out)
     for _ in range(a.warmup):
         st.score_value(view, out=out)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
