@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
 
 // ---------------------------------------------------------------------------
 // single NICH feature (config C2 / C5 scoring pass)
-//   A wave owns one 256-group tile (constants in VGPRs) and a "slot": it scores Q consecutive
-//   rows, then jumps nslots*Q rows ahead.  Waves are numbered tile-fastest, so the waves that are
-//   resident at one moment write one dense, contiguous window of the score matrix that sweeps
-//   forward through it (the pattern a plain fill reaches its best rate with).  The launcher gives
-//   every wave a single quad; the loop only runs when the grid would exceed the launch limit.
+//   A wave owns one 256-group tile (constants in VGPRs) and a "slot": it visits blocks of Q consecutive
+//   rows that lie nslots*Q rows apart.  Waves are numbered tile-fastest, so the waves resident at one
+//   moment write dense, contiguous windows of the score matrix (one per visit) that sweep forward
+//   through it.  How many visits a wave makes is a launch parameter the host settles per context
+//   (launch_score_t, abi.cpp run_score); everything the wave's rows need is fetched once, up front.
 // ---------------------------------------------------------------------------
 template <bool LOO, bool CRP, int Q, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
