@@ -858,11 +858,21 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     };
     // The single-nich pass is bound by the HBM write stream, and which launch shape (rows per visit, visits per
     // wave = write fronts) suits it differs by up to 20 % from box to box and with where the score buffer landed
-    // (profiles/r01_nich1_variants.txt).  Settle it the first time a context sees a pass large enough to time:
+    // (profiles/r01_nich1_variants.txt: the same shape runs at 7.0 TB/s into one buffer and at 5.6 into the next).
+    // Settle it the first time a context sees a large pass into a given output buffer:
     // every shape of kNich1Shapes, six launches each on the caller's own buffers (~10 ms once; every run writes
     // the same values).  MSC_NICH1_SHAPE fixes it.
-    int shape = st->ctx->nich1_shape;
-    if (path == MSC_PATH_NICH1 && shape < 0 && nrows * (uint64_t)st->K >= (64ull << 20)) {
+    int shape = -1;
+    const bool tunable = path == MSC_PATH_NICH1 && nrows * (uint64_t)st->K >= (64ull << 20);
+    auto &memo = st->ctx->nich1_shapes;
+    if (tunable)
+      for (size_t i = 0; i < memo.size(); i++)
+        if (memo[i].out == out_dev && memo[i].nrows == nrows && memo[i].K == st->K) {
+          shape = memo[i].shape;
+          if (i) std::swap(memo[i], memo[0]);
+          break;
+        }
+    if (tunable && shape < 0) {
       static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_SHAPE"); return e ? std::atoi(e) : -1; }();
       if (fixed >= 0 && fixed < kNich1NumShapes) shape = fixed;
       else {
@@ -886,7 +896,8 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
       }
-      st->ctx->nich1_shape = shape;
+      memo.insert(memo.begin(), msc_context::ShapeEntry{out_dev, nrows, st->K, shape});
+      if (memo.size() > 16) memo.pop_back();
     }
     if (launch(shape < 0 ? 0 : shape))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -199,7 +199,10 @@ struct msc_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int num_cus = 256;
-  int nich1_shape = -1;    // k_score_nich1 launch shape (index into kNich1Shapes) chosen at first use (-1 = not yet)
+  // k_score_nich1 launch shape (index into kNich1Shapes) per output buffer: which shape suits the write stream
+  // depends on where the buffer lies (abi.cpp run_score); most recent first, at most 16 buffers remembered
+  struct ShapeEntry { const void *out; uint64_t nrows; uint32_t K; int shape; };
+  std::vector<ShapeEntry> nich1_shapes;
   // pinned, device-mapped mailbox for msc_value_op_single
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;
