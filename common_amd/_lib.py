@@ -74,6 +74,9 @@ _SIGS = {
     "msc_score_data": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_sweep_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "msc_sweep_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                 C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "msc_sweep_step_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "msc_state_reduce_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "msc_state_commit_reduce": (C.c_int, [C.c_void_p]),

@@ -94,6 +94,7 @@ extern "C" int msc_context_destroy(msc_context *ctx) {
   if (!ctx) return MSC_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->mailbox_host) (void)hipHostFree(ctx->mailbox_host);
+  if (ctx->record_stream) (void)hipStreamDestroy(ctx->record_stream);
   delete ctx;
   return MSC_OK;
 }
@@ -409,6 +410,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->logpc, 2 * kpad + 4))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
     msc_feature_host &h = st->feats[f];
@@ -475,6 +477,7 @@ extern "C" int msc_state_destroy(msc_state *st) {
   if (!st) return MSC_OK;
   (void)hipSetDevice(st->ctx->device);
   (void)hipStreamSynchronize(st->ctx->stream);
+  if (st->step_graph.exec) (void)hipGraphExecDestroy(st->step_graph.exec);
   free_all(st->owned);
   delete st;
   return MSC_OK;
@@ -946,16 +949,36 @@ static int commit(msc_state *st) {
   return MSC_OK;
 }
 
-extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols,
-                              uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags) {
-  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
-  MSC_REQUIRE((flags & ~(MSC_ACC_RESET | MSC_ACC_SUBTRACT | MSC_ACC_NO_COMMIT)) == 0, "unknown flags 0x%x", flags);
-  MSC_HIP(hipSetDevice(st->ctx->device));
+// internal flags of accumulate_impl, next to the public MSC_ACC_*: the additive tables are already zero (a fused
+// sweep kernel did it); commit and prepare in one launch, which also moves the random stream on (msc_sweep_step)
+enum : uint32_t { kAccZeroed = 0x100, kAccThenPrepare = 0x200 };
+
+static int commit_and_prepare(msc_state *st) {
+  hipStream_t s = st->ctx->stream;
+  if (launch_commit_prepare(s, st->desc_dev, (int)st->nfeat, st->K, st->kpad, st->red_i64, st->cnt_u32, st->alpha,
+                            st->logpc, st->rng_dev))
+    return fail(MSC_EHIP, "k_commit_prepare launch failed");
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    const msc_feature_host &h = st->feats[f];
+    if (h.family == MSC_NIW && (launch_niw_commit(s, st->desc_dev, f, h.dim, st->K, st->kpad, 1) ||
+                                launch_niw_prepare(s, st->desc_dev, f, h.dim, st->K, st->kpad)))
+      return fail(MSC_EHIP, "niw commit / prepare launch failed");
+    if (h.family == MSC_DM && st->desc_host[f].dm_meta != nullptr &&
+        launch_dm_prepare(s, st->desc_dev, (int)f, h.dim, st->kpad))
+      return fail(MSC_EHIP, "k_dm_prepare launch failed");
+  }
+  for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = true; }
+  st->crp_valid = true;
+  return MSC_OK;
+}
+
+static int accumulate_impl(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                           uint64_t nrows, const int32_t *z_dev, uint32_t flags) {
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
   hipStream_t s = st->ctx->stream;
   if (flags & MSC_ACC_RESET) {
-    MSC_HIP(hipMemsetAsync(st->red_i64, 0, st->n_i64 * sizeof(long long), s));
-    if (st->n_f64) MSC_HIP(hipMemsetAsync(st->red_f64, 0, st->n_f64 * sizeof(double), s));
+    if (!(flags & kAccZeroed) && launch_zero64(s, st->red_i64, st->n_i64, st->red_f64, st->n_f64))
+      return fail(MSC_EHIP, "k_zero64 launch failed");
   } else {
     MSC_TRY(ensure_raw(st));
     for (uint32_t f = 0; f < st->nfeat; f++)
@@ -994,8 +1017,17 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
     }
   }
   for (auto &h : st->feats) h.raw_valid = false;
+  if (flags & kAccThenPrepare) return commit_and_prepare(st);
   if (!(flags & MSC_ACC_NO_COMMIT)) MSC_TRY(commit(st));
   return MSC_OK;
+}
+
+extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols,
+                              uint64_t row0, uint64_t nrows, const int32_t *z_dev, uint32_t flags) {
+  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
+  MSC_REQUIRE((flags & ~(MSC_ACC_RESET | MSC_ACC_SUBTRACT | MSC_ACC_NO_COMMIT)) == 0, "unknown flags 0x%x", flags);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  return accumulate_impl(st, view, cols, row0, nrows, z_dev, flags);
 }
 
 extern "C" int msc_score_data(msc_state *st, float *out_dev) {
@@ -1016,33 +1048,51 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
   return MSC_OK;
 }
 
-extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *cols,
-                                uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z_dev,
-                                uint64_t seed, uint64_t sweep) {
-  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
-  MSC_HIP(hipSetDevice(st->ctx->device));
+// score + sample in one kernel; niw and gp-beyond-table features and wide K need the materialised path
+static bool sweep_is_fused(const msc_state *st) {
+  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  for (uint32_t f = 0; f < st->nfeat; f++)
+    if (st->feats[f].family == MSC_NIW || gp_beyond_table(st, f)) return false;
+  return nich1 ? st->K <= 1024 : st->K <= 256;
+}
+
+// the sampling kernels read (seed, sweep) from the state's device pair and the step ends by incrementing the sweep
+// index there, so consecutive sweeps need no host -> device traffic (and replay as a graph, msc_sweep_step)
+// `zeroed` non-null = part of a sweep step: the fused kernels also empty the additive tables for the accumulate pass
+// that follows (*zeroed says whether one did), and the increment of the sweep index is left to that pass's tail.
+static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                             uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep,
+                             bool *zeroed = nullptr) {
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
   if (nrows == 0) return MSC_OK;
+  if (!st->rng_valid || st->rng_seed != seed || st->rng_sweep != sweep) {
+    if (launch_rng_set(st->ctx->stream, st->rng_dev, seed, sweep)) return fail(MSC_EHIP, "k_rng_set launch failed");
+    st->rng_valid = true;
+    st->rng_seed = seed;
+    st->rng_sweep = sweep;
+  }
   MSC_TRY(ensure_derived(st));
   MSC_TRY(ensure_crp(st));
   hipStream_t s = st->ctx->stream;
   const int cus = st->ctx->num_cus;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
-  bool fused_ok = true;        // niw and gp-beyond-table features need the materialised path
   bool has_dm = false;
-  for (uint32_t f = 0; f < st->nfeat; f++) {
-    fused_ok &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
-    has_dm |= st->feats[f].family == MSC_DM;
-  }
+  for (uint32_t f = 0; f < st->nfeat; f++) has_dm |= st->feats[f].family == MSC_DM;
   int rc = -2;
-  if (fused_ok && (nich1 ? st->K <= 1024 : st->K <= 256)) {
+  ZeroSpans zero;
+  if (zeroed) {
+    zero.a = reinterpret_cast<unsigned long long *>(st->red_i64); zero.na = st->n_i64;
+    zero.b = reinterpret_cast<unsigned long long *>(st->red_f64); zero.nb = st->n_f64;
+  }
+  if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
       if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
-    if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
-    else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, seed, sweep);
+    if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    if (zeroed) *zeroed = rc == 0;
   }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
@@ -1064,12 +1114,145 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
     for (uint64_t r = 0; r < nrows; r += chunk) {
       const uint64_t n = std::min<uint64_t>(chunk, nrows - r);
       MSC_TRY(run_score(st, row0 + r, n, z_dev + r, true, false, st->scratch, ld));
-      if (launch_sample_rows(s, cus, st->scratch, ld, st->K, n, row_id0 + r, z_dev + r, seed, sweep))
+      if (launch_sample_rows(s, cus, st->scratch, ld, st->K, n, row_id0 + r, z_dev + r, st->rng_dev))
         return fail(MSC_EHIP, "k_sample_rows launch failed");
     }
     rc = 0;
   }
   if (rc) return fail(MSC_EHIP, "sweep kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  if (zeroed) return MSC_OK;
+  if (launch_rng_bump(s, st->rng_dev)) return fail(MSC_EHIP, "k_rng_bump launch failed");
+  st->rng_sweep = sweep + 1;
+  return MSC_OK;
+}
+
+extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *cols,
+                                uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z_dev,
+                                uint64_t seed, uint64_t sweep) {
+  MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  return sweep_assign_impl(st, view, cols, row0, nrows, row_id0, z_dev, seed, sweep);
+}
+
+// ---------------------------------------------------------------------------
+// One whole single-process sweep step: assign, then rebuild the tables from the new assignment
+// (msc_sweep_assign + msc_accumulate(RESET), commit included).  On small problems the step is a dozen
+// launches of a few microseconds each and the gaps between them are the cost, so its steady state -- same
+// view, rows and assignment vector, consecutive sweep indices -- is captured once as a HIP graph and replayed.
+// ---------------------------------------------------------------------------
+static int accumulate_impl(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                           uint64_t nrows, const int32_t *z_dev, uint32_t flags);
+
+// everything the host tracks about which device tables are current; a captured step must leave it as it found it
+typedef std::vector<uint8_t> StepFlags;
+static StepFlags save_flags(const msc_state *st) {
+  StepFlags f;
+  for (auto &h : st->feats) f.push_back((uint8_t)(h.raw_valid | (h.additive_valid << 1) | (h.derived_valid << 2)));
+  f.push_back((uint8_t)(st->cnt_additive_valid | (st->crp_valid << 1) | (st->rng_valid << 2)));
+  return f;
+}
+static void restore_flags(msc_state *st, const StepFlags &f) {
+  for (size_t i = 0; i < st->feats.size(); i++) {
+    st->feats[i].raw_valid = f[i] & 1;
+    st->feats[i].additive_valid = (f[i] >> 1) & 1;
+    st->feats[i].derived_valid = (f[i] >> 2) & 1;
+  }
+  st->cnt_additive_valid = f.back() & 1;
+  st->crp_valid = (f.back() >> 1) & 1;
+  st->rng_valid = (f.back() >> 2) & 1;
+}
+
+extern "C" int msc_sweep_step(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                              uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep) {
+  MSC_REQUIRE(st && view && (z_dev || nrows == 0), "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  hipStream_t s = st->ctx->stream;
+  auto eager = [&]() -> int {
+    st->step_graph.n_eager++;
+    bool zeroed = false;
+    MSC_TRY(sweep_assign_impl(st, view, cols, row0, nrows, row_id0, z_dev, seed, sweep, &zeroed));
+    st->rng_valid = false;                              // (until the tail has moved the device's pair on)
+    MSC_TRY(accumulate_impl(st, view, cols, row0, nrows, z_dev,
+                            MSC_ACC_RESET | kAccThenPrepare | (zeroed ? (uint32_t)kAccZeroed : 0u)));
+    st->rng_valid = true;
+    st->rng_sweep = sweep + 1;
+    return MSC_OK;
+  };
+  MSC_TRY(bind_view(st, view, cols, row0, nrows));       // (uploads and waits if the binding changed: never inside a capture)
+  msc_state::StepGraph &g = st->step_graph;
+  // Replay is opt-in: on ROCm 7.2 / MI355X a graph launch of the step's 3-5 kernels measured 4-5 us SLOWER than
+  // launching them (27 -> 32 us at N = 10k), and instantiation costs milliseconds (sweep step).
+  const char *gv = std::getenv("MSC_SWEEP_GRAPH");
+  const bool no_graph = gv == nullptr || gv[0] == '0' || gv[0] == 0;
+  if (nrows == 0) return accumulate_impl(st, view, cols, row0, 0, z_dev, MSC_ACC_RESET);   // (no row draws anything)
+  if (no_graph || g.disabled) return eager();
+  std::vector<uint32_t> colv(st->nfeat);
+  for (uint32_t f = 0; f < st->nfeat; f++) colv[f] = cols ? cols[f] : f;
+  const bool same_key = g.view == view && g.view_serial == view->serial && g.row0 == row0 && g.nrows == nrows &&
+                        g.row_id0 == row_id0 && g.z == z_dev && g.alpha == st->alpha && g.cols == colv;
+  if (!same_key) {
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    g.view = view; g.view_serial = view->serial; g.row0 = row0; g.nrows = nrows; g.row_id0 = row_id0; g.z = z_dev;
+    g.alpha = st->alpha; g.cols = colv;
+    g.seen = 0;
+  }
+  const bool next_sweep = st->rng_valid && st->rng_seed == seed && st->rng_sweep == sweep;
+  const StepFlags entry = save_flags(st);
+  if (g.exec) {
+    if (!next_sweep || entry != g.flags) return eager();
+    MSC_HIP(hipGraphLaunch(g.exec, s));
+    g.n_replayed++;
+    st->rng_sweep = sweep + 1;      // (the graph ends with k_rng_bump; the flags end as they began)
+    return MSC_OK;
+  }
+  // the first two steps with a key run eagerly -- allocations, bindings and first-use setup happen there and the
+  // state reaches its steady flags -- and the third is captured, if it is the fused kind (nothing in it then
+  // allocates, copies to the host or waits)
+  if (g.seen < 2 || !next_sweep || !sweep_is_fused(st)) {
+    g.seen++;
+    return eager();
+  }
+  // record on the library's own stream (the caller's may be the null stream), replay on the caller's
+  msc_context *ctx = st->ctx;
+  if (!ctx->record_stream && hipStreamCreateWithFlags(&ctx->record_stream, hipStreamNonBlocking) != hipSuccess)
+    ctx->record_stream = nullptr;
+  if (!ctx->record_stream || hipStreamBeginCapture(ctx->record_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    g.disabled = true;
+    return eager();
+  }
+  const uint64_t sweep_before = st->rng_sweep;
+  ctx->stream = ctx->record_stream;
+  const int rc = eager();
+  ctx->stream = s;
+  g.n_eager--;                      // (recorded, not run)
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(ctx->record_stream, &graph);
+  bool ok = rc == MSC_OK && ec == hipSuccess && graph != nullptr && save_flags(st) == entry;
+  if (ok && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    g.exec = nullptr;
+    ok = false;
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  if (!ok) {
+    // nothing of the captured step has run: put the host's view of the state back and run the step as it is
+    (void)hipGetLastError();
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    g.disabled = true;
+    restore_flags(st, entry);
+    st->rng_sweep = sweep_before;
+    return eager();
+  }
+  g.flags = entry;
+  MSC_HIP(hipGraphLaunch(g.exec, s));
+  g.n_replayed++;
+  return MSC_OK;
+}
+
+extern "C" int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *graph_steps) {
+  MSC_REQUIRE(st, "null argument");
+  if (eager_steps) *eager_steps = st->step_graph.n_eager;
+  if (graph_steps) *graph_steps = st->step_graph.n_replayed;
   return MSC_OK;
 }
 

@@ -17,6 +17,7 @@
 // broadcast with v_readlane.
 #include <cstdlib>
 
+#include "commit_ops.hpp"
 #include "family_math.hpp"
 #include "launchers.hpp"
 #include "score_block.hpp"
@@ -27,10 +28,7 @@ namespace msc {
 // prepare: one thread per (feature, group slot); pads (k >= K) are prepared from their
 // zeroed raw stats so that vector loads of a full tile stay finite.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ feats, uint32_t kpad) {
-  const FeatDesc fd = feats[blockIdx.y];
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= kpad) return;
+MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad) {
   switch (fd.family) {
     case MSC_BB: {
       float s0, s1;
@@ -88,6 +86,12 @@ __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ fe
   }
 }
 
+__global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ feats, uint32_t kpad) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kpad) return;
+  prepare_group(feats[blockIdx.y], k, kpad);
+}
+
 // dm tables: blockIdx.y = stage (category i < dim, or dim = the row total); one thread per group slot
 __global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__ feats, int f, uint32_t kpad) {
   const FeatDesc fd = feats[f];
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__
 
 // crp layout: [0,kpad) log(cnt) or -inf when empty; [kpad,2kpad) log(cnt-1) or -inf;
 // [2kpad] = log(alpha / n_empty), [2kpad+1] = log(alpha / (n_empty+1)).  One block.
-__global__ __launch_bounds__(256) void k_crp_prepare(const uint32_t *__restrict__ cnt, uint32_t K,
-                                                      uint32_t kpad, float alpha, float *crp) {
+MSC_DEV void crp_prepare_block(const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
+                               float *__restrict__ crp) {
   __shared__ uint32_t s_empty;
   if (threadIdx.x == 0) s_empty = 0;
   __syncthreads();
@@ -129,6 +133,33 @@ __global__ __launch_bounds__(256) void k_crp_prepare(const uint32_t *__restrict_
     crp[2 * (size_t)kpad] = ne > 0 ? (float)log((double)alpha / ne) : -INFINITY;
     crp[2 * (size_t)kpad + 1] = (float)log((double)alpha / (ne + 1.0));
   }
+}
+__global__ __launch_bounds__(256) void k_crp_prepare(const uint32_t *__restrict__ cnt, uint32_t K,
+                                                      uint32_t kpad, float alpha, float *crp) {
+  crp_prepare_block(cnt, K, kpad, alpha, crp);
+}
+
+// The tail of a sweep step in one launch: commit (additive -> raw) and prepare (raw -> score tables) of every
+// (feature, group), by the same thread so no grid-wide ordering is needed; the extra y-slice commits the group
+// sizes and derives the CRP terms from them (one block walks all K), and moves the step's random stream on.
+__global__ __launch_bounds__(256) void k_commit_prepare(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K,
+                                                         uint32_t kpad, const long long *__restrict__ cnt_acc,
+                                                         uint32_t *__restrict__ cnt_u32, float alpha,
+                                                         float *__restrict__ crp, uint64_t *__restrict__ rng_bump) {
+  if ((int)blockIdx.y == nfeat) {
+    if (blockIdx.x != 0) return;
+    for (uint32_t k = threadIdx.x; k < kpad; k += 256) cnt_u32[k] = (uint32_t)cnt_acc[k];
+    __syncthreads();                                   // (each thread reads back what it wrote; the barrier is for s_empty's init)
+    crp_prepare_block(cnt_u32, K, kpad, alpha, crp);
+    if (rng_bump != nullptr && threadIdx.x == 0) rng_bump[1] += 1;
+    return;
+  }
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kpad) return;
+  const FeatDesc fd = feats[blockIdx.y];
+  if (fd.family == MSC_NIW) return;                    // (its own commit / prepare kernels)
+  commit_group(fd, k, kpad);
+  prepare_group(fd, k, kpad);
 }
 
 // ---------------------------------------------------------------------------
@@ -394,6 +425,13 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad) {
   dim3 grid((kpad + 255) / 256, nfeat);
   hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, stream, feats_dev, kpad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad,
+                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump) {
+  hipLaunchKernelGGL(k_commit_prepare, dim3((kpad + 255) / 256, nfeat + 1), dim3(256), 0, stream, feats_dev, nfeat, K, kpad,
+                     cnt_acc, cnt_u32, alpha, crp, rng_bump);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

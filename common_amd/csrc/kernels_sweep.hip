@@ -95,14 +95,28 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
   return k < (int)K ? k : (int)K - 1;
 }
 
+// the whole grid shares the zeroing of the additive tables (nothing in a sweep kernel reads them)
+MSC_DEV void zero_spans(const ZeroSpans &zs) {
+  const size_t n = zs.na + zs.nb;
+  if (n == 0) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (i < zs.na) zs.a[i] = 0ull;
+    else zs.b[i - zs.na] = 0ull;
+  }
+}
+
 // ---------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict__ feats, uint32_t K,
                                                       uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                       uint64_t row_id0, int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
-                                                      const float *__restrict__ crp, uint64_t seed,
-                                                      uint64_t sweep) {
+                                                      const float *__restrict__ crp,
+                                                      const uint64_t *__restrict__ rng, int chunk_rows,
+                                                      ZeroSpans zero) {
+  const uint64_t seed = rng[0], sweep = rng[1];      // (device-resident so that a captured graph can replay the step)
+  zero_spans(zero);
   const FeatDesc fd = feats[0];
   const int lane = threadIdx.x & 63;
   const uint32_t kb = (uint32_t)(G * lane);
@@ -140,12 +154,14 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     emp[j] = empty ? kLog2e : 0.f;
   }
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
-  const uint64_t nchunks = (nrows + 63) / 64;
+  // a wave takes chunk_rows (<= 64) rows at a time, one per lane for the per-row setup, then scores them one after
+  // the other: the rows of a chunk are a serial chain, so few rows want short chunks spread over many waves
+  const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
-    const uint64_t rb = chunk * 64;
-    const int nr = (int)((nrows - rb) < 64 ? (nrows - rb) : 64);
+    const uint64_t rb = chunk * chunk_rows;
+    const int nr = (int)((nrows - rb) < (uint64_t)chunk_rows ? (nrows - rb) : (uint64_t)chunk_rows);
     const bool has_row = lane < nr;
     const float xv = has_row ? xcol[rb + lane] : 0.0f;
     const int gz = has_row ? z[rb + lane] : -1;
@@ -201,8 +217,10 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
                                                                  uint64_t nrows, uint64_t row_id0,
                                                                  int32_t *__restrict__ z,
                                                                  const float *__restrict__ own,
-                                                                 const float *__restrict__ crp, uint64_t seed,
-                                                                 uint64_t sweep) {
+                                                                 const float *__restrict__ crp,
+                                                                 const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
   __shared__ float4 lds[kGrpRows * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = lane * 4;            // single k-tile: K <= 256
@@ -250,8 +268,9 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sample_rows(const float *__restrict__ scores, uint64_t ld,
                                                       uint32_t K, uint64_t nrows, uint64_t row_id0,
-                                                      int32_t *__restrict__ z, uint64_t seed,
-                                                      uint64_t sweep) {
+                                                      int32_t *__restrict__ z,
+                                                      const uint64_t *__restrict__ rng) {
+  const uint64_t seed = rng[0], sweep = rng[1];
   const int lane = threadIdx.x & 63;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -288,15 +307,18 @@ static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int wa
 
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
-  const uint64_t gx = grid_for((nrows + 63) / 64, num_cus, 16);
+                       const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
+  // 64 rows per wave visit once there are enough rows for ~8 waves per SIMD; fewer rows: halve the visit down to 4
+  int chunk_rows = 64;
+  while (chunk_rows > 4 && (nrows + chunk_rows - 1) / chunk_rows < (uint64_t)num_cus * 32) chunk_rows >>= 1;
+  const uint64_t gx = grid_for((nrows + chunk_rows - 1) / chunk_rows, num_cus, 16);
   const dim3 grid((unsigned)gx), block(256);
   if (K <= 256)
-    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 512)
-    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 1024)
-    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, seed, sweep);
+    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else
     return -2;
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -304,7 +326,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
 
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *own, const float *crp, uint64_t seed, uint64_t sweep) {
+                       const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
   const int R = tile_rows_per_wave();
   const uint64_t rows_per_wg = has_dm ? 64 : 128;
@@ -314,21 +336,37 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatD
   const dim3 grid((unsigned)(gx ? gx : 1));
   if (has_dm)
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
-                       row_id0, z, own, crp, seed, sweep);
+                       row_id0, z, own, crp, rng, zero);
   else if (R == 16)
     hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
-                       row_id0, z, own, crp, seed, sweep);
+                       row_id0, z, own, crp, rng, zero);
   else
     hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
-                       row_id0, z, own, crp, seed, sweep);
+                       row_id0, z, own, crp, rng, zero);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
-                       uint64_t nrows, uint64_t row_id0, int32_t *z, uint64_t seed, uint64_t sweep) {
+                       uint64_t nrows, uint64_t row_id0, int32_t *z, const uint64_t *rng) {
   const uint64_t gx = grid_for(nrows, num_cus, 32);
   hipLaunchKernelGGL(k_sample_rows, dim3((unsigned)gx), dim3(256), 0, stream, scores, ld, K, nrows, row_id0,
-                     z, seed, sweep);
+                     z, rng);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// the (seed, sweep index) pair of a state lives on the device: a sweep step captured as a graph replays with the
+// index the previous step left behind
+__global__ void k_rng_set(uint64_t *rng, uint64_t seed, uint64_t sweep) {
+  rng[0] = seed;
+  rng[1] = sweep;
+}
+__global__ void k_rng_bump(uint64_t *rng) { rng[1] += 1; }
+int launch_rng_set(hipStream_t stream, uint64_t *rng, uint64_t seed, uint64_t sweep) {
+  hipLaunchKernelGGL(k_rng_set, dim3(1), dim3(1), 0, stream, rng, seed, sweep);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_rng_bump(hipStream_t stream, uint64_t *rng) {
+  hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, stream, rng);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

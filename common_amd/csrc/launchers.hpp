@@ -43,14 +43,24 @@ int launch_score(hipStream_t stream, int num_cus, int path, int nich1_shape, con
                  const float *own, const float *crp, float *out, uint64_t ld);
 
 // kernels_sweep.hip  (return -2: shape not covered by this kernel)
+// two runs of 8-byte words that a fused sweep kernel zeroes on its way (the additive tables, which the accumulate
+// pass that follows in a sweep step wants empty); all null / 0 when nothing follows
+struct ZeroSpans {
+  unsigned long long *a = nullptr;
+  size_t na = 0;
+  unsigned long long *b = nullptr;
+  size_t nb = 0;
+};
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *own, const float *crp, uint64_t seed, uint64_t sweep);
+                       const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *own, const float *crp, uint64_t seed, uint64_t sweep);
+                       const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
 int launch_sample_rows(hipStream_t stream, int num_cus, const float *scores, uint64_t ld, uint32_t K,
-                       uint64_t nrows, uint64_t row_id0, int32_t *z, uint64_t seed, uint64_t sweep);
+                       uint64_t nrows, uint64_t row_id0, int32_t *z, const uint64_t *rng_dev);
+int launch_rng_set(hipStream_t stream, uint64_t *rng_dev, uint64_t seed, uint64_t sweep);
+int launch_rng_bump(hipStream_t stream, uint64_t *rng_dev);
 
 // kernels_niw.hip
 int launch_niw_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
@@ -71,6 +81,9 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
                       uint64_t nrows, const int32_t *z, int sign, long long *cnt_acc);
 int launch_commit(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
                   const long long *cnt_acc, uint32_t *cnt_u32);
+int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad,
+                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump);
+int launch_zero64(hipStream_t stream, void *a, size_t na, void *b, size_t nb);   // 8-byte words
 int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
                 long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt);
 int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K,

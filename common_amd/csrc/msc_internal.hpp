@@ -203,6 +203,9 @@ struct msc_context {
   // depends on where the buffer lies (abi.cpp run_score); most recent first, at most 16 buffers remembered
   struct ShapeEntry { const void *out; uint64_t nrows; uint32_t K; int shape; };
   std::vector<ShapeEntry> nich1_shapes;
+  // a stream of the library's own on which sweep steps are recorded (the caller's may be the null stream, which
+  // cannot capture); nothing ever executes on it
+  hipStream_t record_stream = nullptr;
   // pinned, device-mapped mailbox for msc_value_op_single
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;
@@ -274,6 +277,22 @@ struct msc_state {
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;
   size_t scratch_floats = 0;
+  // (seed, sweep index) of the sampling kernels, device-resident (kernels_sweep.hip); the host tracks what it holds
+  uint64_t *rng_dev = nullptr;
+  uint64_t rng_seed = 0, rng_sweep = 0;
+  bool rng_valid = false;
+  // a whole sweep step (assign + accumulate + commit) captured as a graph for its steady state (abi.cpp msc_sweep_step)
+  struct StepGraph {
+    hipGraphExec_t exec = nullptr;
+    const void *view = nullptr, *z = nullptr;
+    uint64_t view_serial = 0, row0 = 0, nrows = 0, row_id0 = 0;
+    float alpha = 0.f;
+    std::vector<uint32_t> cols;
+    std::vector<uint8_t> flags;        // validity flags of the state at step entry
+    int seen = 0;                      // eager steps with this key so far
+    bool disabled = false;
+    uint64_t n_eager = 0, n_replayed = 0;   // steps run either way (msc_sweep_step_stats)
+  } step_graph;
   double *niw_qown = nullptr;        // q of every row's own group (niw leave-one-out), [niw_qown_cap]
   size_t niw_qown_cap = 0;
   uint32_t *niw_scratch = nullptr;   // row bucketing for niw accumulate: 2 K + 1 + rows uint32

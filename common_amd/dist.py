@@ -42,6 +42,12 @@ class ShardedSweep(object):
         allreduce_tables(self.red_i64, self.red_f64, self.group)
         self.state.commit_reduce()
 
+    def _alone(self):
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1
+
     def sweep(self, seed, sweep_index):
+        if self._alone():         # nothing to exchange: the whole step is one library call (graph-replayed when it repeats)
+            self.state.sweep_step(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
+            return
         self.state.sweep_assign(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
         self.rebuild_tables()

@@ -358,6 +358,21 @@ class State(object):
                                               row0 if row_id0 is None else row_id0,
                                               C.c_void_p(z.data_ptr()), int(seed), int(sweep)))
 
+    def sweep_step(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
+        """sweep_assign + accumulate(reset) in one call; repeated steps replay as a HIP graph (msc_sweep_step)."""
+        n = view.nrows - row0 if nrows is None else nrows
+        if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
+            raise ValueError("z must be a contiguous int32 tensor of nrows entries")
+        L.check(self.ctx.lib.msc_sweep_step(self._h, view._h, self._cols(cols), row0, n,
+                                            row0 if row_id0 is None else row_id0,
+                                            C.c_void_p(z.data_ptr()), int(seed), int(sweep)))
+
+    def sweep_step_stats(self):
+        """(steps run launch by launch, steps run as one graph launch)"""
+        e, g = C.c_uint64(), C.c_uint64()
+        L.check(self.ctx.lib.msc_sweep_step_stats(self._h, C.byref(e), C.byref(g)))
+        return e.value, g.value
+
     # multi-GPU hook ---------------------------------------------------------
     def reduce_buffers(self):
         """(int64 tensor, float64 tensor) aliasing the additive tables, for all_reduce(SUM)."""

@@ -217,6 +217,24 @@ int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *co
                      uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed,
                      uint64_t sweep);
 
+/*
+ * One whole single-process sweep step: msc_sweep_assign, then
+ * msc_accumulate(MSC_ACC_RESET) of the same rows with the new assignment
+ * (commit included) -- the loop body of SURVEY 3.2 when nothing is sharded.
+ * Same results as the two calls, in fewer launches: the fused sweep kernels
+ * empty the additive tables on their way, and commit + prepare + the CRP terms
+ * of the next sweep are one kernel (3 launches per step for a single nich
+ * feature instead of 7), which is what bounds small problems.
+ * MSC_SWEEP_GRAPH=1 in the environment additionally captures the step as a HIP
+ * graph once consecutive calls repeat (same view, rows, z_dev, seed; sweep =
+ * previous + 1) and replays it; off by default because it measured slower
+ * than the launches it replaces on ROCm 7.2.
+ */
+int msc_sweep_step(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                   uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep);
+/* how many msc_sweep_step calls on this state ran launch by launch / as a graph launch */
+int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *graph_steps);
+
 /* ---- multi-GPU hook ---------------------------------------------------- */
 /*
  * The additive form of every table, ready for a sum all-reduce across row
