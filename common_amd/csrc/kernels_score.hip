@@ -349,32 +349,39 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;       // relative to row0
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
-    int gz = -1;
-    float sloo = 0, erow = le0;
-    if (LOO && lane < nr) {
-      gz = z[rb + lane];
-      sloo = own[rb + lane];
-      if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
-    }
     float4 acc[R];
+    {
+      float erow = le0;
+      if (LOO && CRP && lane < nr) {
+        const int g0 = z[rb + lane];
+        if (g0 >= 0) erow = __builtin_isinf(crp[kpad + g0]) ? le1 : le0;
+      }
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
-      else acc[r] = make_float4(0, 0, 0, 0);
+      for (int r = 0; r < R; r++) {
+        if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
+        else acc[r] = make_float4(0, 0, 0, 0);
+      }
     }
     score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < nr) {
-        float4 s = acc[r];
-        if (LOO) {
-          const int g = lane_bcast(gz, r);
-          if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, r));
-        }
-        store_row(out, ld, rb + r, kb, K, s, vec_ok);
+        store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);      // (LOO: k_loo_patch then overwrites the own group's entry)
       }
     }
   }
+}
+
+// Leave-one-out, tile path: the entry of the row's own group becomes the pre-computed own[n] (k_loo_own).  A pass of
+// its own -- one 4-byte write per row, ~64 MB of sector traffic per million rows -- because doing it in the tile
+// kernel's epilogue cost the 16-wave tiling its last registers (60-100 bytes of scratch per lane: C3 3.01 ms against
+// 2.60 ms plain, and 2x at small K).  The LOO flag of k_score_tile now only selects the row's empty-group prior.
+__global__ __launch_bounds__(256) void k_loo_patch(const int32_t *__restrict__ z, const float *__restrict__ own, uint32_t K,
+                                                    uint64_t nrows, float *__restrict__ out, uint64_t ld) {
+  const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nrows) return;
+  const int g = z[n];
+  if (g >= 0 && (uint32_t)g < K) out[n * ld + (uint32_t)g] = own[n];
 }
 
 // ---------------------------------------------------------------------------
@@ -500,8 +507,14 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)
     // states with a dm feature: 8 waves x 8 rows (64 rows per workgroup, 256-register budget for the hi/lo sums)
+    // few rows: a chunk is a serial chain (feature after feature, the code fetched once), so what counts is that
+    // the chunks spread over the chip in ONE round: 4 or 2 rows per wave while that still fits
     const int R = tile_rows_per_wave();
-    const uint64_t rows_per_wg = path == MSC_PATH_TILE_DM ? 64 : 128;
+    const bool dm = path == MSC_PATH_TILE_DM;
+    const uint64_t round = (uint64_t)num_cus / ktiles;
+    static const uint64_t rounds4 = std::getenv("MSC_TILE_R4_ROUNDS") ? std::atoi(std::getenv("MSC_TILE_R4_ROUNDS")) : 1;
+    const bool small4 = !dm && (nrows + 127) / 128 < round * rounds4, small2 = small4 && (nrows + 31) / 32 <= round;
+    const uint64_t rows_per_wg = dm ? 64 : small2 ? 32 : small4 ? 64 : 128;
     const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
     uint64_t gx = nchunks;
     const uint64_t cap = (uint64_t)num_cus * 4;
@@ -511,12 +524,20 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
+    else if (small2)
+      hipLaunchKernelGGL((k_score_tile<2, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
+    else if (small4)
+      hipLaunchKernelGGL((k_score_tile<4, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
     else if (R == 16)
       hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else
       hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
+    if (LOO && nrows > 0)
+      hipLaunchKernelGGL(k_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, z, own, K, nrows, out, ld);
   }
 }
 

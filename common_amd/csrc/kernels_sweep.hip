@@ -329,13 +329,23 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatD
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
   const int R = tile_rows_per_wave();
-  const uint64_t rows_per_wg = has_dm ? 64 : 128;
+  // few rows: 2 rows per wave instead of 8, so that the chunks -- each a serial chain of feature lookups and R
+  // draws -- spread over the chip instead of queueing in a quarter of it (N = 10k, 12 features: 26 -> ? us)
+  const bool small = !has_dm && (nrows + 127) / 128 < (uint64_t)num_cus;
+  const bool small4 = small && (nrows + 31) / 32 > (uint64_t)num_cus;      // (2 rows per wave would need a second round)
+  const uint64_t rows_per_wg = has_dm ? 64 : small4 ? 64 : small ? 32 : 128;
   uint64_t gx = (nrows + rows_per_wg - 1) / rows_per_wg;
   const uint64_t cap = (uint64_t)num_cus * 4;
   if (gx > cap) gx = cap;
   const dim3 grid((unsigned)(gx ? gx : 1));
   if (has_dm)
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, rng, zero);
+  else if (small4)
+    hipLaunchKernelGGL((k_sweep_tile<4, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, rng, zero);
+  else if (small)
+    hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (R == 16)
     hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,

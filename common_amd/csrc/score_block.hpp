@@ -47,11 +47,15 @@ MSC_DEV float4 crp_prior4(float4 logcnt, float e_row) {
   p.w = __builtin_isinf(logcnt.w) ? e_row : logcnt.w;
   return p;
 }
+// (g is wave-uniform: one vector compare finds the lane, the component is picked by scalar conditions -- keeps
+// kb + 1 .. kb + 3 out of the registers of kernels that have none to spare)
 MSC_DEV void replace_own(float4 &s, uint32_t kb, int g, float v) {
-  if ((int)kb == g) s.x = v;
-  if ((int)kb + 1 == g) s.y = v;
-  if ((int)kb + 2 == g) s.z = v;
-  if ((int)kb + 3 == g) s.w = v;
+  const bool mine = (int)kb == (g & ~3);
+  const int c = g & 3;
+  s.x = (mine && c == 0) ? v : s.x;
+  s.y = (mine && c == 1) ? v : s.y;
+  s.z = (mine && c == 2) ? v : s.z;
+  s.w = (mine && c == 3) ? v : s.w;
 }
 MSC_DEV void add4(float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
@@ -63,11 +67,12 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
     const f32x4 v = {s.x, s.y, s.z, s.w};
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
     else *reinterpret_cast<f32x4 *>(p) = v;
-  } else {
-    if (kb < K) p[0] = s.x;
-    if (kb + 1 < K) p[1] = s.y;
-    if (kb + 2 < K) p[2] = s.z;
-    if (kb + 3 < K) p[3] = s.w;
+  } else if (kb < K) {
+    const uint32_t rem = K - kb;
+    p[0] = s.x;
+    if (rem > 1) p[1] = s.y;
+    if (rem > 2) p[2] = s.z;
+    if (rem > 3) p[3] = s.w;
   }
 }
 
