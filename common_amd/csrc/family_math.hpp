@@ -78,7 +78,10 @@ MSC_DEV double lgamma_drop(double a, uint32_t v) {
 }
 // log(v!): a table for the counts that occur, Stirling beyond
 __device__ const double kLogFactorial[32] = {0, 0, 0.69314718055994495, 1.7917594692280554, 3.1780538303479449, 4.7874917427820467, 6.5792512120101021, 8.5251613610654147, 10.604602902745249, 12.801827480081467, 15.104412573075514, 17.502307845873887, 19.987214495661885, 22.552163853123421, 25.191221182738683, 27.89927138384089, 30.671860106080672, 33.505073450136891, 36.395445208033053, 39.339884187199495, 42.335616460753485, 45.380138898476908, 48.47118135183522, 51.606675567764377, 54.784729398112319, 58.003605222980518, 61.261701761002008, 64.557538627006338, 67.889743137181526, 71.257038967168, 74.658236348830172, 78.092223553315307};
-MSC_DEV double log_factorial(uint32_t v) { return v < 32u ? kLogFactorial[v] : lgamma_pos((double)v + 1.0); }
+// (the rare branch is a real call: inlined, hipcc hoists its ~30 double constants out of the caller's row loop and
+// then spills them -- k_accumulate carried 244 bytes of scratch per lane for it)
+static __device__ __attribute__((noinline)) double log_factorial_big(uint32_t v) { return lgamma_pos((double)v + 1.0); }
+MSC_DEV double log_factorial(uint32_t v) { return v < 32u ? kLogFactorial[v] : log_factorial_big(v); }
 
 MSC_DEV void split_hi_lo(double v, float &hi, float &lo) {
   hi = (float)v;
@@ -239,13 +242,13 @@ MSC_DEV double dm_score_direct(const float *hp, uint32_t dim, const uint32_t *co
 }
 // the row's contribution to `ratio` (dm.cpp:10-22)
 MSC_DEV double dm_row_ratio(uint32_t dim, const int32_t *x) {
-  double r = 0, X = 0;
+  double r = 0;
+  uint32_t tot = 0;
   for (uint32_t i = 0; i < dim; i++) {
-    const double xi = (double)(uint32_t)x[i];
-    r -= lgamma(xi + 1.0);
-    X += xi;
+    r -= log_factorial((uint32_t)x[i]);
+    tot += (uint32_t)x[i];
   }
-  return r + lgamma(X + 1.0);
+  return r + log_factorial(tot);
 }
 MSC_DEV double dm_score_data(const float *hp, uint32_t dim, const uint32_t *counts, size_t cstride, double ratio) {
   double s = ratio, A = 0, N = 0;
