@@ -188,3 +188,35 @@ def test_golden_vectors_through_the_device(gpu_ctx):
                 assert rel_err(got, case["score_value"]).max() <= 5e-5, name
             sd = st.score_data().cpu().numpy()[0, 0]
             assert rel_err(sd, F.score_data(ss64, 0)) <= TOL
+
+
+@pytest.mark.parametrize("N,K", [(40_000, 100), (70_000, 300)])
+def test_leave_one_out_on_the_large_tiling(gpu_ctx, N, K):
+    """N >= 32k rows takes the 8-rows-per-wave tiling, whose own-group entries are written by k_loo_patch
+    (K = 300: two k-tiles); a singleton group exercises the per-row empty-group prior"""
+    import common_amd
+    rng = np.random.default_rng(N)
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BNB, 0), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K - 3, N).astype(np.int32)
+    z[z == K - 4] = 0
+    z[12345] = K - 4                                       # a group with exactly one member
+    z[77] = -1                                             # an unassigned row
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    counts = np.bincount(z[z >= 0], minlength=K)
+    st.set_group_counts(counts.astype(np.uint32))
+    st.set_alpha(0.9)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = st.score_value(view, z=zt, crp_prior=True)
+    rows = np.concatenate([[12345, 77, 0, N - 1], rng.choice(N, 300, replace=False)])
+    want = oracle_scores(feats, fs, z=z, rows=rows) + crp_prior_matrix(counts, 0.9, z[rows])
+    assert rel_err(got[torch.from_numpy(rows).to(gpu_ctx.torch_device)].cpu().numpy(), want).max() <= TOL
+    plain = st.score_value(view, crp_prior=True)
+    other = torch.ones((N, K), dtype=torch.bool, device=gpu_ctx.torch_device)
+    ok = zt >= 0
+    other[ok.nonzero().squeeze(1), zt[ok].long()] = False
+    other[12345] = False                                   # (its empty-group columns carry the other prior)
+    assert torch.equal(got[other], plain[other])           # everything but the own entries: the same bits
