@@ -44,6 +44,10 @@ _SIGS = {
     "msc_context_destroy": (C.c_int, [C.c_void_p]),
     "msc_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_context_synchronize": (C.c_int, [C.c_void_p]),
+    "msc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "msc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "msc_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "msc_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "msc_dataview_from_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.POINTER(RuntimeType), C.c_uint32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_void_p)]),

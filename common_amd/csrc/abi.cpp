@@ -111,6 +111,46 @@ extern "C" int msc_context_synchronize(msc_context *ctx) {
   return MSC_OK;
 }
 
+// plain device buffers for callers that hold no HIP headers of their own (the assignment vector, score rows)
+extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
+  MSC_REQUIRE(ctx && out, "null argument");
+  MSC_HIP(hipSetDevice(ctx->device));
+  void *p = nullptr;
+  MSC_HIP(hipMalloc(&p, nbytes ? nbytes : 1));
+  const hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(MSC_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  *out = p;
+  return MSC_OK;
+}
+extern "C" int msc_device_free(msc_context *ctx, void *dev) {
+  MSC_REQUIRE(ctx, "null context");
+  if (!dev) return MSC_OK;
+  MSC_HIP(hipSetDevice(ctx->device));
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  MSC_HIP(hipFree(dev));
+  return MSC_OK;
+}
+// both copies are ordered on the context's stream and have completed when the call returns
+extern "C" int msc_device_upload(msc_context *ctx, void *dst_dev, const void *src_host, size_t nbytes) {
+  MSC_REQUIRE(ctx && (nbytes == 0 || (dst_dev && src_host)), "null argument");
+  if (nbytes == 0) return MSC_OK;
+  MSC_HIP(hipSetDevice(ctx->device));
+  MSC_HIP(hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, ctx->stream));
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  return MSC_OK;
+}
+extern "C" int msc_device_download(msc_context *ctx, void *dst_host, const void *src_dev, size_t nbytes) {
+  MSC_REQUIRE(ctx && (nbytes == 0 || (dst_host && src_dev)), "null argument");
+  if (nbytes == 0) return MSC_OK;
+  MSC_HIP(hipSetDevice(ctx->device));
+  MSC_HIP(hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  return MSC_OK;
+}
+
 // ---------------------------------------------------------------------------
 // dataview
 // ---------------------------------------------------------------------------

@@ -547,6 +547,23 @@ public:
   void set_ss(const group &g) override { repr_ = static_cast<const distributions_group<T> &>(g).repr_; }
   common::value_mutator get_ss_mutator(const std::string &key) override { return detail::field_access<T>::ss(repr_, key); }
   std::string debug_str() const override { return "<group family " + std::to_string(int(traits::family)) + ">"; }
+  bool device_record_get(const hypers &m, std::vector<uint8_t> &rec) const override {
+    const typename T::Shared &shared = static_cast<const distributions_hypers<T> &>(m).repr_;
+    std::vector<uint8_t> buf;
+    const void *p = traits::record(const_cast<typename T::Group &>(repr_), buf);
+    const uint8_t *b = static_cast<const uint8_t *>(p);
+    rec.assign(b, b + msc_ss_bytes(traits::family, traits::dim(shared)));
+    return true;
+  }
+  bool device_record_set(const hypers &m, const std::vector<uint8_t> &rec) override {
+    const typename T::Shared &shared = static_cast<const distributions_hypers<T> &>(m).repr_;
+    if (rec.size() != msc_ss_bytes(traits::family, traits::dim(shared))) throw std::runtime_error("record size mismatch");
+    std::vector<uint8_t> buf;
+    void *p = traits::record(repr_, buf);
+    if (p == buf.data()) traits::unpack(repr_, rec);          // packed families: straight from the record
+    else std::memcpy(p, rec.data(), rec.size());              // plain-struct families: the record is the struct's head
+    return true;
+  }
 
   typename T::Group repr_;
 
@@ -582,6 +599,12 @@ public:
   void set_hp(const hypers &m) override { repr_ = static_cast<const hypers_base<T> &>(m).repr_; }
   common::value_mutator get_hp_mutator(const std::string &key) override { return field_access<T>::hp(repr_, key); }
   std::string debug_str() const override { return "<hypers family " + std::to_string(int(family_traits<T>::family)) + ">"; }
+  bool device_spec(msc_feature_spec &spec, std::vector<float> &hp) const override {
+    spec.family = family_traits<T>::family;
+    spec.dim = family_traits<T>::dim(repr_);
+    family_traits<T>::pack_hp(repr_, hp);
+    return true;
+  }
 
   typename T::Shared repr_;
 };

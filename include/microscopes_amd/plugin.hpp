@@ -28,6 +28,12 @@ public:
   virtual void set_ss(const group &g) = 0;
   virtual common::value_mutator get_ss_mutator(const std::string &key) = 0;
   virtual std::string debug_str() const = 0;
+
+  // -- HIP backend extension (nothing like it upstream): the suff-stats as the packed record of
+  //    msc_state_set_ss / msc_state_get_ss, so a batched device state (mixture_state.hpp) can host this group.
+  //    false = this model has no device family.
+  virtual bool device_record_get(const hypers &, std::vector<uint8_t> &) const { return false; }
+  virtual bool device_record_set(const hypers &, const std::vector<uint8_t> &) { return false; }
 };
 
 // hyper-parameters of one feature
@@ -40,6 +46,9 @@ public:
   virtual common::value_mutator get_hp_mutator(const std::string &key) = 0;
   virtual std::shared_ptr<group> create_group(common::rng_t &rng) const = 0;
   virtual std::string debug_str() const = 0;
+
+  // -- HIP backend extension: the kernel family + dimension and the hyper-parameters as msc_state_set_hp takes them
+  virtual bool device_spec(msc_feature_spec &, std::vector<float> &) const { return false; }
 };
 
 class model {
@@ -69,6 +78,11 @@ public:
   void set_ss(const group &) override {}
   common::value_mutator get_ss_mutator(const std::string &) override { throw std::runtime_error("noop"); }
   std::string debug_str() const override { return "<noop>"; }
+  bool device_record_get(const hypers &, std::vector<uint8_t> &rec) const override {
+    rec.clear();
+    return true;
+  }
+  bool device_record_set(const hypers &, const std::vector<uint8_t> &) override { return true; }
 };
 
 class noop_hypers : public hypers {
@@ -79,6 +93,12 @@ public:
   common::value_mutator get_hp_mutator(const std::string &) override { throw std::runtime_error("noop"); }
   std::shared_ptr<group> create_group(common::rng_t &) const override { return std::make_shared<noop_group>(); }
   std::string debug_str() const override { return "<noop>"; }
+  bool device_spec(msc_feature_spec &spec, std::vector<float> &hp) const override {
+    spec.family = MSC_NOOP;
+    spec.dim = 0;
+    hp.clear();
+    return true;
+  }
 };
 
 class noop_model : public model {

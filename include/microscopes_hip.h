@@ -88,6 +88,16 @@ int msc_context_destroy(msc_context *ctx);
 int msc_context_set_stream(msc_context *ctx, void *stream);
 int msc_context_synchronize(msc_context *ctx);
 
+/*
+ * Plain device buffers (zero-filled), for hosts that keep no HIP headers of their
+ * own: the assignment vector z, a row of scores.  upload / download are ordered on
+ * the context's stream and complete before they return.
+ */
+int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out_dev);
+int msc_device_free(msc_context *ctx, void *dev);
+int msc_device_upload(msc_context *ctx, void *dst_dev, const void *src_host, size_t nbytes);
+int msc_device_download(msc_context *ctx, void *dst_host, const void *src_dev, size_t nbytes);
+
 /* ---- columnar dataview (replaces recarray/dataview.hpp:194-217) -------- */
 /*
  * Packed row-major records exactly as numpy_dataview hands them over

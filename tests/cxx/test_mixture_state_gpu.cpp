@@ -1,0 +1,189 @@
+// mixture_state (an entity_based_state_object on the device tables) against a host twin built from the same
+// plugin API: the per-entity Gibbs loop of entity_state.hpp, group creation / deletion, likelihoods,
+// suff-stat bags, hyper-parameter changes, and the batched sweep.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+
+#include <microscopes/common/entity_state.hpp>
+#include <microscopes/models/distributions.hpp>
+#include <microscopes_amd/mixture_state.hpp>
+
+using namespace microscopes;
+using namespace microscopes::common;
+
+#define CHECK(c)                                                        \
+  do {                                                                  \
+    if (!(c)) {                                                         \
+      std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); \
+      return 1;                                                         \
+    }                                                                   \
+  } while (0)
+
+static bool close_to(double a, double b, double tol = 2e-5) { return std::fabs(a - b) <= tol * std::max(1.0, std::fabs(b)); }
+
+#pragma pack(push, 1)
+struct Row {
+  bool b;
+  uint32_t c;
+  int32_t d;
+  float x;
+};
+#pragma pack(pop)
+
+int main() {
+  rng_t rng(5);
+  const size_t N = 300, KMAX = 24;
+  std::vector<Row> rows(N);
+  std::mt19937 gen(11);
+  for (size_t i = 0; i < N; i++) {
+    const int comp = int(i % 3);
+    rows[i].b = std::bernoulli_distribution(comp == 0 ? 0.9 : 0.2)(gen);
+    rows[i].c = uint32_t(std::poisson_distribution<int>(2 + 5 * comp)(gen));
+    rows[i].d = int32_t((comp * 2 + std::uniform_int_distribution<int>(0, 1)(gen)) % 6);
+    rows[i].x = float(std::normal_distribution<double>(4.0 * comp, 1.0)(gen));
+  }
+  const std::vector<runtime_type> types = {runtime_type(TYPE_B), runtime_type(TYPE_U32), runtime_type(TYPE_I32),
+                                           runtime_type(TYPE_F32)};
+  recarray::row_major_dataview data(reinterpret_cast<const uint8_t *>(rows.data()), nullptr, N, types);
+  std::vector<models::model_shared_ptr> mdl = {
+      std::make_shared<models::distributions_model<distributions::BetaBernoulli>>(),
+      std::make_shared<models::distributions_model<distributions::GammaPoisson>>(),
+      std::make_shared<models::distributions_model_dd128>(6),
+      std::make_shared<models::distributions_model<distributions::NormalInverseChiSq>>()};
+
+  hip::mixture_state st(mdl, data, KMAX);
+  entity_based_state_object &iface = st;                     // everything below goes through the reference's interface
+  CHECK(iface.nentities() == N && iface.ncomponents() == 4 && iface.ngroups() == 0);
+  iface.get_cluster_hp_mutator("alpha").set<float>(1.5f);
+  iface.get_component_hp_mutator(0, "alpha").set<float>(2.f);
+  iface.get_component_hp_mutator(0, "beta").set<float>(2.f);
+
+  // the host twin: one plugin group per (component, gid), driven by the same calls
+  std::vector<models::hypers_shared_ptr> hy;
+  for (auto &m : mdl) hy.push_back(m->create_hypers());
+  hy[0]->get_hp_mutator("alpha").set<float>(2.f);
+  hy[0]->get_hp_mutator("beta").set<float>(2.f);
+  std::map<size_t, std::vector<models::group_shared_ptr>> twin;
+  auto twin_group = [&](size_t gid) -> std::vector<models::group_shared_ptr> & {
+    auto it = twin.find(gid);
+    if (it == twin.end()) {
+      std::vector<models::group_shared_ptr> gs;
+      for (auto &h : hy) gs.push_back(h->create_group(rng));
+      it = twin.emplace(gid, gs).first;
+    }
+    return it->second;
+  };
+  auto twin_apply = [&](size_t gid, size_t eid, bool add) {
+    auto acc = data.get(eid);
+    auto &gs = twin_group(gid);
+    for (size_t f = 0; f < 4; f++, acc.bump()) {
+      if (add) gs[f]->add_value(*hy[f], acc.get(), rng);
+      else gs[f]->remove_value(*hy[f], acc.get(), rng);
+    }
+  };
+
+  // seed three groups entity by entity
+  std::vector<size_t> g0 = {iface.create_group(rng), iface.create_group(rng), iface.create_group(rng)};
+  CHECK(iface.ngroups() == 3 && iface.empty_groups().size() == 3);
+  for (size_t e = 0; e < N; e++) {
+    const size_t g = g0[(e + (e % 5 == 0)) % 3];              // every fifth entity starts in the wrong group
+    iface.add_value(g, e, rng);
+    twin_apply(g, e, true);
+  }
+  CHECK(iface.empty_groups().empty() && iface.groupsize(g0[0]) + iface.groupsize(g0[1]) + iface.groupsize(g0[2]) == N);
+  bool threw = false;
+  try { iface.add_value(g0[0], 0, rng); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);                                              // already assigned
+
+  // the Gibbs assignment kernel, entity by entity, for a stretch of entities
+  size_t moved = 0;
+  for (size_t e = 0; e < 60; e++) {
+    if (iface.empty_groups().empty()) iface.create_group(rng);
+    const size_t old = iface.remove_value(e, rng);
+    twin_apply(old, e, false);
+    auto sc = iface.score_value(e, rng);
+    CHECK(sc.first == iface.groups() && sc.second.size() == sc.first.size());
+    // against the twin: log pseudocount + sum of the components' score_value
+    for (size_t i = 0; i < sc.first.size(); i++) {
+      const size_t gid = sc.first[i];
+      const size_t cnt = iface.groupsize(gid);
+      double want = std::log(cnt ? double(cnt) : 1.5 / double(iface.empty_groups().size()));
+      auto acc = data.get(e);
+      auto &gs = twin_group(gid);
+      for (size_t f = 0; f < 4; f++, acc.bump()) want += gs[f]->score_value(*hy[f], acc.get(), rng);
+      CHECK(close_to(sc.second[i], want));
+    }
+    const size_t pick = sc.first[util::sample_discrete_log(sc.second, rng)];
+    iface.add_value(pick, e, rng);
+    twin_apply(pick, e, true);
+    moved += pick != old;
+    for (size_t gid : iface.empty_groups())                  // keep exactly one empty group around
+      if (iface.empty_groups().size() > 1) iface.delete_group(gid);
+  }
+  CHECK(moved > 0);
+  size_t total = 0;
+  for (size_t gid : iface.groups()) total += iface.groupsize(gid);
+  CHECK(total == N);
+
+  // likelihoods and bags against the twin
+  for (size_t gid : iface.groups())
+    for (size_t f = 0; f < 4; f++) {
+      CHECK(close_to(iface.score_likelihood(f, gid, rng), twin_group(gid)[f]->score_data(*hy[f], rng), 1e-4));
+      if (f == 0 || f == 2) CHECK(iface.get_suffstats(f, gid) == twin_group(gid)[f]->get_ss());   // integer suff-stats: same bytes
+    }
+  double lsum = 0;
+  for (size_t gid : iface.groups()) lsum += twin_group(gid)[3]->score_data(*hy[3], rng);
+  CHECK(close_to(iface.score_likelihood(3, rng), lsum, 1e-4));
+  CHECK(std::isfinite(iface.score_assignment()));
+
+  // set_suffstats round trip: overwrite a group's gp stats with another group's
+  {
+    const auto gs = iface.groups();
+    const auto bag = iface.get_suffstats(1, gs[0]);
+    const auto keep = iface.get_suffstats(1, gs[1]);
+    iface.set_suffstats(1, gs[1], bag);
+    CHECK(iface.get_suffstats(1, gs[1]) == bag);
+    CHECK(close_to(iface.score_likelihood(1, gs[1], rng), iface.score_likelihood(1, gs[0], rng), 1e-6));
+    iface.set_suffstats(1, gs[1], keep);
+  }
+
+  // a hyper-parameter written through a mutator reaches the device before the next score
+  {
+    const size_t gid = iface.groups()[0];
+    const float before = iface.score_likelihood(3, gid, rng);
+    iface.get_component_hp_mutator(3, "kappa").set<float>(7.f);
+    hy[3]->get_hp_mutator("kappa").set<float>(7.f);
+    const float after = iface.score_likelihood(3, gid, rng);
+    CHECK(before != after && close_to(after, twin_group(gid)[3]->score_data(*hy[3], rng), 1e-4));
+  }
+
+  // the batched sweep: the partition stays a partition, group sizes follow, tables equal a rebuild from scratch
+  {
+    for (int sweep = 0; sweep < 3; sweep++) st.gibbs_sweep(99, uint64_t(sweep), rng);
+    const auto as = iface.assignments();
+    std::map<size_t, size_t> cnt;
+    for (ssize_t a : as) {
+      CHECK(a >= 0);
+      cnt[size_t(a)]++;
+    }
+    for (size_t gid : iface.groups()) CHECK(iface.groupsize(gid) == (cnt.count(gid) ? cnt[gid] : 0));
+    for (const auto &c : cnt) CHECK(iface.groupsize(c.first) == c.second);
+    // a fresh state given the same partition in one call holds the same integer suff-stats
+    hip::mixture_state st2(mdl, data, KMAX);
+    st2.get_cluster_hp_mutator("alpha").set<float>(1.5f);
+    std::vector<size_t> labels(as.begin(), as.end());
+    st2.assign_all(labels, rng);
+    std::map<size_t, std::string> by_size_a, by_size_b;      // compare through a key that does not depend on ids
+    for (size_t gid : iface.groups())
+      if (iface.groupsize(gid)) by_size_a[iface.groupsize(gid) * 1000003 + size_t(as.end() - std::find(as.begin(), as.end(), ssize_t(gid)))] = iface.get_suffstats(2, gid);
+    const auto as2 = st2.assignments();
+    for (size_t gid : st2.groups())
+      if (st2.groupsize(gid)) by_size_b[st2.groupsize(gid) * 1000003 + size_t(as2.end() - std::find(as2.begin(), as2.end(), ssize_t(gid)))] = st2.get_suffstats(2, gid);
+    CHECK(by_size_a == by_size_b);
+  }
+  std::printf("test_mixture_state_gpu ok\n");
+  return 0;
+}

@@ -92,3 +92,14 @@ def test_perf_group_harness_runs():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bin")])
     out = subprocess.check_output([os.path.join(ROOT, "bin", "perf_group_hip"), "64", "2"]).decode()
     assert "noop virtual API" in out and "bb batched C ABI" in out and "score_value evals/s" in out
+
+
+def test_mixture_state_builds_against_the_reference_interface_names():
+    """the entity_based_state_object implementation compiles and links as downstream code would use it (no device call)"""
+    _cxx(os.path.join(ROOT, "tests", "cxx", "test_mixture_state_gpu.cpp"), "test_mixture_state_gpu", LINK)
+
+
+@pytest.mark.gpu
+def test_mixture_state_per_entity_gibbs_and_batched_sweep():
+    exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_mixture_state_gpu.cpp"), "test_mixture_state_gpu", LINK)
+    assert "test_mixture_state_gpu ok" in subprocess.check_output([exe]).decode()
