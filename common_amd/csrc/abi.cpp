@@ -883,7 +883,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   hipStream_t s = st->ctx->stream;
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+    if (launch_loo_own(s, st->ctx->num_cus, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
   }
   uint32_t n_niw = 0;
@@ -1127,7 +1127,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
-      if (launch_loo_own(s, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      if (launch_loo_own(s, st->ctx->num_cus, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
     if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);

@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
                                                   uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                   const int32_t *__restrict__ z,
                                                   const float *__restrict__ crp, float *__restrict__ own) {
+  // (one thread per row.  Sharing a row among 2-16 lanes, a feature each, was tried for small inputs: the
+  // descriptor loads stop being scalar, 10k rows x 12 features go from 13 to 9 us and everything larger gets
+  // slower -- 100k rows 20 -> 29 us, C3 0.49 -> 0.66 ms even at one lane per row)
   const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nrows) return;
   const int g = z[n];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
                                                                  const float *__restrict__ own,
                                                                  const float *__restrict__ crp,
                                                                  float *__restrict__ out, uint64_t ld) {
-  __shared__ float4 lds[kGrpRows * 64];
+  __shared__ float4 lds[kGrpRows * 64 + (LOO ? W * 64 : 0)];       // the table slot (+ a KiB per wave for the LOO epilogue)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -363,25 +366,38 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
       }
     }
     score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
+    if (LOO) {
+      // The own group's entry becomes the row's pre-computed leave-one-out value (k_loo_own): row by row through a
+      // KiB of LDS that belongs to the wave (beyond the table slot, so no barrier) -- park the row, one lane
+      // overwrites the entry, read the row back.  Ways that cost more: merging the value into the owning lane's float4
+      // in registers (replace_own per row; the tiling has no SGPRs / VGPRs left: 60-100 bytes of scratch per lane,
+      // C3 +13 %); a 4-byte store after the row stores (needs a fence and cached stores, +45 %); a pass of its own
+      // over the finished matrix (a million random read-modify-writes in HBM, +12 %); all rows parked in the table
+      // slot (one more barrier per chunk, +8 %).
+      float4 *mine = lds + (size_t)kGrpRows * 64 + (size_t)wave * 64;
+      int gz = -1;
+      float sloo = 0.f;
+      if (lane < nr) {
+        gz = z[rb + lane];
+        sloo = own[rb + lane];
+      }
+      if (gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (r < nr) {
-        store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);      // (LOO: k_loo_patch then overwrites the own group's entry)
+      for (int r = 0; r < R; r++) {
+        const int g = lane_bcast(gz, r);
+        if (g >= 0) {                                     // (wave-uniform)
+          mine[lane] = acc[r];
+          if (lane == 0) reinterpret_cast<float *>(mine)[(uint32_t)g % kGroupTile] = lane_bcast(sloo, r);
+          __builtin_amdgcn_wave_barrier();
+          acc[r] = mine[lane];
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
+    }
   }
-}
-
-// Leave-one-out, tile path: the entry of the row's own group becomes the pre-computed own[n] (k_loo_own).  A pass of
-// its own -- one 4-byte write per row, ~64 MB of sector traffic per million rows -- because doing it in the tile
-// kernel's epilogue cost the 16-wave tiling its last registers (60-100 bytes of scratch per lane: C3 3.01 ms against
-// 2.60 ms plain, and 2x at small K).  The LOO flag of k_score_tile now only selects the row's empty-group prior.
-__global__ __launch_bounds__(256) void k_loo_patch(const int32_t *__restrict__ z, const float *__restrict__ own, uint32_t K,
-                                                    uint64_t nrows, float *__restrict__ out, uint64_t ld) {
-  const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= nrows) return;
-  const int g = z[n];
-  if (g >= 0 && (uint32_t)g < K) out[n * ld + (uint32_t)g] = own[n];
 }
 
 // ---------------------------------------------------------------------------
@@ -453,8 +469,9 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_loo_own(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
+int launch_loo_own(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own) {
+  (void)num_cus;
   hipLaunchKernelGGL(k_loo_own, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
                      kpad, row0, nrows, z, crp, own);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -536,8 +553,6 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
     else
       hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
-    if (LOO && nrows > 0)
-      hipLaunchKernelGGL(k_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, z, own, K, nrows, out, ld);
   }
 }
 
