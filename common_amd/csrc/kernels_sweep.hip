@@ -39,23 +39,27 @@ template <int CTRL, int ROW_MASK>
 MSC_DEV float dpp_f32(float identity, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+// Both reductions are written as the DPP instruction itself: "v_op_dpp v, v, v <ctrl>" computes op(moved v, v) in the
+// lanes that have a source and leaves the others alone, which is what a shift-reduction wants.  From the builtins
+// hipcc makes a v_mov_b32_dpp with a fill value, the op, and (for fmaxf, IEEE mode) a canonicalising v_max on top:
+// 3 instructions a step instead of 1.  s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.
+#define MSC_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
 MSC_DEV float wave_max(float v) {
-  const float ninf = -INFINITY;
-  v = fmaxf(v, dpp_f32<0x111, 0xf>(ninf, v));   // row_shr:1
-  v = fmaxf(v, dpp_f32<0x112, 0xf>(ninf, v));   // row_shr:2
-  v = fmaxf(v, dpp_f32<0x114, 0xf>(ninf, v));   // row_shr:4
-  v = fmaxf(v, dpp_f32<0x118, 0xf>(ninf, v));   // row_shr:8
-  v = fmaxf(v, dpp_f32<0x142, 0xa>(ninf, v));   // row_bcast:15 -> rows 1, 3
-  v = fmaxf(v, dpp_f32<0x143, 0xc>(ninf, v));   // row_bcast:31 -> rows 2, 3
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");   // -> rows 1, 3
+  MSC_DPP_STEP("v_max_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");   // -> rows 2, 3
   return lane_bcast(v, 63);                      // lane 63 now holds the maximum over the wave
 }
 MSC_DEV float wave_incl_scan(float v, int) {
-  v += dpp_f32<0x111, 0xf>(0.f, v);
-  v += dpp_f32<0x112, 0xf>(0.f, v);
-  v += dpp_f32<0x114, 0xf>(0.f, v);
-  v += dpp_f32<0x118, 0xf>(0.f, v);
-  v += dpp_f32<0x142, 0xa>(0.f, v);
-  v += dpp_f32<0x143, 0xc>(0.f, v);
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  MSC_DPP_STEP("v_add_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
   return v;
 }
 
