@@ -43,23 +43,22 @@ MSC_DEV float dpp_f32(float identity, float v) {
 // lanes that have a source and leaves the others alone, which is what a shift-reduction wants.  From the builtins
 // hipcc makes a v_mov_b32_dpp with a fill value, the op, and (for fmaxf, IEEE mode) a canonicalising v_max on top:
 // 3 instructions a step instead of 1.  s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.
-#define MSC_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+// (one asm block per reduction, so that exactly the needed wait states sit between the steps)
+#define MSC_DPP_REDUCE(op, v)                                                     \
+  asm volatile("s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
+               "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"      \
+               "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"      \
+               "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"      \
+               "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"   \
+               "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"   \
+               "s_nop 1"                                                          \
+               : "+v"(v))
 MSC_DEV float wave_max(float v) {
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");   // -> rows 1, 3
-  MSC_DPP_STEP("v_max_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");   // -> rows 2, 3
+  MSC_DPP_REDUCE("v_max_f32_dpp", v);            // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3
   return lane_bcast(v, 63);                      // lane 63 now holds the maximum over the wave
 }
 MSC_DEV float wave_incl_scan(float v, int) {
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-  MSC_DPP_STEP("v_add_f32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  MSC_DPP_REDUCE("v_add_f32_dpp", v);
   return v;
 }
 
