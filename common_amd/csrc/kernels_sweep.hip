@@ -67,20 +67,38 @@ MSC_DEV float wave_incl_scan(float v, int) {
 // exponentiate, and return the first k whose running sum reaches dart * total; K-1 if
 // rounding lets the dart fall off the end (util.hpp:155).
 // LOG2: the scores are already in units of log2 (the caller folded log2(e) into its constants).
-template <int G, bool LOG2 = false>
-MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_t K) {
-  float m = s[0];
+// BOUND: `bound` is a wave-uniform upper bound of the scores the caller knows without looking at them; it stands in
+// for the maximum (6 DPP steps + 4 compares saved per row) whenever the total it leads to is a comfortably normal float,
+// and the exact maximum is taken otherwise (an outlier row far below the bound, or a bound that was not one).
+template <int G, bool LOG2 = false, bool BOUND = false>
+MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_t K, float bound = 0.f) {
+  float p[G], sum = 0.f, incl = 0.f, total = 0.f;
+  bool done = false;
+  if (BOUND) {
+    sum = 0.f;
 #pragma unroll
-  for (int j = 1; j < G; j++) m = fmaxf(m, s[j]);
-  m = wave_max(m);
-  float p[G], sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < G; j++) {
-    p[j] = __builtin_amdgcn_exp2f(LOG2 ? s[j] - m : (s[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
-    sum += p[j];
+    for (int j = 0; j < G; j++) {
+      p[j] = __builtin_amdgcn_exp2f(LOG2 ? s[j] - bound : (s[j] - bound) * 1.44269504088896340736f);
+      sum += p[j];
+    }
+    incl = wave_incl_scan(sum, lane);
+    total = lane_bcast(incl, 63);
+    done = total > 0x1p-60f && total < 0x1p100f;        // (false for NaN too)
   }
-  const float incl = wave_incl_scan(sum, lane);
-  const float total = lane_bcast(incl, 63);
+  if (!done) {
+    float m = s[0];
+#pragma unroll
+    for (int j = 1; j < G; j++) m = fmaxf(m, s[j]);
+    m = wave_max(m);
+    sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      p[j] = __builtin_amdgcn_exp2f(LOG2 ? s[j] - m : (s[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
+      sum += p[j];
+    }
+    incl = wave_incl_scan(sum, lane);
+    total = lane_bcast(incl, 63);
+  }
   const float dart = u01 * total;
   // the running sum is monotone, so the first entry that reaches the dart is found by counting the
   // entries that do not; entries with k >= K have p = 0 and cannot be the first
@@ -156,6 +174,13 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     c1s[j] = c1[j] * kLog2e;
     emp[j] = empty ? kLog2e : 0.f;
   }
+  // no score exceeds its c0' (log1p >= 0) plus what the empty-group prior can add; the own group's leave-one-out
+  // value and a masked row's prior-only scores may, by a little: 16 bits of headroom, and sample_from_scores checks
+  float bound = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < G; j++)
+    if (kb + j < K) bound = fmaxf(bound, c0s[j] + emp[j] * fmaxf(0.f, fmaxf(__builtin_isinf(le0) ? 0.f : le0, le1)));
+  bound = wave_max(bound) + 16.f;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
   // a wave takes chunk_rows (<= 64) rows at a time, one per lane for the per-row setup, then scores them one after
   // the other: the rows of a chunk are a serial chain, so few rows want short chunks spread over many waves
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
         for (int j = 0; j < G; j++)
           if (j == g % G) s[j] = sl;
       }
-      const int pick = sample_from_scores<G, true>(s, lane_bcast(u01, r), lane, K);
+      const int pick = sample_from_scores<G, true, true>(s, lane_bcast(u01, r), lane, K, bound);
       if (lane == r) znew = pick;
     }
     if (has_row) z[rb + lane] = znew;
