@@ -150,3 +150,26 @@ def test_sweep_draws_follow_the_softmax_of_the_scores(gpu_ctx):
     p = np.exp(s - s.max())
     p /= p.sum()
     assert np.abs(emp - p).max() < 4 * np.sqrt(0.25 / N) + 1e-3, (emp, p)
+
+
+def test_sweep_rows_far_below_the_score_bound_take_the_exact_maximum(gpu_ctx):
+    """k_sweep_nich1 normalises with a per-wave upper bound of the scores and falls back to the row's exact maximum
+    when that underflows: rows thousands of bits below the bound (outliers), next to ordinary rows in the same wave"""
+    import common_amd
+    N, K, seed, sweep_idx = 3000, 40, 17, 4
+    rng = np.random.default_rng(seed)
+    f = make_feature(orc.NICH, N, K, rng)
+    far = rng.choice(N, 400, replace=False)
+    f["values"][far] = (rng.choice([-1.0, 1.0], 400) * 10.0 ** rng.uniform(3, 7, 400)).astype(np.float32)
+    z = rng.integers(0, K - 2, N).astype(np.int32)
+    z[far[:5]] = K - 3                                     # a small group made of outliers only
+    fs = state_from_assignment([f], K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of([f]))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(2.5)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
+    want, scores = orc.sweep([(fs[0][0], fs[0][1], f["values"])], K, 2.5, z, seed, sweep_idx, "f64", want_scores=True)
+    _check_agreement(zt.cpu().numpy(), want, scores, seed, sweep_idx, 0.995)
