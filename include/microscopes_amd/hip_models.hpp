@@ -517,6 +517,101 @@ template <> struct bag<NormalInverseWishartV> {
   }
 };
 
+// ---- sample_value (base.hpp:29): one draw from the group's posterior predictive ---------------------------------
+// Host-side, from the Shared / Group structs alone: it is not on the scoring path and there is no stream of the
+// reference's to reproduce (its draws come from the absent library with the caller's std engine), so these are the
+// textbook samplers of the predictives that score_value scores (SURVEY 8a formulas), driven by the caller's rng_t.
+template <typename T> struct sampler {
+  static void draw(const typename T::Shared &, const typename T::Group &, common::value_mutator &, common::rng_t &) {
+    throw std::runtime_error("sample_value is not implemented for this model");      // dm: as upstream (dm.cpp:100-111)
+  }
+};
+inline double draw_gamma(double shape, double scale, common::rng_t &rng) { return std::gamma_distribution<double>(shape, scale)(rng); }
+inline double draw_beta(double a, double b, common::rng_t &rng) {
+  const double x = draw_gamma(a, 1.0, rng), y = draw_gamma(b, 1.0, rng);
+  return x / (x + y);
+}
+template <> struct sampler<BetaBernoulli> {
+  static void draw(const BetaBernoulli::Shared &s, const BetaBernoulli::Group &g, common::value_mutator &v, common::rng_t &rng) {
+    const double p = (double(s.alpha) + g.heads) / (double(s.alpha) + s.beta + g.heads + g.tails);
+    v.set<bool>(std::bernoulli_distribution(p)(rng));
+  }
+};
+template <> struct sampler<distributions::BetaBernoulliNonConj> {
+  typedef distributions::BetaBernoulliNonConj T;
+  static void draw(const T::Shared &, const T::Group &g, common::value_mutator &v, common::rng_t &rng) {
+    v.set<bool>(std::bernoulli_distribution(g.p)(rng));                              // bbnc.cpp:76-82
+  }
+};
+template <> struct sampler<GammaPoisson> {
+  static void draw(const GammaPoisson::Shared &s, const GammaPoisson::Group &g, common::value_mutator &v, common::rng_t &rng) {
+    const double rate = draw_gamma(double(s.alpha) + g.sum, 1.0 / (double(s.inv_beta) + g.count), rng);
+    v.set<uint32_t>(uint32_t(std::poisson_distribution<uint64_t>(rate)(rng)));
+  }
+};
+template <> struct sampler<distributions::BetaNegativeBinomial> {
+  typedef distributions::BetaNegativeBinomial T;
+  static void draw(const T::Shared &s, const T::Group &g, common::value_mutator &v, common::rng_t &rng) {
+    const double p = draw_beta(double(s.alpha) + double(s.r) * g.count, double(s.beta) + g.sum, rng);
+    const double rate = draw_gamma(double(s.r), (1.0 - p) / p, rng);                 // failures before the r-th success
+    v.set<uint32_t>(uint32_t(std::poisson_distribution<uint64_t>(rate)(rng)));
+  }
+};
+template <> struct sampler<DD128> {
+  static void draw(const DD128::Shared &s, const DD128::Group &g, common::value_mutator &v, common::rng_t &rng) {
+    double total = 0;
+    for (int i = 0; i < s.dim; i++) total += double(s.alphas[i]) + g.counts[i];
+    double dart = std::uniform_real_distribution<double>(0.0, total)(rng);
+    int pick = s.dim - 1;
+    for (int i = 0; i < s.dim; i++)
+      if ((dart -= double(s.alphas[i]) + g.counts[i]) <= 0.0) {
+        pick = i;
+        break;
+      }
+    v.set<int>(pick);
+  }
+};
+template <> struct sampler<NormalInverseChiSq> {
+  static void draw(const NormalInverseChiSq::Shared &s, const NormalInverseChiSq::Group &g, common::value_mutator &v,
+                   common::rng_t &rng) {
+    const double n = g.count, kn = double(s.kappa) + n, nun = double(s.nu) + n;
+    const double mun = (double(s.kappa) * s.mu + n * g.mean) / kn, d = double(s.mu) - g.mean;
+    const double sigsq = (double(s.nu) * s.sigmasq + g.count_times_variance + n * s.kappa * d * d / kn) / nun;
+    const double t = std::student_t_distribution<double>(nun)(rng);
+    v.set<float>(float(mun + std::sqrt(sigsq * (kn + 1.0) / kn) * t));
+  }
+};
+template <> struct sampler<NormalInverseWishartV> {
+  static void draw(const NormalInverseWishartV::Shared &s, const NormalInverseWishartV::Group &g, common::value_mutator &v,
+                   common::rng_t &rng) {
+    const unsigned d = s.dim();
+    const double n = g.count, kn = double(s.kappa) + n, nun = double(s.nu) + n, dof = nun - double(d) + 1.0;
+    std::vector<double> mun(d), L(std::size_t(d) * d, 0.0), z(d);
+    for (unsigned i = 0; i < d; i++) mun[i] = (double(s.kappa) * s.mu[i] + g.sum_x[i]) / kn;
+    // Sigma = Psi_n (kn + 1) / (kn dof), Psi_n = Psi + sum xxT + kappa mu muT - kn mun munT; lower Cholesky in place
+    const double scale = (kn + 1.0) / (kn * dof);
+    for (unsigned i = 0; i < d; i++)
+      for (unsigned j = 0; j <= i; j++) {
+        double a = (double(s.psi[std::size_t(i) * d + j]) + g.sum_xxT[std::size_t(i) * d + j] +
+                    double(s.kappa) * s.mu[i] * s.mu[j] - kn * mun[i] * mun[j]) * scale;
+        for (unsigned k = 0; k < j; k++) a -= L[std::size_t(i) * d + k] * L[std::size_t(j) * d + k];
+        if (i == j) {
+          if (!(a > 0.0)) throw std::runtime_error("niw posterior scale matrix is not positive definite");
+          L[std::size_t(i) * d + i] = std::sqrt(a);
+        } else {
+          L[std::size_t(i) * d + j] = a / L[std::size_t(j) * d + j];
+        }
+      }
+    for (double &zi : z) zi = std::normal_distribution<double>()(rng);
+    const double w = std::sqrt(dof / std::chi_squared_distribution<double>(dof)(rng));
+    for (unsigned i = 0; i < d; i++) {
+      double x = 0;
+      for (unsigned k = 0; k <= i; k++) x += L[std::size_t(i) * d + k] * z[k];
+      v.set<float>(float(mun[i] + w * x), i);
+    }
+  }
+};
+
 }  // namespace detail
 
 template <typename T> class distributions_hypers;
@@ -539,8 +634,8 @@ public:
   float score_data(const hypers &m, common::rng_t &) const override {
     return const_cast<distributions_group *>(this)->run(MSC_OP_SCORE_DATA, m, nullptr);
   }
-  void sample_value(const hypers &, common::value_mutator &, common::rng_t &) const override {
-    throw std::runtime_error("sample_value: not on the scoring path, not built for the HIP backend");
+  void sample_value(const hypers &m, common::value_mutator &value, common::rng_t &rng) const override {
+    detail::sampler<T>::draw(static_cast<const distributions_hypers<T> &>(m).repr_, repr_, value, rng);
   }
   common::suffstats_bag_t get_ss() const override { return detail::bag<T>::dump(repr_); }
   void set_ss(const common::suffstats_bag_t &ss) override { detail::bag<T>::load(repr_, ss); }

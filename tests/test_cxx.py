@@ -103,3 +103,9 @@ def test_mixture_state_builds_against_the_reference_interface_names():
 def test_mixture_state_per_entity_gibbs_and_batched_sweep():
     exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_mixture_state_gpu.cpp"), "test_mixture_state_gpu", LINK)
     assert "test_mixture_state_gpu ok" in subprocess.check_output([exe]).decode()
+
+
+def test_sample_value_draws_from_the_posterior_predictive():
+    """host-side samplers of the device-backed models (no device call): moments against the closed forms"""
+    exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_sample_value.cpp"), "test_sample_value", LINK)
+    assert "test_sample_value ok" in subprocess.check_output([exe]).decode()
