@@ -826,12 +826,31 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
   return upload_desc(st);
 }
 
+static uint32_t dm_value_slices(const msc_feature_host &h) {
+  uint32_t rows = 1;
+  for (size_t i = 1; i < h.dm_meta.size(); i += 2) rows = std::max(rows, h.dm_meta[i]);     // {first_row, vcap} per stage
+  return std::min<uint32_t>(64, (rows + 3) / 4);
+}
+
+// threads per (feature, group) that share the rows of a count / categorical table in the prepare kernels: ~4 rows each
+static uint32_t prepare_value_slices(const msc_state *st) {
+  static const int forced = std::getenv("MSC_PREPARE_SLICES") ? std::atoi(std::getenv("MSC_PREPARE_SLICES")) : 0;   // tuning knob
+  if (forced > 0) return (uint32_t)forced;
+  uint32_t rows = 1;
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    const int fam = st->feats[f].family;
+    if (is_count_family(fam)) rows = std::max(rows, st->desc_host[f].vcap);
+    else if (fam == MSC_DD) rows = std::max(rows, st->feats[f].dim);
+  }
+  return std::min<uint32_t>(64, (rows + 3) / 4);
+}
+
 static int ensure_derived(msc_state *st) {
   MSC_TRY(ensure_raw(st));
   bool any = false;
   for (auto &h : st->feats) any |= !h.derived_valid;
   if (!any) return MSC_OK;
-  if (launch_prepare(st->ctx->stream, st->desc_dev, st->nfeat, st->kpad))
+  if (launch_prepare(st->ctx->stream, st->desc_dev, st->nfeat, st->kpad, prepare_value_slices(st)))
     return fail(MSC_EHIP, "k_prepare launch failed");
   for (uint32_t f = 0; f < st->nfeat; f++)
     if (st->feats[f].family == MSC_NIW && !st->feats[f].derived_valid &&
@@ -839,7 +858,7 @@ static int ensure_derived(msc_state *st) {
       return fail(MSC_EHIP, "k_niw_prepare launch failed");
   for (uint32_t f = 0; f < st->nfeat; f++)
     if (st->feats[f].family == MSC_DM && !st->feats[f].derived_valid && st->desc_host[f].dm_meta != nullptr &&
-        launch_dm_prepare(st->ctx->stream, st->desc_dev, (int)f, st->feats[f].dim, st->kpad))
+        launch_dm_prepare(st->ctx->stream, st->desc_dev, (int)f, st->feats[f].dim, st->kpad, dm_value_slices(st->feats[f])))
       return fail(MSC_EHIP, "k_dm_prepare launch failed");
   for (auto &h : st->feats) h.derived_valid = true;
   return MSC_OK;
@@ -996,7 +1015,7 @@ enum : uint32_t { kAccZeroed = 0x100, kAccThenPrepare = 0x200 };
 static int commit_and_prepare(msc_state *st) {
   hipStream_t s = st->ctx->stream;
   if (launch_commit_prepare(s, st->desc_dev, (int)st->nfeat, st->K, st->kpad, st->red_i64, st->cnt_u32, st->alpha,
-                            st->logpc, st->rng_dev))
+                            st->logpc, st->rng_dev, prepare_value_slices(st)))
     return fail(MSC_EHIP, "k_commit_prepare launch failed");
   for (uint32_t f = 0; f < st->nfeat; f++) {
     const msc_feature_host &h = st->feats[f];
@@ -1004,7 +1023,7 @@ static int commit_and_prepare(msc_state *st) {
                                 launch_niw_prepare(s, st->desc_dev, f, h.dim, st->K, st->kpad)))
       return fail(MSC_EHIP, "niw commit / prepare launch failed");
     if (h.family == MSC_DM && st->desc_host[f].dm_meta != nullptr &&
-        launch_dm_prepare(s, st->desc_dev, (int)f, h.dim, st->kpad))
+        launch_dm_prepare(s, st->desc_dev, (int)f, h.dim, st->kpad, dm_value_slices(h)))
       return fail(MSC_EHIP, "k_dm_prepare launch failed");
   }
   for (auto &h : st->feats) { h.raw_valid = true; h.derived_valid = true; }

@@ -28,7 +28,11 @@ namespace msc {
 // prepare: one thread per (feature, group slot); pads (k >= K) are prepared from their
 // zeroed raw stats so that vector loads of a full tile stay finite.
 // ---------------------------------------------------------------------------
-MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad) {
+// (z, nz): the table rows of the count / categorical families are dealt out over nz threads per (feature, group) --
+// a column with counts up to 1000 would otherwise be ~2000 lgamma chains in a row per thread; what a group needs
+// once is done by z = 0
+MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32_t z, uint32_t nz) {
+  if (z != 0 && fd.family != MSC_GP && fd.family != MSC_BNB && fd.family != MSC_DD) return;
   switch (fd.family) {
     case MSC_BB: {
       float s0, s1;
@@ -49,28 +53,28 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad) {
     } break;
     case MSC_GP: {
       const uint32_t cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
-      gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
-      for (uint32_t v = 0; v < fd.vcap; v++)
+      if (z == 0) gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
+      for (uint32_t v = z; v < fd.vcap; v += nz)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
       if (fd.loo_tab != nullptr)
-        for (uint32_t v = 0; v < fd.vcap; v++)
+        for (uint32_t v = z; v < fd.vcap; v += nz)
           fd.loo_tab[(size_t)v * kpad + k] = (cnt >= 1 && sum >= v) ? (float)gp_loo(fd.hp, cnt, sum, v) : 0.f;
     } break;
     case MSC_BNB: {
       const double cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
-      for (uint32_t v = 0; v < fd.vcap; v++)
+      for (uint32_t v = z; v < fd.vcap; v += nz)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = (float)bnb_score(fd.hp, cnt, sum, (double)v);
       if (fd.loo_tab != nullptr)
-        for (uint32_t v = 0; v < fd.vcap; v++)
+        for (uint32_t v = z; v < fd.vcap; v += nz)
           fd.loo_tab[(size_t)v * kpad + k] = (cnt >= 1.0 && sum >= (double)v) ? (float)bnb_score(fd.hp, cnt - 1.0, sum - (double)v, (double)v) : 0.f;
     } break;
     case MSC_DD: {
       const uint32_t csum = fd.raw_u32[k];
-      for (uint32_t i = 0; i < fd.dim; i++)
+      for (uint32_t i = z; i < fd.dim; i += nz)
         fd.tab[(size_t)i * kpad + k] =
             dd_prepare_entry(fd.hp[i], fd.raw_u32[(size_t)(1 + i) * kpad + k], fd.aux, csum);
       if (fd.loo_tab != nullptr)
-        for (uint32_t i = 0; i < fd.dim; i++) {
+        for (uint32_t i = z; i < fd.dim; i += nz) {
           const uint32_t c = fd.raw_u32[(size_t)(1 + i) * kpad + k];
           fd.loo_tab[(size_t)i * kpad + k] = c ? (float)dd_loo(fd.hp[i], c, fd.aux, csum) : 0.f;
         }
@@ -89,7 +93,7 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad) {
 __global__ __launch_bounds__(256) void k_prepare(const FeatDesc *__restrict__ feats, uint32_t kpad) {
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= kpad) return;
-  prepare_group(feats[blockIdx.y], k, kpad);
+  prepare_group(feats[blockIdx.y], k, kpad, blockIdx.z, gridDim.z);
 }
 
 // dm tables: blockIdx.y = stage (category i < dim, or dim = the row total); one thread per group slot
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__
   } else {
     for (uint32_t i = 0; i < fd.dim; i++) n += (double)fd.raw_u32[(size_t)i * kpad + k];
   }
-  for (uint32_t v = 0; v < rows; v++) {
+  for (uint32_t v = blockIdx.z; v < rows; v += gridDim.z) {   // (table rows dealt out over the z-slices, as in k_prepare)
     const double term = sub < fd.dim ? dm_cat_term(a, n, (double)v) : dm_sum_term(fd.aux, n, (double)v);
     dm_split(term, t[(size_t)(2 * v) * kpad], t[(size_t)(2 * v + 1) * kpad]);
   }
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_commit_prepare(const FeatDesc *__restri
                                                          uint32_t *__restrict__ cnt_u32, float alpha,
                                                          float *__restrict__ crp, uint64_t *__restrict__ rng_bump) {
   if ((int)blockIdx.y == nfeat) {
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || blockIdx.z != 0) return;
     for (uint32_t k = threadIdx.x; k < kpad; k += 256) cnt_u32[k] = (uint32_t)cnt_acc[k];
     __syncthreads();                                   // (each thread reads back what it wrote; the barrier is for s_empty's init)
     crp_prepare_block(cnt_u32, K, kpad, alpha, crp);
@@ -158,8 +162,9 @@ __global__ __launch_bounds__(256) void k_commit_prepare(const FeatDesc *__restri
   if (k >= kpad) return;
   const FeatDesc fd = feats[blockIdx.y];
   if (fd.family == MSC_NIW) return;                    // (its own commit / prepare kernels)
-  commit_group(fd, k, kpad);
-  prepare_group(fd, k, kpad);
+  if (blockIdx.z != 0 && fd.family != MSC_GP && fd.family != MSC_BNB && fd.family != MSC_DD) return;
+  commit_group(fd, k, kpad);                           // (every value slice commits: same numbers, and each reads back its own)
+  prepare_group(fd, k, kpad, blockIdx.z, gridDim.z);
 }
 
 // ---------------------------------------------------------------------------
@@ -445,21 +450,22 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
 // ---------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp)
 // ---------------------------------------------------------------------------
-int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad) {
-  dim3 grid((kpad + 255) / 256, nfeat);
+int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad, uint32_t value_slices) {
+  dim3 grid((kpad + 255) / 256, nfeat, value_slices ? value_slices : 1);
   hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, stream, feats_dev, kpad);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad,
-                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump) {
-  hipLaunchKernelGGL(k_commit_prepare, dim3((kpad + 255) / 256, nfeat + 1), dim3(256), 0, stream, feats_dev, nfeat, K, kpad,
+                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump,
+                          uint32_t value_slices) {
+  hipLaunchKernelGGL(k_commit_prepare, dim3((kpad + 255) / 256, nfeat + 1, value_slices ? value_slices : 1), dim3(256), 0, stream, feats_dev, nfeat, K, kpad,
                      cnt_acc, cnt_u32, alpha, crp, rng_bump);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad) {
-  hipLaunchKernelGGL(k_dm_prepare, dim3((kpad + 255) / 256, dim + 1), dim3(256), 0, stream, feats_dev, f, kpad);
+int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad, uint32_t value_slices) {
+  hipLaunchKernelGGL(k_dm_prepare, dim3((kpad + 255) / 256, dim + 1, value_slices ? value_slices : 1), dim3(256), 0, stream, feats_dev, f, kpad);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -23,8 +23,8 @@ struct MailboxHeader {
 int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int family);
 
 // kernels_score.hip
-int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad);
-int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad);
+int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad, uint32_t value_slices);
+int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad, uint32_t value_slices);
 int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
                        float *crp);
 int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
@@ -82,7 +82,8 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
 int launch_commit(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
                   const long long *cnt_acc, uint32_t *cnt_u32);
 int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad,
-                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump);
+                          const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump,
+                          uint32_t value_slices);
 int launch_zero64(hipStream_t stream, void *a, size_t na, void *b, size_t nb);   // 8-byte words
 int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
                 long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt);
