@@ -1156,11 +1156,11 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;
-    // 64 MiB of scores stays in the Infinity Cache between the two kernels; a state with niw features is bound
-    // by its MFMA kernel instead, which wants >= 4 waves per SIMD: 256k rows per launch
-    bool has_niw = false;
-    for (auto &h : st->feats) has_niw |= h.family == MSC_NIW;
-    uint64_t chunk = ((has_niw ? 256ull : 64ull) << 20) / (ld * sizeof(float));
+    // 256 MiB of scores per chunk: measured on K = 300 .. 5000 (32 / 64 / 128 / 256 / 512 MiB: 1.88 / 1.55 / 1.28 /
+    // 1.13 / 1.05 ms for 1M rows x 300 groups), fewer and larger launches beat keeping the chunk cache-resident,
+    // and a state with niw features wants >= 4 waves per SIMD on its MFMA kernel anyway
+    static const uint64_t forced_mib = std::getenv("MSC_SWEEP_CHUNK_MIB") ? std::strtoull(std::getenv("MSC_SWEEP_CHUNK_MIB"), nullptr, 10) : 0;
+    uint64_t chunk = ((forced_mib ? forced_mib : 256ull) << 20) / (ld * sizeof(float));
     if (chunk == 0) chunk = 1;
     if (chunk > nrows) chunk = nrows;
     if (st->scratch_floats < chunk * ld) {
