@@ -978,7 +978,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
       st->niw_qown = static_cast<double *>(p);
       st->niw_qown_cap = nrows;
     }
-    if (launch_niw_score(s, st->ctx->num_cus, st->desc_dev, f, st->K, st->kpad, row0, nrows, z_dev, written,
+    if (launch_niw_score(s, st->ctx->num_cus, st->desc_dev, f, st->feats[f].dim, st->K, st->kpad, row0, nrows, z_dev, written,
                          niw_f32, st->niw_qown, out_dev, ld_out))
       return fail(MSC_EHIP, "k_score_niw launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;

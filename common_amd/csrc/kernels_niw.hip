@@ -23,6 +23,9 @@
 //   C_k = (kappa_n+1)/(kappa_n-1),  B_k = (dof-1+d-1)/2,
 //   A_k = lgamma((dof-1+d)/2) - lgamma((dof-1)/2) - (d/2) ln((dof-1) pi)
 //         - logdet(Psi_n)/2 - (d/2) ln(kappa_n/((kappa_n-1)(dof-1)))
+#include <algorithm>
+#include <cstdlib>
+
 #include "family_math.hpp"
 #include "launchers.hpp"
 #include "score_block.hpp"
@@ -419,6 +422,86 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// dim <= 8: the padded 32 x 32 contraction above would spend 16 .. 256 times the arithmetic the problem has (a
+// 3-d niw feature scored at the rate of a 32-d one: 2.7e10 evals/s whatever the dimension).  Here a lane keeps one
+// group -- the lower triangle of W_k, W_k mu_k, c0, c1, all in double registers -- and the rows of a 64-row chunk
+// stream past it as wave-uniform values (lane r loads row r, v_readlane hands it round): D (D + 3) / 2 double fma
+// per evaluation on the vector pipe, the same float log1p epilogue, same own-group / mask protocol as
+// k_score_niw64.  grid.y = tiles of 64 groups; a row of 64 scores is one 256-byte store.
+// ---------------------------------------------------------------------------
+MSC_DEV double bcast_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_score_niw_small(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                          uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                          const int32_t *__restrict__ z, double *__restrict__ qown,
+                                                          float *__restrict__ out, uint64_t ld, int accum) {
+  const FeatDesc fd = feats[f];
+  const int lane = threadIdx.x & 63;
+  const uint32_t k = blockIdx.y * 64 + lane;
+  const bool has_k = k < K;
+  const size_t kc = has_k ? k : 0;
+  double w[D * (D + 1) / 2], nb[D];
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) w[i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
+    nb[i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];       // (the f64 MFMA kernel's slot order, k_niw_prepare)
+  }
+  const double c0 = fd.niw_c64[kc * 8], c1 = fd.niw_c64[kc * 8 + 1];
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const uint64_t nchunks = (nrows + 63) / 64;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
+    const uint64_t rb = chunk * 64;
+    const int nr = (int)((nrows - rb) < 64 ? (nrows - rb) : 64);
+    double xd[D];
+    int gz = -1;
+    bool msk = false;
+    if (lane < nr) {
+      const uint64_t row = row0 + rb + lane;
+#pragma unroll
+      for (int j = 0; j < D; j++) xd[j] = (double)X[row * D + j];
+      if (z != nullptr) gz = z[rb + lane];
+      if (fd.mask != nullptr)
+#pragma unroll
+        for (int j = 0; j < D; j++) msk |= fd.mask[row * D + j] != 0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; j++) xd[j] = 0.0;
+    }
+    const unsigned long long mbits = __builtin_amdgcn_ballot_w64(msk);
+    for (int r = 0; r < nr; r++) {
+      float *p = out + (rb + r) * ld + k;
+      if ((mbits >> r) & 1ull) {                          // a masked value adds nothing (wave-uniform branch)
+        if (!accum && has_k) *p = 0.f;
+        continue;
+      }
+      double x[D];
+#pragma unroll
+      for (int j = 0; j < D; j++) x[j] = bcast_f64(xd[j], r);
+      double q = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        double y = nb[i];                                 // W x - W mu
+#pragma unroll
+        for (int j = 0; j <= i; j++) y = fma(w[i * (i + 1) / 2 + j], x[j], y);
+        q = fma(y, y, q);
+      }
+      double sc = c0 - c1 * (double)log1p_acc((float)q);
+      const int g = __builtin_amdgcn_readlane(gz, r);
+      if (g >= 0 && (uint32_t)g == k) {                   // the own group: its value comes from k_niw_loo_patch
+        qown[rb + r] = q;
+        sc = 0.0;
+      }
+      if (has_k) *p = accum ? *p + (float)sc : (float)sc;
+    }
+  }
+}
+
 // leave-one-out value of every row's own group (closed form in the file header) from the q the score kernel
 // left in qown; the score kernel wrote 0 there, so this adds.  One thread per row.
 __global__ __launch_bounds__(256) void k_niw_loo_patch(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
@@ -626,9 +709,37 @@ static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, c
   }
 }
 
-int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+template <int D>
+static void launch_niw_small(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K, uint32_t kpad,
+                             uint64_t row0, uint64_t nrows, const int32_t *z, double *qown, float *out, uint64_t ld, bool accum) {
+  const uint32_t ktiles = (K + 63) / 64;
+  uint64_t gx = ((nrows + 63) / 64 + 3) / 4;
+  const uint64_t cap = std::max<uint64_t>(1, (uint64_t)num_cus * 8 / ktiles);
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_score_niw_small<D>, dim3((unsigned)(gx ? gx : 1), ktiles), dim3(256), 0, stream, feats_dev, f, K, kpad,
+                     row0, nrows, z, qown, out, ld, accum ? 1 : 0);
+  if (z != nullptr)
+    hipLaunchKernelGGL(k_niw_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, f, K, row0,
+                       nrows, z, qown, out, ld);
+}
+
+int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
                      uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
                      double *qown, float *out, uint64_t ld) {
+  static const bool no_small = std::getenv("MSC_NIW_NO_SMALL") != nullptr;      // (A/B knob)
+  if (!f32_fast && !no_small && dim >= 1 && dim <= 8 && nrows > 0) {
+    switch (dim) {
+      case 1: launch_niw_small<1>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 2: launch_niw_small<2>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 3: launch_niw_small<3>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 4: launch_niw_small<4>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 5: launch_niw_small<5>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 6: launch_niw_small<6>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      case 7: launch_niw_small<7>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+      default: launch_niw_small<8>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);

@@ -220,3 +220,40 @@ def test_leave_one_out_on_the_large_tiling(gpu_ctx, N, K):
     other[ok.nonzero().squeeze(1), zt[ok].long()] = False
     other[12345] = False                                   # (its empty-group columns carry the other prior)
     assert torch.equal(got[other], plain[other])           # everything but the own entries: the same bits
+
+
+@pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 16, 20])
+@pytest.mark.parametrize("K", [3, 70, 130])
+def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
+    """dim <= 8 runs the per-lane-group vector kernel (64-group tiles: K = 70 and 130 end in partial tiles), 9 .. 31
+    the zero-padded f64 MFMA kernel; plain, leave-one-out, accumulated on top of another feature, masked rows"""
+    import common_amd
+    N = 900
+    rng = np.random.default_rng(1000 * dim + K)
+    feats = [make_feature(orc.BB, N, K, rng), make_feature(orc.NIW, N, K, rng, dim)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[5] = -1
+    fs = state_from_assignment(feats, K, z)
+    rec = recarray_of(feats)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    # the niw feature alone (writes the matrix) and after a bb feature (adds to it)
+    for cols in ([1], [0, 1]):
+        sub = [feats[c] for c in cols]
+        view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(sub))
+        st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in sub], K)
+        load_state(st, [fs[c] for c in cols])
+        st.set_group_counts(np.bincount(z[z >= 0], minlength=K).astype(np.uint32))
+        assert rel_err(st.score_value(view).cpu().numpy(), oracle_scores(sub, [fs[c] for c in cols])).max() <= TOL
+        assert rel_err(st.score_value(view, z=zt).cpu().numpy(), oracle_scores(sub, [fs[c] for c in cols], z=z)).max() <= TOL
+    # masked vectors contribute nothing
+    mask = np.zeros(N, dtype=[("f0", np.bool_), ("f1", np.bool_, (dim,))])
+    hide = rng.random(N) < 0.3
+    mask["f1"][hide, rng.integers(0, dim, hide.sum())] = True
+    view = common_amd.DataView.from_recarray(gpu_ctx, np.ma.masked_array(rec, mask=mask))
+    st = common_amd.State(gpu_ctx, [(orc.BB, 0), (orc.NIW, dim)], K)
+    load_state(st, fs)
+    got = st.score_value(view).cpu().numpy()
+    want = fs[0][0].score_matrix(fs[0][1], feats[0]["values"])
+    niw = fs[1][0].score_matrix(fs[1][1], feats[1]["values"])
+    niw[hide] = 0.0
+    assert rel_err(got, want + niw).max() <= TOL
