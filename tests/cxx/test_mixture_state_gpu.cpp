@@ -9,6 +9,7 @@
 
 #include <microscopes/common/entity_state.hpp>
 #include <microscopes/models/distributions.hpp>
+#include <microscopes/models/dm.hpp>
 #include <microscopes_amd/mixture_state.hpp>
 
 using namespace microscopes;
@@ -183,6 +184,63 @@ int main() {
     for (size_t gid : st2.groups())
       if (st2.groupsize(gid)) by_size_b[st2.groupsize(gid) * 1000003 + size_t(as2.end() - std::find(as2.begin(), as2.end(), ssize_t(gid)))] = st2.get_suffstats(2, gid);
     CHECK(by_size_a == by_size_b);
+  }
+  // vector-valued components (packed records on the ABI): niw(2) and dm(3) through the same interface
+  {
+#pragma pack(push, 1)
+    struct VRow { float v[2]; int32_t c[3]; };
+#pragma pack(pop)
+    const size_t M = 40;
+    std::vector<VRow> vr(M);
+    for (size_t i = 0; i < M; i++) {
+      vr[i].v[0] = float(std::normal_distribution<double>(i % 2 ? 3.0 : -3.0, 1.0)(gen));
+      vr[i].v[1] = float(std::normal_distribution<double>(0.0, 1.0)(gen));
+      for (int j = 0; j < 3; j++) vr[i].c[j] = std::uniform_int_distribution<int>(0, 4)(gen);
+    }
+    const std::vector<runtime_type> vt = {runtime_type(TYPE_F32, 2), runtime_type(TYPE_I32, 3)};
+    recarray::row_major_dataview vdata(reinterpret_cast<const uint8_t *>(vr.data()), nullptr, M, vt);
+    std::vector<models::model_shared_ptr> vm = {std::make_shared<models::distributions_model_niwv>(2),
+                                                std::make_shared<models::dm_model>(3)};
+    hip::mixture_state vs(vm, vdata, 8);
+    vs.get_cluster_hp_mutator("alpha").set<float>(1.f);
+    std::vector<models::hypers_shared_ptr> vh = {vm[0]->create_hypers(), vm[1]->create_hypers()};
+    for (int i = 0; i < 3; i++) {                            // (a fresh dm_hypers holds zero alphas, as upstream: dm.hpp:168)
+      vs.get_component_hp_mutator(1, "alphas").set<float>(0.5f + i, i);
+      vh[1]->get_hp_mutator("alphas").set<float>(0.5f + i, i);
+    }
+    const size_t ga = vs.create_group(rng), gb = vs.create_group(rng);
+    std::vector<models::group_shared_ptr> ta = {vh[0]->create_group(rng), vh[1]->create_group(rng)},
+                                          tb = {vh[0]->create_group(rng), vh[1]->create_group(rng)};
+    for (size_t e = 0; e + 1 < M; e++) {
+      vs.add_value(e % 2 ? ga : gb, e, rng);
+      auto acc = vdata.get(e);
+      auto &t = e % 2 ? ta : tb;
+      for (size_t f = 0; f < 2; f++, acc.bump()) t[f]->add_value(*vh[f], acc.get(), rng);
+    }
+    {  // dm counts are exact (the float `ratio` next to them is a float sum on one side, a double one on the other)
+      auto g = vh[1]->create_group(rng);
+      g->set_ss(vs.get_suffstats(1, ga));
+      auto *got = static_cast<models::dm_group *>(g.get());
+      auto *want = static_cast<models::dm_group *>(ta[1].get());
+      CHECK(got->repr_.counts == want->repr_.counts);
+    }
+    for (size_t f = 0; f < 2; f++) {
+      CHECK(close_to(vs.score_likelihood(f, ga, rng), ta[f]->score_data(*vh[f], rng), 1e-4));
+      CHECK(close_to(vs.score_likelihood(f, gb, rng), tb[f]->score_data(*vh[f], rng), 1e-4));
+    }
+    auto sc = vs.score_value(M - 1, rng);                    // the last entity was never added
+    CHECK(sc.first.size() == 2);
+    for (size_t i = 0; i < 2; i++) {
+      auto &t = sc.first[i] == ga ? ta : tb;
+      double want = std::log(double(vs.groupsize(sc.first[i])));
+      auto acc = vdata.get(M - 1);
+      for (size_t f = 0; f < 2; f++, acc.bump()) want += t[f]->score_value(*vh[f], acc.get(), rng);
+      CHECK(close_to(sc.second[i], want));
+    }
+    // niw suff-stats round trip through the packed record
+    const auto bag = vs.get_suffstats(0, ga);
+    vs.set_suffstats(0, gb, bag);
+    CHECK(close_to(vs.score_likelihood(0, gb, rng), vs.score_likelihood(0, ga, rng), 1e-6));
   }
   std::printf("test_mixture_state_gpu ok\n");
   return 0;
