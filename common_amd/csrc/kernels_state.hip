@@ -156,6 +156,68 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// accumulate when the per-workgroup histograms no longer fit LDS (K beyond ~8000 groups): one thread per
+// (row, feature) -- blockIdx.y = 0 the group sizes, 1 + f feature f -- adding straight into the additive tables.
+// With that many groups the rows of a wave rarely meet in one, which is what the LDS stage was there to absorb.
+// ---------------------------------------------------------------------------
+MSC_DEV void add_i64(long long *p, long long v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
+__global__ __launch_bounds__(256) void k_accumulate_global(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
+                                                            uint64_t row0, uint64_t nrows, const int32_t *__restrict__ z,
+                                                            int sign, long long *__restrict__ cnt_acc) {
+  const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nrows) return;
+  const int g = z[n];
+  if (g < 0 || (uint32_t)g >= K) return;
+  const long long sgn = sign;
+  if (blockIdx.y == 0) {
+    add_i64(&cnt_acc[g], sgn);
+    return;
+  }
+  const FeatDesc fd = feats[blockIdx.y - 1];
+  const uint64_t row = row0 + n;
+  if (fd.mask != nullptr) {
+    bool m = false;
+    if (fd.family == MSC_DM) for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
+    else m = fd.mask[row] != 0;
+    if (m) return;
+  }
+  switch (fd.family) {
+    case MSC_BBNC:
+    case MSC_BB:
+      add_i64(&fd.acc_i64[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 0 : kpad) + g], sgn);
+      break;
+    case MSC_GP: {
+      const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+      add_i64(&fd.acc_i64[g], sgn);
+      add_i64(&fd.acc_i64[kpad + g], sgn * (long long)v);
+      atomicAdd(&fd.acc_f64[g], (double)sign * log_factorial(v));
+    } break;
+    case MSC_BNB: {
+      const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+      add_i64(&fd.acc_i64[g], sgn);
+      add_i64(&fd.acc_i64[kpad + g], sgn * (long long)v);
+    } break;
+    case MSC_DM: {
+      const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
+      for (uint32_t i = 0; i < fd.dim; i++)
+        if (x[i]) add_i64(&fd.acc_i64[(size_t)i * kpad + g], sgn * (long long)(uint32_t)x[i]);
+      atomicAdd(&fd.acc_f64[g], (double)sign * dm_row_ratio(fd.dim, x));
+    } break;
+    case MSC_DD: {
+      const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+      if (v >= 0 && v < (int)fd.dim) add_i64(&fd.acc_i64[(size_t)v * kpad + g], sgn);
+    } break;
+    case MSC_NICH: {
+      const double x = reinterpret_cast<const float *>(fd.col)[row];
+      add_i64(&fd.acc_i64[g], sgn);
+      atomicAdd(&fd.acc_f64[g], (double)sign * x);
+      atomicAdd(&fd.acc_f64[kpad + g], (double)sign * x * x);
+    } break;
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // commit: additive -> raw.  blockIdx.y = feature (nfeat = the group-size table)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_commit(const FeatDesc *__restrict__ feats, int nfeat,
@@ -427,7 +489,11 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
   uint32_t dd_slice = kMaxDDDim;
   while (dd_slice > 1 && (size_t)K * 4u * dd_slice > 64u * 1024u) dd_slice /= 2;
   const size_t lds = accumulate_lds_bytes(feats_host, nfeat, K, dd_slice);
-  if (lds > 160u * 1024u) return -2;
+  if (lds > 160u * 1024u) {                                // too many groups for LDS histograms
+    hipLaunchKernelGGL(k_accumulate_global, dim3((unsigned)((nrows + 255) / 256), (unsigned)nfeat + 1), dim3(256), 0, stream,
+                       feats_dev, K, kpad, row0, nrows, z, sign, cnt_acc);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate),

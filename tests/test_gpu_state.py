@@ -170,3 +170,50 @@ def test_wrong_column_type_is_refused(gpu_ctx):
         st.score_value(view)
     view32 = common_amd.DataView.from_recarray(gpu_ctx, arr, col_types=[orc.TYPE_F32])
     assert st.score_value(view32).shape == (10, 4)
+
+
+def test_accumulate_with_more_groups_than_lds_histograms_hold(gpu_ctx):
+    """K = 12000: the per-workgroup LDS histograms do not fit; rows are added straight into the additive tables
+    (k_accumulate_global).  Same numbers, then a subtraction, then scores and a sweep on that many groups."""
+    import common_amd
+    K, N = 12000, 40000
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.NICH, 0), (orc.BNB, 0), (orc.DM, 3)]
+    rng = np.random.default_rng(12)
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[::13] = -1
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    for i, f in enumerate(feats):
+        st.set_hp(i, orc.Family(f["family"], f["hp"], f["dim"], "f64").hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    fs = []
+    for f in feats:
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        fs.append((F, F.accumulate(K, f["values"], z), None))
+    _check_ss(st, fs)
+    assert np.array_equal(st.get_group_counts(), np.bincount(z[z >= 0], minlength=K))
+    # take the second half out again
+    half = N // 2
+    st.accumulate(view, zt[half:].contiguous(), row0=half, nrows=N - half, reset=False, subtract=True)
+    fs_half = []
+    for f in feats:
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        fs_half.append((F, F.accumulate(K, f["values"][:half], z[:half]), None))
+    for i, (F, ss64, _) in enumerate(fs_half):
+        rec = st.get_ss(i)
+        for name in rec.dtype.names:
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(rec[name], np.asarray(ss64[name])), (F.family, name)
+    # scores of a few rows against all 12000 groups
+    rows = np.arange(0, 64)
+    got = st.score_value(view, row0=0, nrows=64).cpu().numpy()
+    want = sum(F.score_matrix(ss64, f["values"][rows]) for f, (F, ss64, _) in zip(feats, fs_half))
+    assert rel_err(got, want).max() <= 5 * TOL          # (float suff-stats after add + subtract carry the extra rounding)
+    st.set_alpha(1.0)
+    z2 = zt.clone()
+    st.sweep_step(view, z2, seed=3, sweep=0)
+    zn = z2.cpu().numpy()
+    assert ((zn >= 0) & (zn < K)).all() and (zn != np.where(z < 0, 0, z)).any()
+    assert np.array_equal(st.get_group_counts(), np.bincount(zn, minlength=K))
