@@ -1071,7 +1071,7 @@ static int accumulate_impl(msc_state *st, const msc_dataview *view, const uint32
         st->niw_scratch_len = need;
       }
       if (launch_niw_accumulate(s, st->ctx->num_cus, st->desc_dev, f, st->K, row0, nrows, z_dev,
-                                (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->niw_scratch))
+                                (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->niw_scratch, st->feats[f].dim))
         return fail(MSC_EHIP, "niw accumulate launch failed");
     }
   }

@@ -747,10 +747,84 @@ int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------
+// accumulate for small dimensions: d + d^2 sums per group are few enough for the per-workgroup LDS histogram the
+// scalar families use (ds_add_f64; float x float is exact in double), flushed with one global atomic per non-zero
+// bin.  The bucketing pass above earns its three extra kernels at dim 32 (1056 sums per row); at dim 3 it was
+// 110 us of a 420 us sweep step (262k rows x 128 groups), this is ~10.
+// LDS: double sums[K][d + d*d] | uint32 counts[K]
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(1024) void k_niw_accumulate_small(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
+                                                                uint64_t row0, uint64_t nrows, const int32_t *__restrict__ z,
+                                                                int sign) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kStride = D + D * D;
+  const FeatDesc fd = feats[f];
+  double *sums = reinterpret_cast<double *>(smem);
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(sums + (size_t)K * kStride);
+  for (uint32_t i = threadIdx.x; i < K * kStride; i += blockDim.x) sums[i] = 0.0;
+  for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) cnt[i] = 0u;
+  __syncthreads();
+  const uint64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < nrows ? lo + per : nrows;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
+    const int g = z[n];
+    const uint64_t row = row0 + n;
+    if (!niw_row_counts(fd, K, row, g)) continue;
+    double x[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) x[j] = (double)X[row * D + j];
+    double *dst = sums + (size_t)g * kStride;
+    atomicAdd(&cnt[g], 1u);
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      atomicAdd(&dst[i], x[i]);
+#pragma unroll
+      for (int j = 0; j < D; j++) atomicAdd(&dst[D + i * D + j], x[i] * x[j]);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < K * kStride; i += blockDim.x)
+    if (sums[i] != 0.0) atomicAdd(&fd.acc_f64[i], (double)sign * sums[i]);
+  for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
+    if (cnt[i]) atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[i]), (unsigned long long)((long long)sign * (long long)cnt[i]));
+}
+template <int D>
+static void launch_niw_accumulate_small(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
+                                        uint64_t row0, uint64_t nrows, const int32_t *z, int sign, size_t lds) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_niw_accumulate_small<D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  uint64_t blocks = (nrows + 4095) / 4096;
+  if (blocks < (uint64_t)num_cus) blocks = (nrows + 1023) / 1024;
+  if (blocks > (uint64_t)num_cus * 2) blocks = (uint64_t)num_cus * 2;
+  hipLaunchKernelGGL(k_niw_accumulate_small<D>, dim3((unsigned)(blocks ? blocks : 1)), dim3(1024), lds, stream, feats_dev, f, K,
+                     row0, nrows, z, sign);
+}
+
 // scratch_dev: 2 K + 1 + nrows uint32 (see k_niw_bucket_*)
 int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
-                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign, uint32_t *scratch_dev) {
+                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign, uint32_t *scratch_dev, uint32_t dim) {
   if (nrows == 0) return 0;
+  const size_t small_lds = (size_t)K * ((dim + (size_t)dim * dim) * sizeof(double) + sizeof(uint32_t));
+  if (dim >= 1 && dim <= 8 && small_lds <= 96u * 1024u) {
+    switch (dim) {
+      case 1: launch_niw_accumulate_small<1>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 2: launch_niw_accumulate_small<2>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 3: launch_niw_accumulate_small<3>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 4: launch_niw_accumulate_small<4>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 5: launch_niw_accumulate_small<5>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 6: launch_niw_accumulate_small<6>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      case 7: launch_niw_accumulate_small<7>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+      default: launch_niw_accumulate_small<8>(stream, num_cus, feats_dev, f, K, row0, nrows, z, sign, small_lds); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (hipMemsetAsync(scratch_dev, 0, sizeof(uint32_t) * (2 * (size_t)K + 1), stream) != hipSuccess) return -1;
   uint64_t gx = (nrows + 255) / 256;
   const uint64_t cap = (uint64_t)num_cus * 8;

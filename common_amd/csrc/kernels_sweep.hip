@@ -320,6 +320,13 @@ __global__ __launch_bounds__(256) void k_sample_rows(const float *__restrict__ s
   constexpr float kLog2e = 1.44269504088896340736f;
   for (uint64_t row = wave_id; row < nrows; row += nwaves) {
     const float *s = scores + row * ld;
+    if (ntiles == 1) {                                   // the whole row is one load: keep it in registers
+      const float4 v = load_score4(s, 4 * lane, K, vec_ok);
+      const float sc[4] = {v.x, v.y, v.z, v.w};
+      const int pick1 = sample_from_scores<4>(sc, philox_uniform01(seed, sweep, row_id0 + row), lane, K);
+      if (lane == 0) z[row] = pick1;
+      continue;
+    }
     float m = -INFINITY;
     for (uint32_t t = 0; t < ntiles; t++) {
       const float4 v = load_score4(s, t * kGroupTile + 4 * lane, K, vec_ok);

@@ -71,7 +71,7 @@ int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
                      uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
                      double *qown /* [nrows] scratch, leave-one-out only */, float *out, uint64_t ld);
 int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
-                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign, uint32_t *scratch_dev);
+                          uint64_t row0, uint64_t nrows, const int32_t *z, int sign, uint32_t *scratch_dev, uint32_t dim);
 int launch_niw_commit(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
                       uint32_t kpad, int to_raw);
 
