@@ -142,24 +142,38 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
   const int lane = threadIdx.x & 63;
   const uint32_t kb = (uint32_t)(G * lane);
   float mh[G], ml[G], c0[G], c1l[G], c1[G], c2[G], lc[G];
+  if constexpr (G < 4) {                 // few groups (K <= 64 G): one or two per lane, scalar loads
 #pragma unroll
-  for (int j = 0; j < G; j += 4) {
-    const uint32_t k = kb + j;           // kpad is a multiple of 256 >= 64*G only when K allows; guard loads
-    const bool in = k < kpad;
-    const float4 a = in ? ld4(fd.tab + (size_t)NICH_MU_HI * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 b = in ? ld4(fd.tab + (size_t)NICH_MU_LO * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 c = in ? ld4(fd.tab + (size_t)NICH_C0 * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 d = in ? ld4(fd.tab + (size_t)NICH_C1LN2 * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 e = in ? ld4(fd.tab + (size_t)NICH_C1 * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 f = in ? ld4(fd.tab + (size_t)NICH_C2 * kpad + k) : make_float4(0, 0, 0, 0);
-    const float4 g = in ? ld4(crp + k) : make_float4(0, 0, 0, 0);
-    mh[j] = a.x; mh[j + 1] = a.y; mh[j + 2] = a.z; mh[j + 3] = a.w;
-    ml[j] = b.x; ml[j + 1] = b.y; ml[j + 2] = b.z; ml[j + 3] = b.w;
-    c0[j] = c.x; c0[j + 1] = c.y; c0[j + 2] = c.z; c0[j + 3] = c.w;
-    c1l[j] = d.x; c1l[j + 1] = d.y; c1l[j + 2] = d.z; c1l[j + 3] = d.w;
-    c1[j] = e.x; c1[j + 1] = e.y; c1[j + 2] = e.z; c1[j + 3] = e.w;
-    c2[j] = f.x; c2[j + 1] = f.y; c2[j + 2] = f.z; c2[j + 3] = f.w;
-    lc[j] = g.x; lc[j + 1] = g.y; lc[j + 2] = g.z; lc[j + 3] = g.w;
+    for (int j = 0; j < G; j++) {
+      const uint32_t k = kb + j;         // < 64 G <= kpad
+      mh[j] = fd.tab[(size_t)NICH_MU_HI * kpad + k];
+      ml[j] = fd.tab[(size_t)NICH_MU_LO * kpad + k];
+      c0[j] = fd.tab[(size_t)NICH_C0 * kpad + k];
+      c1l[j] = fd.tab[(size_t)NICH_C1LN2 * kpad + k];
+      c1[j] = fd.tab[(size_t)NICH_C1 * kpad + k];
+      c2[j] = fd.tab[(size_t)NICH_C2 * kpad + k];
+      lc[j] = crp[k];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < G; j += 4) {
+      const uint32_t k = kb + j;           // kpad is a multiple of 256 >= 64*G only when K allows; guard loads
+      const bool in = k < kpad;
+      const float4 a = in ? ld4(fd.tab + (size_t)NICH_MU_HI * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 b = in ? ld4(fd.tab + (size_t)NICH_MU_LO * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 c = in ? ld4(fd.tab + (size_t)NICH_C0 * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 d = in ? ld4(fd.tab + (size_t)NICH_C1LN2 * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 e = in ? ld4(fd.tab + (size_t)NICH_C1 * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 f = in ? ld4(fd.tab + (size_t)NICH_C2 * kpad + k) : make_float4(0, 0, 0, 0);
+      const float4 g = in ? ld4(crp + k) : make_float4(0, 0, 0, 0);
+      mh[j] = a.x; mh[j + 1] = a.y; mh[j + 2] = a.z; mh[j + 3] = a.w;
+      ml[j] = b.x; ml[j + 1] = b.y; ml[j + 2] = b.z; ml[j + 3] = b.w;
+      c0[j] = c.x; c0[j + 1] = c.y; c0[j + 2] = c.z; c0[j + 3] = c.w;
+      c1l[j] = d.x; c1l[j + 1] = d.y; c1l[j + 2] = d.z; c1l[j + 3] = d.w;
+      c1[j] = e.x; c1[j + 1] = e.y; c1[j + 2] = e.z; c1[j + 3] = e.w;
+      c2[j] = f.x; c2[j + 1] = f.y; c2[j + 2] = f.z; c2[j + 3] = f.w;
+      lc[j] = g.x; lc[j + 1] = g.y; lc[j + 2] = g.z; lc[j + 3] = g.w;
+    }
   }
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
   // Sampling only needs the scores up to what exp2 sees, so everything is moved to log2 units once
@@ -387,7 +401,11 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   while (chunk_rows > 4 && (nrows + chunk_rows - 1) / chunk_rows < (uint64_t)num_cus * 32) chunk_rows >>= 1;
   const uint64_t gx = grid_for((nrows + chunk_rows - 1) / chunk_rows, num_cus, 16);
   const dim3 grid((unsigned)gx), block(256);
-  if (K <= 256)
+  if (K <= 64)
+    hipLaunchKernelGGL(k_sweep_nich1<1>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+  else if (K <= 128)
+    hipLaunchKernelGGL(k_sweep_nich1<2>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+  else if (K <= 256)
     hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 512)
     hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);

@@ -42,7 +42,7 @@ def _check_agreement(got, want, scores, seed, sweep_idx, min_agree):
         assert abs(cdf[lo] - u) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, (n, lo, hi, cdf[lo], u)
 
 
-@pytest.mark.parametrize("K", [7, 256, 300, 512, 1000])
+@pytest.mark.parametrize("K", [7, 64, 100, 256, 300, 512, 1000])
 def test_sweep_single_nich_feature_matches_oracle(gpu_ctx, K):
     got, want, scores, _ = _run(gpu_ctx, [(orc.NICH, 0)], 3000, K, seed=11 + K, sweep_idx=3)
     _check_agreement(got, want, scores, 11 + K, 3, 0.998)
