@@ -302,7 +302,8 @@ MSC_DEV double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-template <int JB, bool LOO, bool ACCUM>
+// HALF: dim <= 16 -- the lower 16 rows of W are zero, so is their half of the output: one MFMA chain instead of two
+template <int JB, bool LOO, bool ACCUM, bool HALF>
 __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict__ feats, uint32_t f,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
@@ -348,9 +349,12 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 #pragma unroll
       for (int s = 0; s < 8; s += 2) {
         const double2 p0 = *reinterpret_cast<const double2 *>(Wk + s);
-        const double2 p1 = *reinterpret_cast<const double2 *>(Wk + 16 * kNiwPad + s);
         const double2 pb = *reinterpret_cast<const double2 *>(Bk + s);
-        a0[s] = p0.x; a0[s + 1] = p0.y; a1[s] = p1.x; a1[s + 1] = p1.y; nb[s] = -pb.x; nb[s + 1] = -pb.y;
+        a0[s] = p0.x; a0[s + 1] = p0.y; nb[s] = -pb.x; nb[s + 1] = -pb.y;
+        if (!HALF) {
+          const double2 p1 = *reinterpret_cast<const double2 *>(Wk + 16 * kNiwPad + s);
+          a1[s] = p1.x; a1[s + 1] = p1.y;
+        }
       }
       const uint32_t slot = k & 3;
       const bool mine = (int)((k >> 2) & 3) == kk;
@@ -360,11 +364,11 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 #pragma unroll
         for (int s = 0; s < 8; s++) {
           acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], xd[jb][s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], xd[jb][s], acc1, 0, 0, 0);
+          if (!HALF) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], xd[jb][s], acc1, 0, 0, 0);
         }
         double qp = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) qp = fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
+        for (int i = 0; i < 4; i++) qp = HALF ? fma(acc0[i], acc0[i], qp) : fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
         qp += shfl_xor_f64(qp, 16);
         const double q = qp + shfl_xor_f64(qp, 32);
         if (mine) {
@@ -690,7 +694,7 @@ int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_
 }
 
 template <bool LOO, bool ACCUM>
-static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, const FeatDesc *feats_dev,
+static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, bool half, const FeatDesc *feats_dev,
                                uint32_t f, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                const int32_t *z, double *qown, float *out, uint64_t ld) {
   constexpr int kRowsPerWave = 64;             // 2 tiles of 32 (f32) or 4 blocks of 16 (f64)
@@ -702,7 +706,10 @@ static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, c
   if (f32_fast)
     hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
   else {
-    hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    if (half)
+      hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM, true>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    else
+      hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM, false>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
     if (LOO)
       hipLaunchKernelGGL(k_niw_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, f, K, row0,
                          nrows, z, qown, out, ld);
@@ -740,10 +747,10 @@ int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
