@@ -897,6 +897,32 @@ static bool gp_beyond_table(const msc_state *st, uint32_t f) {
   return false;
 }
 
+// K <= 64 and nothing but scalar families whose tables all fit 64 KiB of LDS at 4 L groups per row: the narrow tiling
+// (kernels_sweep.hip k_narrow).  Returns L = lanes per row (4 / 8 / 16) or 0, and the table rows to stage.
+static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
+  static const bool off = std::getenv("MSC_NO_NARROW") != nullptr;        // (A/B knob; the tests run both tilings)
+  if (off || st->K > 64) return 0;
+  const int L = st->K <= 16 ? 4 : st->K <= 32 ? 8 : 16;
+  uint32_t rows = 0;
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    const msc_feature_host &h = st->feats[f];
+    switch (h.family) {
+      case MSC_BB: case MSC_BBNC: rows += 2; break;
+      case MSC_NICH: rows += 6; break;                                      // (NICH_ROWS)
+      case MSC_DD: rows += h.dim; break;
+      case MSC_GP: case MSC_BNB:
+        if (gp_beyond_table(st, f)) return 0;
+        rows += st->desc_host[f].vcap;
+        break;
+      case MSC_NOOP: break;
+      default: return 0;                                                    // niw, dm: their own kernels
+    }
+  }
+  if ((size_t)rows * L * 16 > 64u * 1024u) return 0;
+  *table_rows = rows;
+  return L;
+}
+
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
                      bool niw_f32, float *out_dev, uint64_t ld_out) {
   hipStream_t s = st->ctx->stream;
@@ -908,6 +934,13 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   uint32_t n_niw = 0;
   for (auto &h : st->feats) n_niw += h.family == MSC_NIW;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
+  uint32_t narrow_rows = 0;
+  if (const int nl = narrow_lanes(st, &narrow_rows)) {
+    if (launch_narrow(s, st->ctx->num_cus, nl, narrow_rows, false, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows,
+                      z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out, 0, nullptr, nullptr, ZeroSpans()))
+      return fail(MSC_EHIP, "k_narrow launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return MSC_OK;
+  }
   bool written = false;
   if (n_niw < st->nfeat || crp) {
     bool has_dm = false;
@@ -1149,7 +1182,11 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       if (launch_loo_own(s, st->ctx->num_cus, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
+    uint32_t narrow_rows = 0;
+    const int nl = nich1 ? 0 : narrow_lanes(st, &narrow_rows);
     if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
+                                    st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
     else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0;
   }

@@ -305,6 +305,185 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 }
 
 // ---------------------------------------------------------------------------
+// K <= 64: the narrow tiling.  In the 256-group tiling above a lane owns 4 groups of a 256-group tile, so with 16
+// groups 4 lanes of 64 work (a million rows x 16 groups x 8 bb columns scored at 1/17 of what the bytes allow).
+// Here L = ceil(K / 4) rounded to 4 / 8 / 16 lanes share a row -- lane q of them owns groups 4q .. 4q+3 -- and a
+// wave takes 64 / L rows per step.  Every lane fetches its own row's value, so nothing is broadcast; the tables,
+// compacted to 4 L groups per row, all sit in LDS (the host checks that they fit: narrow_lanes in abi.cpp); the
+// own group's leave-one-out entry is a per-lane compare; the draw reduces over the L lanes of a row with
+// width-L shuffles.  Features are added in the caller's order.  SWEEP = false writes scores, true draws.
+// ---------------------------------------------------------------------------
+MSC_DEV uint32_t narrow_table_rows(const FeatDesc &fd) {
+  switch (fd.family) {
+    case MSC_BB: case MSC_BBNC: return 2;
+    case MSC_NICH: return NICH_ROWS;
+    case MSC_DD: return fd.dim;
+    case MSC_GP: case MSC_BNB: return fd.vcap;
+    default: return 0;
+  }
+}
+template <int L, bool SWEEP>
+__global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad,
+                                                 uint64_t row0, uint64_t nrows, const int32_t *__restrict__ z,
+                                                 const float *__restrict__ own, const float *__restrict__ crp,
+                                                 float *__restrict__ out, uint64_t ld, uint64_t row_id0,
+                                                 int32_t *__restrict__ z_out, const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  extern __shared__ float4 nlds[];
+  if (SWEEP) zero_spans(zero);
+  // stage every feature's table, 4 L groups wide
+  {
+    uint32_t off = 0;
+    for (int f = 0; f < nfeat; f++) {
+      const FeatDesc &fd = feats[f];
+      const uint32_t rows = narrow_table_rows(fd), first = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
+      for (uint32_t i = threadIdx.x; i < rows * L; i += 256) {
+        const uint32_t r = i / L, q = i % L;
+        nlds[off + i] = ld4(fd.tab + (size_t)(first + r) * kpad + 4 * q);
+      }
+      off += rows * L;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane % L, sub = lane / L;
+  constexpr int kRowsPerStep = 64 / L;
+  const uint32_t kb = 4 * q;
+  const bool loo = z != nullptr, pri = crp != nullptr;
+  float4 logcnt = make_float4(0, 0, 0, 0);
+  float le0 = 0.f, le1 = 0.f;
+  if (pri) {
+    logcnt = ld4(crp + kb);
+    le0 = crp[2 * (size_t)kpad];
+    le1 = crp[2 * (size_t)kpad + 1];
+  }
+  const uint64_t seed = SWEEP ? rng[0] : 0, sweep = SWEEP ? rng[1] : 0;
+  const bool vec_ok = !SWEEP && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const uint64_t nsteps = (nrows + kRowsPerStep - 1) / kRowsPerStep;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t step = wave_id; step < nsteps; step += nwaves) {
+    const uint64_t n = step * kRowsPerStep + sub;          // relative to row0
+    const bool has_row = n < nrows;
+    const uint64_t row = row0 + (has_row ? n : 0);
+    int gz = -1;
+    float erow = le0;
+    if (loo && has_row) {
+      gz = z[n];
+      if (pri && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+    }
+    float4 acc = pri ? crp_prior4(logcnt, erow) : make_float4(0, 0, 0, 0);
+    uint32_t off = 0;
+    for (int f = 0; f < nfeat; f++) {
+      const FeatDesc &fd = feats[f];
+      const float4 *tab = nlds + off + q;
+      off += narrow_table_rows(fd) * L;
+      if (!has_row || fd.family == MSC_NOOP || (fd.mask != nullptr && fd.mask[row] != 0)) continue;
+      switch (fd.family) {
+        case MSC_BB: case MSC_BBNC:
+          add4(acc, tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 1 : 0) * L]);
+          break;
+        case MSC_DD: {
+          int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+          v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
+          add4(acc, tab[v * L]);
+        } break;
+        case MSC_GP: case MSC_BNB: {
+          const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+          if (v < fd.vcap) add4(acc, tab[v * L]);        // (the host only takes this path when every count is in the table)
+        } break;
+        case MSC_NICH: {
+          const float x = reinterpret_cast<const float *>(fd.col)[row];
+          const float4 mh = tab[NICH_MU_HI * L], ml = tab[NICH_MU_LO * L], c0 = tab[NICH_C0 * L], c1l = tab[NICH_C1LN2 * L],
+                       c1 = tab[NICH_C1 * L], c2 = tab[NICH_C2 * L];
+          acc.x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+          acc.y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+          acc.z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+          acc.w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+        } break;
+        default: break;
+      }
+    }
+    if (loo && gz >= 0 && (uint32_t)gz / 4 == (uint32_t)q) {     // this lane holds the row's own group
+      const float v = own[n];
+      const int c = gz & 3;
+      acc.x = c == 0 ? v : acc.x; acc.y = c == 1 ? v : acc.y; acc.z = c == 2 ? v : acc.z; acc.w = c == 3 ? v : acc.w;
+    }
+    if (!SWEEP) {
+      if (has_row) store_row(out, ld, n, kb, K, acc, vec_ok);
+      continue;
+    }
+    // ---- draw: softmax + inverse CDF over the L lanes of the row (every lane of the wave takes part) ----
+    float sc[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (kb + j >= K) sc[j] = -INFINITY;
+    float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+    for (int w = 1; w < L; w <<= 1) m = fmaxf(m, __shfl_xor(m, w, 64));
+    float p[4], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      p[j] = __builtin_amdgcn_exp2f((sc[j] - m) * 1.44269504088896340736f);
+      sum += p[j];
+    }
+    float incl = sum;
+#pragma unroll
+    for (int w = 1; w < L; w <<= 1) {
+      const float t = __shfl_up(incl, w, L);
+      if (q >= w) incl += t;
+    }
+    const float total = __shfl(incl, sub * L + L - 1, 64);
+    const float dart = philox_uniform01(seed, sweep, row_id0 + n) * total;
+    float c = incl - sum;
+    int nmiss = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c += p[j];
+      nmiss += c < dart ? 1 : 0;
+    }
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(nmiss < 4);
+    const unsigned long long mine = (hit >> (sub * L)) & ((L == 64) ? ~0ull : ((1ull << L) - 1ull));
+    int pick = (int)K - 1;                               // rounding may let the dart fall off the end
+    const int first = mine ? (int)__builtin_ctzll(mine) : 0;
+    const int nm = __shfl(nmiss, sub * L + first, 64);
+    if (mine) {
+      const int k = 4 * first + nm;
+      pick = k < (int)K ? k : (int)K - 1;
+    }
+    if (has_row && q == 0) z_out[n] = pick;
+  }
+}
+
+static size_t g_narrow_lds_limit = 64 * 1024;
+template <int L, bool SWEEP>
+static int launch_narrow_t(hipStream_t stream, int num_cus, size_t lds_bytes, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                           uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
+                           float *out, uint64_t ld, uint64_t row_id0, int32_t *z_out, const uint64_t *rng, ZeroSpans zero) {
+  if (lds_bytes > g_narrow_lds_limit) return -2;
+  const uint64_t steps = (nrows + 64 / L - 1) / (64 / L);
+  uint64_t gx = (steps + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * 8;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL((k_narrow<L, SWEEP>), dim3((unsigned)(gx ? gx : 1)), dim3(256), lds_bytes, stream, feats_dev, nfeat, K, kpad,
+                     row0, nrows, z, own, crp, out, ld, row_id0, z_out, rng, zero);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// lanes_per_row: 4, 8 or 16 (abi.cpp narrow_lanes); table_rows: sum over features of narrow_table_rows
+int launch_narrow(hipStream_t stream, int num_cus, int lanes_per_row, uint32_t table_rows, bool sweep, const FeatDesc *feats_dev,
+                  int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
+                  const float *crp, float *out, uint64_t ld, uint64_t row_id0, int32_t *z_out, const uint64_t *rng,
+                  ZeroSpans zero) {
+  const size_t lds = (size_t)table_rows * lanes_per_row * sizeof(float4);
+#define MSC_NARROW(Lv)                                                                                                    \
+  return sweep ? launch_narrow_t<Lv, true>(stream, num_cus, lds, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, \
+                                           ld, row_id0, z_out, rng, zero)                                                 \
+               : launch_narrow_t<Lv, false>(stream, num_cus, lds, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, \
+                                            ld, row_id0, z_out, rng, zero)
+  if (lanes_per_row == 4) { MSC_NARROW(4); }
+  if (lanes_per_row == 8) { MSC_NARROW(8); }
+  MSC_NARROW(16);
+#undef MSC_NARROW
+}
+
+// ---------------------------------------------------------------------------
 // fallback: one wave per row of a materialised [nrows, ld] score chunk.  The row is walked in tiles of 256 groups,
 // lane l taking groups 4l .. 4l+3 of the tile (one coalesced 1 KiB load per tile and pass, the score kernels' own
 // layout): maximum, then the total, then the walk to the first group whose running sum reaches the dart, which
