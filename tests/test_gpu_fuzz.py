@@ -38,7 +38,7 @@ def test_random_feature_lists_match_the_oracle(gpu_ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     spec = _random_spec(rng)
     N = int(rng.choice([1, 5, 64, 127, 129, 300, 777]))
-    K = int(rng.choice([1, 3, 16, 255, 256, 257, 300]))
+    K = int(rng.choice([1, 3, 16, 20, 33, 64, 255, 256, 257, 300]))
     feats = [make_feature(f, N, K, rng, d) for f, d in spec]
     if rng.random() < 0.3:                                       # gp counts beyond what a feature stages / tables hold
         for f in feats:
@@ -112,6 +112,6 @@ def test_random_sweeps_draw_the_oracles_assignments(gpu_ctx, seed):
     rng = np.random.default_rng(5000 + seed)
     spec = _random_spec(rng)
     N = int(rng.choice([64, 300, 1000]))
-    K = int(rng.choice([2, 17, 256, 300]))
+    K = int(rng.choice([2, 17, 40, 64, 256, 300]))
     got, want, scores, _ = _run(gpu_ctx, spec, N, K, seed=300 + seed, sweep_idx=seed % 5, alpha=0.9, empty=min(2, K - 1))
     _check_agreement(got, want, scores, 300 + seed, seed % 5, 0.98)
