@@ -901,6 +901,7 @@ static bool gp_beyond_table(const msc_state *st, uint32_t f) {
 // (kernels_sweep.hip k_narrow).  Returns L = lanes per row (4 / 8 / 16) or 0, and the table rows to stage.
 static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
   static const bool off = std::getenv("MSC_NO_NARROW") != nullptr;        // (A/B knob; the tests run both tilings)
+  // (32 lanes per row for K <= 128 was measured and loses to the 256-group tiling: 8 bb at K = 100, 0.52 against 0.20 ms)
   if (off || st->K > 64) return 0;
   const int L = st->K <= 16 ? 4 : st->K <= 32 ? 8 : 16;
   uint32_t rows = 0;
