@@ -313,6 +313,25 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // own group's leave-one-out entry is a per-lane compare; the draw reduces over the L lanes of a row with
 // width-L shuffles.  Features are added in the caller's order.  SWEEP = false writes scores, true draws.
 // ---------------------------------------------------------------------------
+// max / sum over the L (4, 8, 16) neighbouring lanes of a row, every lane getting the result, on the DPP path:
+// quad_perm [1,0,3,2] and [2,3,0,1] exchange within a quad, row_half_mirror / row_mirror reverse 8 / 16 lanes (for a
+// commutative reduction a reversal pairs each lane with the other half as well as an exchange would)
+template <int L, bool MAX>
+MSC_DEV float narrow_allreduce(float v) {
+  float t = dpp_f32<0xB1, 0xf>(v, v);                    // quad_perm:[1,0,3,2]
+  v = MAX ? fmaxf(v, t) : v + t;
+  t = dpp_f32<0x4E, 0xf>(v, v);                          // quad_perm:[2,3,0,1]
+  v = MAX ? fmaxf(v, t) : v + t;
+  if (L > 4) {
+    t = dpp_f32<0x141, 0xf>(v, v);                       // row_half_mirror
+    v = MAX ? fmaxf(v, t) : v + t;
+  }
+  if (L > 8) {
+    t = dpp_f32<0x140, 0xf>(v, v);                       // row_mirror
+    v = MAX ? fmaxf(v, t) : v + t;
+  }
+  return v;
+}
 MSC_DEV uint32_t narrow_table_rows(const FeatDesc &fd) {
   switch (fd.family) {
     case MSC_BB: case MSC_BBNC: return 2;
@@ -416,8 +435,7 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
     for (int j = 0; j < 4; j++)
       if (kb + j >= K) sc[j] = -INFINITY;
     float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int w = 1; w < L; w <<= 1) m = fmaxf(m, __shfl_xor(m, w, 64));
+    m = narrow_allreduce<L, true>(m);
     float p[4], sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -425,12 +443,21 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
       sum += p[j];
     }
     float incl = sum;
-#pragma unroll
-    for (int w = 1; w < L; w <<= 1) {
-      const float t = __shfl_up(incl, w, L);
-      if (q >= w) incl += t;
+    {                                                     // inclusive scan over the L lanes: row_shr by 1, 2, 4, 8 (zero fill)
+      float t = dpp_f32<0x111, 0xf>(0.f, incl);
+      if (q >= 1) incl += t;
+      t = dpp_f32<0x112, 0xf>(0.f, incl);
+      if (q >= 2) incl += t;
+      if (L > 4) {
+        t = dpp_f32<0x114, 0xf>(0.f, incl);
+        if (q >= 4) incl += t;
+      }
+      if (L > 8) {
+        t = dpp_f32<0x118, 0xf>(0.f, incl);
+        if (q >= 8) incl += t;
+      }
     }
-    const float total = __shfl(incl, sub * L + L - 1, 64);
+    const float total = narrow_allreduce<L, false>(sum);
     const float dart = philox_uniform01(seed, sweep, row_id0 + n) * total;
     float c = incl - sum;
     int nmiss = 0;
