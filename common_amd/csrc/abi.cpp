@@ -897,6 +897,17 @@ static bool gp_beyond_table(const msc_state *st, uint32_t f) {
   return false;
 }
 
+// does any row's leave-one-out value need the formula paths (dm always; gp / bnb when the column holds counts beyond the table)?
+static bool loo_needs_heavy(const msc_state *st) {
+  for (uint32_t f = 0; f < st->nfeat; f++) {
+    const int fam = st->feats[f].family;
+    if (fam == MSC_DM) return true;
+    // (a count family's table covers 0 .. the bound column's maximum unless that exceeds the cap)
+    if (is_count_family(fam) && gp_beyond_table(st, f)) return true;
+  }
+  return false;
+}
+
 // K <= 64 and nothing but scalar families whose tables all fit 64 KiB of LDS at 4 L groups per row: the narrow tiling
 // (kernels_sweep.hip k_narrow).  Returns L = lanes per row (4 / 8 / 16) or 0, and the table rows to stage.
 static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
@@ -929,7 +940,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   hipStream_t s = st->ctx->stream;
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->ctx->num_cus, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
   }
   uint32_t n_niw = 0;
@@ -1180,7 +1191,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
-      if (launch_loo_own(s, st->ctx->num_cus, st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
     uint32_t narrow_rows = 0;

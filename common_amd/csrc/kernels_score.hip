@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void k_commit_prepare(const FeatDesc *__restri
 // sum over scalar features of score_value(group z[n] minus row n, row n).  One thread per row,
 // everything in double; niw features add theirs inside the niw kernel.
 // ---------------------------------------------------------------------------
+// HEAVY = false leaves out the branches with lgamma chains in them (gp / bnb counts beyond the table, dm): with them
+// inlined the kernel sits at 225 VGPRs, 2 waves per SIMD, for rows that never take them (launch_loo_own picks)
+template <bool HEAVY>
 __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ feats, int nfeat,
                                                   uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                   const int32_t *__restrict__ z,
@@ -204,16 +207,17 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         break;
       case MSC_GP: {
         const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-        s += v < fd.vcap ? (double)fd.loo_tab[(size_t)v * kpad + g] : gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], v);
+        if (v < fd.vcap) s += (double)fd.loo_tab[(size_t)v * kpad + g];
+        else if (HEAVY) s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], v);
       } break;
       case MSC_BNB: {
         const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-        s += v < fd.vcap ? (double)fd.loo_tab[(size_t)v * kpad + g]
-                         : bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
+        if (v < fd.vcap) s += (double)fd.loo_tab[(size_t)v * kpad + g];
+        else if (HEAVY) s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
       } break;
       case MSC_DM:
-        s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad,
-                             reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim, true);
+        if (HEAVY) s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad,
+                                        reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim, true);
         break;
       case MSC_DD: {
         int v = reinterpret_cast<const int32_t *>(fd.col)[row];
@@ -475,11 +479,15 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_loo_own(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
+int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own) {
   (void)num_cus;
-  hipLaunchKernelGGL(k_loo_own, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
-                     kpad, row0, nrows, z, crp, own);
+  if (heavy)
+    hipLaunchKernelGGL(k_loo_own<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
+                       kpad, row0, nrows, z, crp, own);
+  else
+    hipLaunchKernelGGL(k_loo_own<false>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
+                       kpad, row0, nrows, z, crp, own);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
