@@ -1,6 +1,7 @@
 // mixture_state (an entity_based_state_object on the device tables) against a host twin built from the same
 // plugin API: the per-entity Gibbs loop of entity_state.hpp, group creation / deletion, likelihoods,
 // suff-stat bags, hyper-parameter changes, and the batched sweep.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -100,6 +101,7 @@ int main() {
   CHECK(threw);                                              // already assigned
 
   // the Gibbs assignment kernel, entity by entity, for a stretch of entities
+  const auto t_loop = std::chrono::steady_clock::now();
   size_t moved = 0;
   for (size_t e = 0; e < 60; e++) {
     if (iface.empty_groups().empty()) iface.create_group(rng);
@@ -125,10 +127,25 @@ int main() {
       if (iface.empty_groups().size() > 1) iface.delete_group(gid);
   }
   CHECK(moved > 0);
+  std::printf("per-entity gibbs move (remove + score + twin checks + add, 4 components): %.0f us\n",
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop).count() / 60.0);
   size_t total = 0;
   for (size_t gid : iface.groups()) total += iface.groupsize(gid);
   CHECK(total == N);
 
+  {  // the same move without the twin's per-value device calls: what a downstream kernel pays per entity
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t e = 100; e < 160; e++) {
+      const size_t old = iface.remove_value(e, rng);
+      twin_apply(old, e, false);
+      auto sc = iface.score_value(e, rng);
+      const size_t pick = sc.first[util::sample_discrete_log(sc.second, rng)];
+      iface.add_value(pick, e, rng);
+      twin_apply(pick, e, true);
+    }
+    std::printf("per-entity gibbs move incl. 8 per-value twin calls: %.0f us\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 60.0);
+  }
   // likelihoods and bags against the twin
   for (size_t gid : iface.groups())
     for (size_t f = 0; f < 4; f++) {
