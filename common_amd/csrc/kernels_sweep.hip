@@ -341,7 +341,7 @@ MSC_DEV uint32_t narrow_table_rows(const FeatDesc &fd) {
     default: return 0;
   }
 }
-template <int L, bool SWEEP>
+template <int L, int S, bool SWEEP>
 __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad,
                                                  uint64_t row0, uint64_t nrows, const int32_t *__restrict__ z,
                                                  const float *__restrict__ own, const float *__restrict__ crp,
@@ -376,50 +376,85 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
   }
   const uint64_t seed = SWEEP ? rng[0] : 0, sweep = SWEEP ? rng[1] : 0;
   const bool vec_ok = !SWEEP && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  // A wave carries S steps at a time (S x 64 / L rows, one accumulator each) and walks the features once for all
+  // of them: the descriptor of a feature is fetched once per S steps and the S value loads are in flight together
+  // (one step at a time, a row's walk over its features was one load latency after the other).
   const uint64_t nsteps = (nrows + kRowsPerStep - 1) / kRowsPerStep;
+  const uint64_t nbatches = (nsteps + S - 1) / S;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
-  for (uint64_t step = wave_id; step < nsteps; step += nwaves) {
-    const uint64_t n = step * kRowsPerStep + sub;          // relative to row0
-    const bool has_row = n < nrows;
-    const uint64_t row = row0 + (has_row ? n : 0);
-    int gz = -1;
-    float erow = le0;
-    if (loo && has_row) {
-      gz = z[n];
-      if (pri && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+  for (uint64_t batch = wave_id; batch < nbatches; batch += nwaves) {
+    uint64_t nn[S];
+    bool has[S];
+    int gzs[S];
+    float4 accs[S];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+      nn[i] = (batch * S + i) * kRowsPerStep + sub;        // relative to row0
+      has[i] = nn[i] < nrows;
+      gzs[i] = -1;
+      float erow = le0;
+      if (loo && has[i]) {
+        gzs[i] = z[nn[i]];
+        if (pri && gzs[i] >= 0) erow = __builtin_isinf(crp[kpad + gzs[i]]) ? le1 : le0;
+      }
+      accs[i] = pri ? crp_prior4(logcnt, erow) : make_float4(0, 0, 0, 0);
     }
-    float4 acc = pri ? crp_prior4(logcnt, erow) : make_float4(0, 0, 0, 0);
     uint32_t off = 0;
     for (int f = 0; f < nfeat; f++) {
       const FeatDesc &fd = feats[f];
       const float4 *tab = nlds + off + q;
       off += narrow_table_rows(fd) * L;
-      if (!has_row || fd.family == MSC_NOOP || (fd.mask != nullptr && fd.mask[row] != 0)) continue;
+      if (fd.family == MSC_NOOP) continue;
+      uint32_t raw[S];
+      bool use[S];
+#pragma unroll
+      for (int i = 0; i < S; i++) {
+        const uint64_t row = row0 + (has[i] ? nn[i] : 0);
+        use[i] = has[i] && !(fd.mask != nullptr && fd.mask[row] != 0);
+        raw[i] = fd.family == MSC_BB || fd.family == MSC_BBNC ? (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0)
+                                                              : reinterpret_cast<const uint32_t *>(fd.col)[row];
+      }
       switch (fd.family) {
         case MSC_BB: case MSC_BBNC:
-          add4(acc, tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 1 : 0) * L]);
+#pragma unroll
+          for (int i = 0; i < S; i++)
+            if (use[i]) add4(accs[i], tab[raw[i] * L]);
           break;
-        case MSC_DD: {
-          int v = reinterpret_cast<const int32_t *>(fd.col)[row];
-          v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
-          add4(acc, tab[v * L]);
-        } break;
-        case MSC_GP: case MSC_BNB: {
-          const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-          if (v < fd.vcap) add4(acc, tab[v * L]);        // (the host only takes this path when every count is in the table)
-        } break;
+        case MSC_DD:
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            int v = (int)raw[i];
+            v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
+            if (use[i]) add4(accs[i], tab[v * L]);
+          }
+          break;
+        case MSC_GP: case MSC_BNB:
+#pragma unroll
+          for (int i = 0; i < S; i++)
+            if (use[i] && raw[i] < fd.vcap) add4(accs[i], tab[raw[i] * L]);   // (the host only takes this path when every count is in the table)
+          break;
         case MSC_NICH: {
-          const float x = reinterpret_cast<const float *>(fd.col)[row];
           const float4 mh = tab[NICH_MU_HI * L], ml = tab[NICH_MU_LO * L], c0 = tab[NICH_C0 * L], c1l = tab[NICH_C1LN2 * L],
                        c1 = tab[NICH_C1 * L], c2 = tab[NICH_C2 * L];
-          acc.x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-          acc.y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-          acc.z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-          acc.w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            if (!use[i]) continue;
+            const float x = __uint_as_float(raw[i]);
+            accs[i].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+            accs[i].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+            accs[i].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+            accs[i].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+          }
         } break;
         default: break;
       }
     }
+#pragma unroll
+    for (int si = 0; si < S; si++) {
+    const uint64_t n = nn[si];
+    const bool has_row = has[si];
+    const int gz = gzs[si];
+    float4 acc = accs[si];
     if (loo && gz >= 0 && (uint32_t)gz / 4 == (uint32_t)q) {     // this lane holds the row's own group
       const float v = own[n];
       const int c = gz & 3;
@@ -476,22 +511,35 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
       pick = k < (int)K ? k : (int)K - 1;
     }
     if (has_row && q == 0) z_out[n] = pick;
+    }
   }
 }
 
 static size_t g_narrow_lds_limit = 64 * 1024;
+template <int L, int S, bool SWEEP>
+static int launch_narrow_s(hipStream_t stream, uint64_t gx, size_t lds_bytes, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                           uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
+                           float *out, uint64_t ld, uint64_t row_id0, int32_t *z_out, const uint64_t *rng, ZeroSpans zero) {
+  hipLaunchKernelGGL((k_narrow<L, S, SWEEP>), dim3((unsigned)(gx ? gx : 1)), dim3(256), lds_bytes, stream, feats_dev, nfeat, K, kpad,
+                     row0, nrows, z, own, crp, out, ld, row_id0, z_out, rng, zero);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 template <int L, bool SWEEP>
 static int launch_narrow_t(hipStream_t stream, int num_cus, size_t lds_bytes, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                            uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                            float *out, uint64_t ld, uint64_t row_id0, int32_t *z_out, const uint64_t *rng, ZeroSpans zero) {
   if (lds_bytes > g_narrow_lds_limit) return -2;
   const uint64_t steps = (nrows + 64 / L - 1) / (64 / L);
-  uint64_t gx = (steps + 3) / 4;
   const uint64_t cap = (uint64_t)num_cus * 8;
+  // 8 steps per wave visit once that still leaves ~4 waves per SIMD of work; few rows: one step each, spread out
+  if (steps >= (uint64_t)num_cus * 16 * 8) {
+    uint64_t gx = ((steps + 7) / 8 + 3) / 4;
+    if (gx > cap) gx = cap;
+    return launch_narrow_s<L, 8, SWEEP>(stream, gx, lds_bytes, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld, row_id0, z_out, rng, zero);
+  }
+  uint64_t gx = (steps + 3) / 4;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL((k_narrow<L, SWEEP>), dim3((unsigned)(gx ? gx : 1)), dim3(256), lds_bytes, stream, feats_dev, nfeat, K, kpad,
-                     row0, nrows, z, own, crp, out, ld, row_id0, z_out, rng, zero);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return launch_narrow_s<L, 1, SWEEP>(stream, gx, lds_bytes, feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld, row_id0, z_out, rng, zero);
 }
 // lanes_per_row: 4, 8 or 16 (abi.cpp narrow_lanes); table_rows: sum over features of narrow_table_rows
 int launch_narrow(hipStream_t stream, int num_cus, int lanes_per_row, uint32_t table_rows, bool sweep, const FeatDesc *feats_dev,
