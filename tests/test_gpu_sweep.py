@@ -173,3 +173,40 @@ def test_sweep_rows_far_below_the_score_bound_take_the_exact_maximum(gpu_ctx):
     st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
     want, scores = orc.sweep([(fs[0][0], fs[0][1], f["values"])], K, 2.5, z, seed, sweep_idx, "f64", want_scores=True)
     _check_agreement(zt.cpu().numpy(), want, scores, seed, sweep_idx, 0.995)
+
+
+@pytest.mark.parametrize("N,K", [(600_000, 16), (300_000, 20), (140_000, 50)])
+def test_narrow_tiling_at_the_sizes_that_take_eight_steps_per_wave(gpu_ctx, N, K):
+    """K <= 64 runs k_narrow (4 / 8 / 16 lanes per row); from ~32k wave steps on a wave carries eight steps at a time.
+    Scores (plain, leave-one-out + prior) on sampled rows and the whole sweep against the oracle."""
+    import common_amd
+    from tests.gpu_helpers import crp_prior_matrix, oracle_scores, rel_err, TOL
+    rng = np.random.default_rng(K)
+    specs = [(orc.BB, 0), (orc.NICH, 0), (orc.GP, 0), (orc.DD, 6)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K - 1, N).astype(np.int32)            # the last group stays empty
+    z[1234] = -1
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    counts = np.bincount(z[z >= 0], minlength=K)
+    st.set_group_counts(counts.astype(np.uint32))
+    st.set_alpha(1.7)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    rows = np.concatenate([[0, 1234, N - 1], rng.choice(N, 400, replace=False)])
+    rt = torch.from_numpy(rows).to(gpu_ctx.torch_device)
+    plain = st.score_value(view)
+    assert rel_err(plain[rt].cpu().numpy(), oracle_scores(feats, fs, rows=rows)).max() <= TOL
+    loo = st.score_value(view, z=zt, crp_prior=True)
+    prior = crp_prior_matrix(counts, 1.7, z[rows])
+    want = oracle_scores(feats, fs, z=z, rows=rows) + prior
+    # groups of ~40k rows: the prior term is log(40k) = 10.6 and the likelihood terms cancel most of it, so the float
+    # sum rounds relative to its terms, not to the result (either tiling: 1.4e-6 / 1.6e-6 of the result measured)
+    err = np.abs(loo[rt].cpu().numpy() - want) / np.maximum(1.0, np.maximum(np.abs(want), np.abs(prior)))
+    assert err.max() <= TOL
+    st.sweep_assign(view, zt, seed=5, sweep=1)
+    got = zt.cpu().numpy()
+    feats_o = [(F, ss64, f["values"]) for f, (F, ss64, _) in zip(feats, fs)]
+    want_z, scores = orc.sweep(feats_o, K, 1.7, z, 5, 1, "f64", want_scores=True)
+    _check_agreement(got, want_z, scores, 5, 1, 0.998)
