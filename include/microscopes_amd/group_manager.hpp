@@ -175,6 +175,26 @@ public:
     return std::pair<std::size_t, T &>(gid, g.data_);
   }
 
+  // the whole assignment vector at once (every gid must exist): sizes and the empty set follow in O(n + groups)
+  void reassign_all(const std::vector<ssize_t> &a) {
+    if (a.size() != assignments_.size()) throw std::runtime_error("wrong number of entities");
+    for (auto &g : groups_) g.second.count_ = 0;
+    gd<T> *last = nullptr;                               // consecutive entities mostly share few groups: skip the map when they repeat
+    ssize_t last_gid = -2;
+    for (ssize_t gid : a) {
+      if (gid == -1) continue;
+      if (gid != last_gid) {
+        last = &group(std::size_t(gid));
+        last_gid = gid;
+      }
+      last->count_++;
+    }
+    assignments_ = a;
+    gempty_.clear();
+    for (const auto &g : groups_)
+      if (!g.second.count_) gempty_.insert(g.first);
+  }
+
   // sequential CRP probability of the assignment vector
   float score_assignment() const {
     std::map<ssize_t, std::size_t> seen;

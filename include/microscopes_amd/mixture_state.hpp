@@ -74,12 +74,13 @@ public:
 
   // ---- sizes and the partition ----
   size_t nentities() const override { return n_; }
-  size_t ngroups() const override { return gm_.ngroups(); }
+  size_t ngroups() const override { sync(); return gm_.ngroups(); }
   size_t ncomponents() const override { return hypers_.size(); }
-  std::vector<ssize_t> assignments() const override { return gm_.assignments(); }
-  std::vector<size_t> groups() const override { return gm_.groups(); }
-  size_t groupsize(size_t gid) const override { return gm_.groupsize(gid); }
+  std::vector<ssize_t> assignments() const override { sync(); return gm_.assignments(); }
+  std::vector<size_t> groups() const override { sync(); return gm_.groups(); }
+  size_t groupsize(size_t gid) const override { sync(); return gm_.groupsize(gid); }
   std::vector<size_t> empty_groups() const override {
+    sync();
     return std::vector<size_t>(gm_.empty_groups().begin(), gm_.empty_groups().end());
   }
 
@@ -95,7 +96,7 @@ public:
   }
 
   // ---- sufficient statistics (identifier = group id) ----
-  std::vector<common::ident_t> suffstats_identifiers(size_t) const override { return gm_.groups(); }
+  std::vector<common::ident_t> suffstats_identifiers(size_t) const override { sync(); return gm_.groups(); }
   common::suffstats_bag_t get_suffstats(size_t c, common::ident_t gid) const override { return fetch_group(c, gid)->get_ss(); }
   void set_suffstats(size_t c, common::ident_t gid, const common::suffstats_bag_t &ss) override {
     common::rng_t rng;
@@ -111,6 +112,7 @@ public:
 
   // ---- membership ----
   void add_value(size_t gid, size_t eid, common::rng_t &) override {
+    sync();
     const size_t slot = gm_.add_value(gid, eid);
     push_params();
     z_host_[eid] = int32_t(slot);
@@ -118,6 +120,7 @@ public:
     check(msc_accumulate(st_, view_, nullptr, eid, 1, z_dev_ + eid, 0));
   }
   size_t remove_value(size_t eid, common::rng_t &) override {
+    sync();
     const auto r = gm_.remove_value(eid);                 // (throws if the entity is not assigned)
     check(msc_accumulate(st_, view_, nullptr, eid, 1, z_dev_ + eid, MSC_ACC_SUBTRACT));
     z_host_[eid] = -1;
@@ -129,6 +132,7 @@ public:
   // unnormalised log-probability of the entity joining each group, empty groups included (alpha / n_empty each).
   // The likelihood terms come from one device pass over all slots; the prior is added here from the host partition.
   void inplace_score_value(scores_t &scores, size_t eid, common::rng_t &) const override {
+    sync();
     if (gm_.assignments().at(eid) != -1) throw std::runtime_error("entity must be removed before it is scored");
     mixture_state *self = const_cast<mixture_state *>(this);
     self->push_params();
@@ -143,9 +147,10 @@ public:
     }
   }
 
-  float score_assignment() const override { return gm_.score_assignment(); }
+  float score_assignment() const override { sync(); return gm_.score_assignment(); }
   using common::entity_based_state_object::score_likelihood;
   float score_likelihood(size_t c, common::ident_t gid, common::rng_t &) const override {
+    sync();
     if (c >= hypers_.size()) throw std::runtime_error("invalid component");
     const size_t slot = gm_.group(gid).data_;
     const_cast<mixture_state *>(this)->push_params();
@@ -156,6 +161,7 @@ public:
   }
   // every group of a component with one device pass and one copy (the per-id form above costs a pass each)
   float score_likelihood(size_t c, common::rng_t &) const override {
+    sync();
     if (c >= hypers_.size()) throw std::runtime_error("invalid component");
     const_cast<mixture_state *>(this)->push_params();
     check(msc_score_data(st_, sd_dev_));
@@ -167,14 +173,12 @@ public:
   }
 
   // ---- the supply of empty groups ----
-  size_t create_group(common::rng_t &) override {
-    if (free_slots_.empty()) throw std::runtime_error("all max_groups device slots are in use");
-    auto r = gm_.create_group();
-    r.second = free_slots_.back();
-    free_slots_.pop_back();
-    return r.first;
+  size_t create_group(common::rng_t &rng) override {
+    sync();
+    return create_group_unsynced(rng);
   }
   void delete_group(size_t gid) override {
+    sync();
     const size_t slot = gm_.group(gid).data_;
     gm_.delete_group(gid);                                // (throws unless the group is empty: its device column is all zero then)
     free_slots_.push_back(slot);
@@ -184,6 +188,7 @@ public:
   // the whole partition at once: entity e joins group gids[e] (groups are created as needed); replaces
   // N add_value calls by one accumulate pass
   void assign_all(const std::vector<size_t> &labels, common::rng_t &rng) {
+    sync();
     if (labels.size() != n_) throw std::runtime_error("one label per entity expected");
     for (size_t e = 0; e < n_; e++)
       if (gm_.assignments()[e] != -1) throw std::runtime_error("assign_all wants every entity unassigned");
@@ -201,40 +206,60 @@ public:
   // One synchronous Gibbs sweep over all entities on the device: every entity is scored leave-one-out against the
   // tables as they stand, with the CRP prior (every free slot is an empty group on offer and they share alpha,
   // which is the prior of "a new group" however many empty groups the host has created), re-drawn with the
-  // counter-based uniform Philox(seed, sweep, entity), and the tables are rebuilt.  Afterwards the host partition
-  // follows the new assignment vector: slots that gained their first member get a group id, groups that lost
-  // every member stay as empty groups (delete_group them if unwanted).
-  void gibbs_sweep(uint64_t seed, uint64_t sweep, common::rng_t &rng) {
-    for (size_t e = 0; e < n_; e++)
-      if (gm_.assignments()[e] == -1) throw std::runtime_error("gibbs_sweep wants every entity assigned");
+  // counter-based uniform Philox(seed, sweep, entity), and the tables are rebuilt.  The host partition follows the new
+  // assignment vector the next time something looks at it (sync(): slots that gained their first member get a group
+  // id, groups that lost every member stay as empty groups -- delete_group them if unwanted), so a run of sweeps costs
+  // the host nothing.
+  void gibbs_sweep(uint64_t seed, uint64_t sweep, common::rng_t &) {
+    if (!stale_)                                        // (after a sweep every entity is assigned)
+      for (size_t e = 0; e < n_; e++)
+        if (gm_.assignments()[e] == -1) throw std::runtime_error("gibbs_sweep wants every entity assigned");
     push_params();
     check(msc_sweep_step(st_, view_, nullptr, 0, n_, 0, z_dev_, seed, sweep));
-    check(msc_device_download(ctx_, z_host_.data(), z_dev_, 4 * n_));
-    std::map<size_t, size_t> slot_gid;
-    for (auto it = gm_.begin(); it != gm_.end(); ++it) slot_gid[it->second.data_] = it->first;
-    for (size_t e = 0; e < n_; e++) {
-      const size_t slot = size_t(z_host_[e]);
-      auto it = slot_gid.find(slot);
-      if (it == slot_gid.end()) {                         // a free slot was drawn: it becomes a group
-        const auto pos = std::find(free_slots_.begin(), free_slots_.end(), slot);
-        if (pos == free_slots_.end()) throw std::runtime_error("device drew a slot the host does not know");
-        std::swap(*pos, free_slots_.back());
-        it = slot_gid.emplace(slot, create_group(rng)).first;
-      }
-      if (size_t(gm_.assignments()[e]) != it->second) {
-        gm_.remove_value(e);
-        gm_.add_value(it->second, e);
-      }
-    }
+    stale_ = true;      // the host partition follows when somebody looks at it: sweep after sweep costs the host nothing
   }
 
   // the device handles, for callers that mix in calls of microscopes_hip.h
   msc_state *device_state() const { return st_; }
   msc_dataview *device_view() const { return view_; }
   const int32_t *device_assignments() const { return z_dev_; }
-  size_t slot_of(size_t gid) const { return gm_.group(gid).data_; }
+  size_t slot_of(size_t gid) const { sync(); return gm_.group(gid).data_; }
 
 private:
+  // After batched sweeps the partition lives in z_dev_ alone; anything that reads or edits the host's view of it
+  // calls this first: one download and an O(n + groups) rebuild (slots that gained their first member become
+  // groups, groups that lost every member stay as empty groups).
+  void sync() const {
+    if (!stale_) return;
+    mixture_state *self = const_cast<mixture_state *>(this);
+    self->stale_ = false;
+    check(msc_device_download(ctx_, self->z_host_.data(), z_dev_, 4 * n_));
+    std::vector<ssize_t> slot_gid(kmax_, -1);
+    for (auto it = gm_.begin(); it != gm_.end(); ++it) slot_gid[it->second.data_] = ssize_t(it->first);
+    std::vector<ssize_t> a(n_);
+    for (size_t e = 0; e < n_; e++) {
+      const size_t slot = size_t(z_host_[e]);
+      if (slot >= kmax_) throw std::runtime_error("device drew a slot outside the table");
+      if (slot_gid[slot] < 0) {                          // a free slot was drawn: it becomes a group
+        const auto pos = std::find(self->free_slots_.begin(), self->free_slots_.end(), slot);
+        if (pos == self->free_slots_.end()) throw std::runtime_error("device drew a slot the host does not know");
+        std::swap(*pos, self->free_slots_.back());
+        common::rng_t rng;
+        slot_gid[slot] = ssize_t(self->create_group_unsynced(rng));
+      }
+      a[e] = slot_gid[slot];
+    }
+    self->gm_.reassign_all(a);
+  }
+  size_t create_group_unsynced(common::rng_t &) {
+    if (free_slots_.empty()) throw std::runtime_error("all max_groups device slots are in use");
+    auto r = gm_.create_group();
+    r.second = free_slots_.back();
+    free_slots_.pop_back();
+    return r.first;
+  }
+  mutable bool stale_ = false;
+
   // hyper-parameters can change behind our back (mutators are raw pointers), so what the device holds is
   // compared with the hypers objects before every device call; a handful of floats per component
   void push_params() {
@@ -254,6 +279,7 @@ private:
     }
   }
   std::shared_ptr<models::group> fetch_group(size_t c, size_t gid) const {
+    sync();
     const size_t slot = gm_.group(gid).data_;
     common::rng_t rng;
     auto g = hypers_.at(c)->create_group(rng);
@@ -266,6 +292,7 @@ private:
     return g;
   }
   void store_group(size_t c, size_t gid, const models::group &g) {
+    sync();
     const size_t slot = gm_.group(gid).data_;
     std::vector<uint8_t> rec;
     g.device_record_get(*hypers_.at(c), rec);

@@ -202,6 +202,41 @@ int main() {
       if (st2.groupsize(gid)) by_size_b[st2.groupsize(gid) * 1000003 + size_t(as2.end() - std::find(as2.begin(), as2.end(), ssize_t(gid)))] = st2.get_suffstats(2, gid);
     CHECK(by_size_a == by_size_b);
   }
+  // a run of batched sweeps on a larger state: the host partition is only rebuilt when somebody looks
+  {
+    const size_t M = 200000;
+    std::vector<Row> big(M);
+    for (size_t i = 0; i < M; i++) big[i] = rows[i % N];
+    recarray::row_major_dataview bdata(reinterpret_cast<const uint8_t *>(big.data()), nullptr, M, types);
+    hip::mixture_state bs(mdl, bdata, 32);
+    bs.get_cluster_hp_mutator("alpha").set<float>(1.f);
+    std::vector<size_t> labels(M);
+    for (size_t i = 0; i < M; i++) labels[i] = i % 5;
+    bs.assign_all(labels, rng);
+    bs.gibbs_sweep(7, 0, rng);                                // (first step: setup)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int sw = 1; sw <= 20; sw++) bs.gibbs_sweep(7, uint64_t(sw), rng);
+    const auto as = bs.assignments();                         // <- download + rebuild happen here, once
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("20 batched sweeps of %zu entities + one partition sync: %.0f us per sweep\n", M, us / 20.0);
+    std::map<size_t, size_t> cnt;
+    for (ssize_t a : as) {
+      CHECK(a >= 0);
+      cnt[size_t(a)]++;
+    }
+    size_t tot = 0;
+    for (size_t gid : bs.groups()) {
+      CHECK(bs.groupsize(gid) == (cnt.count(gid) ? cnt[gid] : 0));
+      tot += bs.groupsize(gid);
+    }
+    CHECK(tot == M);
+    // and the per-entity calls continue from the synced partition
+    const size_t old = bs.remove_value(17, rng);
+    auto sc = bs.score_value(17, rng);
+    CHECK(sc.first == bs.groups());
+    bs.add_value(old, 17, rng);
+    CHECK(bs.groupsize(old) == cnt[old]);
+  }
   // vector-valued components (packed records on the ABI): niw(2) and dm(3) through the same interface
   {
 #pragma pack(push, 1)
