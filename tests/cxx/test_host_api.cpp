@@ -112,6 +112,18 @@ static void test_group_manager_bookkeeping_and_serialization() {
   CHECK(g.groupsize(1) == 2 && g.groupsize(2) == 2 && g.groupsize(4) == 0 && g.groupsize(6) == 1);
   CHECK(g.empty_groups().size() == 1 && g.empty_groups().count(4) == 1);
   CHECK(g.pseudocount(1, g.group(1)) == 2.f && g.pseudocount(4, g.group(4)) == 2.f);   // alpha / 1 empty group
+  {  // the whole partition at once (what a batched sweep hands back): sizes and the empty set follow
+    gm h(10);
+    for (int i = 0; i < 7; i++) h.create_group();
+    h.delete_group(3);
+    const std::vector<ssize_t> a = {4, 4, 4, 0, 6, 6, -1, 0, 4, 4};
+    h.reassign_all(a);
+    CHECK(h.assignments() == a && h.groupsize(4) == 5 && h.groupsize(0) == 2 && h.groupsize(6) == 2 && h.groupsize(1) == 0);
+    CHECK(h.empty_groups() == (std::set<size_t>{1, 2, 5}));
+    bool bad = false;
+    try { h.reassign_all({3, 0, 0, 0, 0, 0, 0, 0, 0, 0}); } catch (const std::runtime_error &) { bad = true; }
+    CHECK(bad);                                           // gid 3 was deleted
+  }
   bool threw = false;
   try { g.delete_group(1); } catch (const std::runtime_error &) { threw = true; }
   CHECK(threw);
