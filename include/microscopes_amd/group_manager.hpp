@@ -178,6 +178,14 @@ public:
   // the whole assignment vector at once (every gid must exist): sizes and the empty set follow in O(n + groups)
   void reassign_all(const std::vector<ssize_t> &a) {
     if (a.size() != assignments_.size()) throw std::runtime_error("wrong number of entities");
+    {                                                    // check before touching anything
+      ssize_t seen = -2;
+      for (ssize_t gid : a)
+        if (gid != -1 && gid != seen) {
+          (void)find(std::size_t(gid));                  // throws "invalid gid"
+          seen = gid;
+        }
+    }
     for (auto &g : groups_) g.second.count_ = 0;
     gd<T> *last = nullptr;                               // consecutive entities mostly share few groups: skip the map when they repeat
     ssize_t last_gid = -2;

@@ -122,7 +122,7 @@ static void test_group_manager_bookkeeping_and_serialization() {
     CHECK(h.empty_groups() == (std::set<size_t>{1, 2, 5}));
     bool bad = false;
     try { h.reassign_all({3, 0, 0, 0, 0, 0, 0, 0, 0, 0}); } catch (const std::runtime_error &) { bad = true; }
-    CHECK(bad);                                           // gid 3 was deleted
+    CHECK(bad && h.groupsize(4) == 5);                    // gid 3 was deleted; nothing changed
   }
   bool threw = false;
   try { g.delete_group(1); } catch (const std::runtime_error &) { threw = true; }
