@@ -1153,7 +1153,14 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
 }
 
 // score + sample in one kernel; niw and gp-beyond-table features and wide K need the materialised path
+// one niw feature of small dimension on few groups: the fused k_sweep_niw1
+static bool sweep_is_niw1(const msc_state *st) {
+  static const bool off = std::getenv("MSC_NIW_NO_SMALL") != nullptr;
+  return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && st->feats[0].dim <= 8 && st->K <= 64;
+}
+
 static bool sweep_is_fused(const msc_state *st) {
+  if (sweep_is_niw1(st)) return true;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   for (uint32_t f = 0; f < st->nfeat; f++)
     if (st->feats[f].family == MSC_NIW || gp_beyond_table(st, f)) return false;
@@ -1188,7 +1195,11 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     zero.a = reinterpret_cast<unsigned long long *>(st->red_i64); zero.na = st->n_i64;
     zero.b = reinterpret_cast<unsigned long long *>(st->red_f64); zero.nb = st->n_f64;
   }
-  if (sweep_is_fused(st)) {
+  if (sweep_is_niw1(st)) {
+    rc = launch_sweep_niw1(s, cus, st->feats[0].dim, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc,
+                           st->rng_dev, zero);
+    if (zeroed) *zeroed = rc == 0;
+  } else if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
       if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))

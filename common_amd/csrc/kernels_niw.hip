@@ -34,9 +34,7 @@ namespace msc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { NIW_C0 = 0, NIW_C1 = 1, NIW_A_LOO = 2, NIW_B_LOO = 3, NIW_C_LOO = 4, NIW_LOGDET_HI = 5, NIW_LOGDET_LO = 6,
-       NIW_ROWS = 7 };   // row NIW_ROWS holds the prior's ln det Psi (hi, lo) in its first two slots
-constexpr int kNiwPad = 32;
+// (NIW_* table rows and kNiwPad: msc_internal.hpp)
 
 // hp layout: {kappa, nu, mu[d], psi[d*d]}; raw_f32 per group: {sum_x[d], sum_xxT[d*d]}
 __global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__ feats, uint32_t f,

@@ -251,6 +251,120 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// One niw feature of small dimension, K <= 64 -- a Gaussian mixture on low-dimensional vectors, the textbook use of
+// the family: the whole Gibbs step fused like k_sweep_nich1.  A lane keeps one group (lower triangle of W_k, W_k mu_k
+// and the constants in registers), the rows of a chunk stream past as wave-uniform values, and q = |W_k (x - mu_k)|^2
+// gives both the plain score and, on the lane that owns the row's group, the leave-one-out one in closed form
+// (kernels_niw.hip header).  Nothing is materialised: the step was k_loo_own + a prior pass + the score kernel in
+// accumulate mode + k_niw_loo_patch + k_sample_rows before (210 us of kernels for 262k rows x 128 groups at dim 3).
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
+                                                     uint64_t row0, uint64_t nrows, uint64_t row_id0,
+                                                     int32_t *__restrict__ z, const float *__restrict__ crp,
+                                                     const uint64_t *__restrict__ rng, int chunk_rows, ZeroSpans zero) {
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  const FeatDesc fd = feats[0];
+  const int lane = threadIdx.x & 63;
+  const uint32_t k = (uint32_t)lane;
+  const bool has_k = k < K;
+  const size_t kc = has_k ? k : 0;
+  double w[D * (D + 1) / 2], nb[D];
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) w[i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
+    nb[i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];
+  }
+  const float c0 = fd.tab[(size_t)NIW_C0 * kpad + kc], c1 = fd.tab[(size_t)NIW_C1 * kpad + kc];
+  const float a_loo = fd.tab[(size_t)NIW_A_LOO * kpad + kc], b_loo = fd.tab[(size_t)NIW_B_LOO * kpad + kc],
+              c_loo = fd.tab[(size_t)NIW_C_LOO * kpad + kc];
+  const float lc = crp[kc], lm1 = crp[kpad + kc];          // log count, log(count - 1); -inf when that is zero
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (uint64_t)gridDim.x * 4;
+  for (uint64_t chunk = wave_id; chunk < nchunks; chunk += nwaves) {
+    const uint64_t rb = chunk * chunk_rows;
+    const int nr = (int)((nrows - rb) < (uint64_t)chunk_rows ? (nrows - rb) : (uint64_t)chunk_rows);
+    const bool has_row = lane < nr;
+    double xd[D];
+    bool msk = false;
+#pragma unroll
+    for (int j = 0; j < D; j++) xd[j] = has_row ? (double)X[(row0 + rb + lane) * D + j] : 0.0;
+    if (has_row && fd.mask != nullptr)
+#pragma unroll
+      for (int j = 0; j < D; j++) msk |= fd.mask[(row0 + rb + lane) * D + j] != 0;
+    const int gz = has_row ? z[rb + lane] : -1;
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    const unsigned long long mbits = __builtin_amdgcn_ballot_w64(msk);
+    int znew = gz;
+    for (int r = 0; r < nr; r++) {
+      const int g = __builtin_amdgcn_readlane(gz, r);
+      const bool own = g >= 0 && (uint32_t)g == k;
+      // removing the row empties its group when that group has one member: one more empty group shares alpha
+      const bool empties = __builtin_amdgcn_ballot_w64(own && __builtin_isinf(lm1)) != 0ull;
+      const float e_row = empties ? le1 : le0;
+      float prior = own ? (__builtin_isinf(lm1) ? e_row : lm1) : (__builtin_isinf(lc) ? e_row : lc);
+      float s[1];
+      if ((mbits >> r) & 1ull) {
+        s[0] = prior;                                      // masked vector: only the prior speaks
+      } else {
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; j++)
+          x[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xd[j]), r), __builtin_amdgcn_readlane(__double2loint(xd[j]), r));
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+          double y = nb[i];
+#pragma unroll
+          for (int j = 0; j <= i; j++) y = fma(w[i * (i + 1) / 2 + j], x[j], y);
+          q = fma(y, y, q);
+        }
+        const float qf = (float)q;
+        const float plain = fmaf(-c1, log1p_acc(qf), c0);
+        const float loo = fmaf(b_loo, log1p_acc(-fminf(c_loo * qf, 0.99999994f)), a_loo);
+        s[0] = prior + (own ? loo : plain);
+      }
+      if (!has_k) s[0] = -INFINITY;
+      const int pick = sample_from_scores<1>(s, __shfl(u01, r, 64), lane, K);
+      if (lane == r) znew = pick;
+    }
+    if (has_row) z[rb + lane] = znew;
+  }
+}
+template <int D>
+static void launch_sweep_niw1_t(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad, uint64_t row0,
+                                uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng, ZeroSpans zero) {
+  int chunk_rows = 64;
+  while (chunk_rows > 4 && (nrows + chunk_rows - 1) / chunk_rows < (uint64_t)num_cus * 32) chunk_rows >>= 1;
+  uint64_t gx = ((nrows + chunk_rows - 1) / chunk_rows + 3) / 4;
+  const uint64_t cap = (uint64_t)num_cus * 4;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_sweep_niw1<D>, dim3((unsigned)(gx ? gx : 1)), dim3(256), 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z,
+                     crp, rng, chunk_rows, zero);
+}
+// one niw feature, dim <= 8, K <= 64 (abi.cpp checks)
+int launch_sweep_niw1(hipStream_t stream, int num_cus, uint32_t dim, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad,
+                      uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng,
+                      ZeroSpans zero) {
+  switch (dim) {
+    case 1: launch_sweep_niw1_t<1>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 2: launch_sweep_niw1_t<2>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 3: launch_sweep_niw1_t<3>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 4: launch_sweep_niw1_t<4>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 5: launch_sweep_niw1_t<5>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 6: launch_sweep_niw1_t<6>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 7: launch_sweep_niw1_t<7>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 8: launch_sweep_niw1_t<8>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    default: return -2;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------
 // any feature list, K <= 256: the workgroup tile of score_block.hpp, sampled from registers
 // ---------------------------------------------------------------------------
 template <int R, int W, bool DM>

@@ -192,6 +192,11 @@ inline int value_type_of(int family) {
 }
 size_t primitive_size(int t);
 
+// rows of a niw feature's float table (k_niw_prepare fills them) and the padded width of its W matrices
+enum { NIW_C0 = 0, NIW_C1 = 1, NIW_A_LOO = 2, NIW_B_LOO = 3, NIW_C_LOO = 4, NIW_LOGDET_HI = 5, NIW_LOGDET_LO = 6,
+       NIW_ROWS = 7 };   // row NIW_ROWS holds the prior's ln det Psi (hi, lo) in its first two slots
+constexpr int kNiwPad = 32;
+
 }  // namespace msc
 
 // ---- opaque objects ---------------------------------------------------------

@@ -210,3 +210,52 @@ def test_narrow_tiling_at_the_sizes_that_take_eight_steps_per_wave(gpu_ctx, N, K
     feats_o = [(F, ss64, f["values"]) for f, (F, ss64, _) in zip(feats, fs)]
     want_z, scores = orc.sweep(feats_o, K, 1.7, z, 5, 1, "f64", want_scores=True)
     _check_agreement(got, want_z, scores, 5, 1, 0.998)
+
+
+@pytest.mark.parametrize("dim,K", [(1, 5), (2, 40), (3, 64), (8, 33), (5, 1)])
+def test_sweep_single_small_niw_feature_is_one_fused_kernel(gpu_ctx, dim, K):
+    """one niw feature, dim <= 8, K <= 64 (a Gaussian mixture on low-dimensional vectors): k_sweep_niw1"""
+    got, want, scores, _ = _run(gpu_ctx, [(orc.NIW, dim)], 3000, K, seed=100 * dim + K, sweep_idx=2, empty=min(2, K - 1))
+    _check_agreement(got, want, scores, 100 * dim + K, 2, 0.997)
+
+
+def test_sweep_small_niw_with_masked_vectors_and_singletons(gpu_ctx):
+    import common_amd
+    N, K, dim, seed = 2500, 20, 3, 31
+    rng = np.random.default_rng(seed)
+    f = make_feature(orc.NIW, N, K, rng, dim)
+    z = rng.integers(0, K - 3, N).astype(np.int32)
+    z[7] = K - 3                                            # a group of one: removing the row empties it
+    z[11] = -1
+    mask = np.zeros(N, dtype=[("f0", np.bool_, (dim,))])
+    hide = rng.random(N) < 0.2
+    mask["f0"][hide, rng.integers(0, dim, hide.sum())] = True
+    keep = ~hide
+    fs = state_from_assignment([dict(f, values=f["values"][keep])], K, z[keep])
+    view = common_amd.DataView.from_recarray(gpu_ctx, np.ma.masked_array(recarray_of([f]), mask=mask))
+    st = common_amd.State(gpu_ctx, [(orc.NIW, dim)], K)
+    load_state(st, fs)
+    counts = np.bincount(z[z >= 0], minlength=K)
+    st.set_group_counts(counts.astype(np.uint32))
+    st.set_alpha(0.8)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, zt, seed=seed, sweep=0)
+    got = zt.cpu().numpy()
+    # the oracle's view: masked rows score with the prior alone
+    F, ss64, _ = fs[0]
+    from tests.gpu_helpers import crp_prior_matrix
+    like = np.zeros((N, K))
+    zk = np.where(hide, -1, z)                               # a masked row is not in its group's suff-stats: nothing to leave out
+    like[keep] = F.score_matrix(ss64, f["values"][keep], zk[keep])
+    total = like + crp_prior_matrix(counts, 0.8, z)
+    agree = 0
+    for n in range(N):
+        p = orc.scores_to_probs(total[n])
+        pick = orc.sample_discrete(p, orc.uniform01(seed, 0, n))
+        if pick == got[n]:
+            agree += 1
+        else:
+            cdf = np.cumsum(p)
+            lo, hi = sorted((int(got[n]), int(pick)))
+            assert abs(cdf[lo] - orc.uniform01(seed, 0, n)) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, n
+    assert agree >= 0.997 * N
