@@ -1156,7 +1156,7 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
 // one niw feature of small dimension on few groups: the fused k_sweep_niw1
 static bool sweep_is_niw1(const msc_state *st) {
   static const bool off = std::getenv("MSC_NIW_NO_SMALL") != nullptr;
-  return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && st->feats[0].dim <= 8 && st->K <= 64;
+  return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && (int)st->K <= sweep_niw1_max_groups(st->feats[0].dim);
 }
 
 static bool sweep_is_fused(const msc_state *st) {

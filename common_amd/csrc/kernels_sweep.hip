@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
 // (kernels_niw.hip header).  Nothing is materialised: the step was k_loo_own + a prior pass + the score kernel in
 // accumulate mode + k_niw_loo_patch + k_sample_rows before (210 us of kernels for 262k rows x 128 groups at dim 3).
 // ---------------------------------------------------------------------------
-template <int D>
+template <int D, int G>
 __global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
                                                      uint64_t row0, uint64_t nrows, uint64_t row_id0,
                                                      int32_t *__restrict__ z, const float *__restrict__ crp,
@@ -267,20 +267,26 @@ __global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__
   zero_spans(zero);
   const FeatDesc fd = feats[0];
   const int lane = threadIdx.x & 63;
-  const uint32_t k = (uint32_t)lane;
-  const bool has_k = k < K;
-  const size_t kc = has_k ? k : 0;
-  double w[D * (D + 1) / 2], nb[D];
+  const uint32_t kb = (uint32_t)(G * lane);              // lane l owns groups G l .. G l + G - 1 (k order, as the draw wants)
+  double w[G][D * (D + 1) / 2], nb[G][D];
+  float c0[G], c1[G], a_loo[G], b_loo[G], c_loo[G], lc[G], lm1[G];
 #pragma unroll
-  for (int i = 0; i < D; i++) {
+  for (int t = 0; t < G; t++) {
+    const size_t kc = kb + t < K ? kb + t : 0;
 #pragma unroll
-    for (int j = 0; j <= i; j++) w[i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
-    nb[i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) w[t][i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
+      nb[t][i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];
+    }
+    c0[t] = fd.tab[(size_t)NIW_C0 * kpad + kc];
+    c1[t] = fd.tab[(size_t)NIW_C1 * kpad + kc];
+    a_loo[t] = fd.tab[(size_t)NIW_A_LOO * kpad + kc];
+    b_loo[t] = fd.tab[(size_t)NIW_B_LOO * kpad + kc];
+    c_loo[t] = fd.tab[(size_t)NIW_C_LOO * kpad + kc];
+    lc[t] = crp[kc];                                       // log count, log(count - 1); -inf when that is zero
+    lm1[t] = crp[kpad + kc];
   }
-  const float c0 = fd.tab[(size_t)NIW_C0 * kpad + kc], c1 = fd.tab[(size_t)NIW_C1 * kpad + kc];
-  const float a_loo = fd.tab[(size_t)NIW_A_LOO * kpad + kc], b_loo = fd.tab[(size_t)NIW_B_LOO * kpad + kc],
-              c_loo = fd.tab[(size_t)NIW_C_LOO * kpad + kc];
-  const float lc = crp[kc], lm1 = crp[kpad + kc];          // log count, log(count - 1); -inf when that is zero
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
   const float *X = reinterpret_cast<const float *>(fd.col);
   const uint64_t nchunks = (nrows + chunk_rows - 1) / chunk_rows;
@@ -302,40 +308,45 @@ __global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__
     int znew = gz;
     for (int r = 0; r < nr; r++) {
       const int g = __builtin_amdgcn_readlane(gz, r);
-      const bool own = g >= 0 && (uint32_t)g == k;
-      // removing the row empties its group when that group has one member: one more empty group shares alpha
-      const bool empties = __builtin_amdgcn_ballot_w64(own && __builtin_isinf(lm1)) != 0ull;
-      const float e_row = empties ? le1 : le0;
-      float prior = own ? (__builtin_isinf(lm1) ? e_row : lm1) : (__builtin_isinf(lc) ? e_row : lc);
-      float s[1];
-      if ((mbits >> r) & 1ull) {
-        s[0] = prior;                                      // masked vector: only the prior speaks
-      } else {
-        double x[D];
+      bool own[G], own_single = false;
 #pragma unroll
-        for (int j = 0; j < D; j++)
-          x[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xd[j]), r), __builtin_amdgcn_readlane(__double2loint(xd[j]), r));
-        double q = 0.0;
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-          double y = nb[i];
-#pragma unroll
-          for (int j = 0; j <= i; j++) y = fma(w[i * (i + 1) / 2 + j], x[j], y);
-          q = fma(y, y, q);
-        }
-        const float qf = (float)q;
-        const float plain = fmaf(-c1, log1p_acc(qf), c0);
-        const float loo = fmaf(b_loo, log1p_acc(-fminf(c_loo * qf, 0.99999994f)), a_loo);
-        s[0] = prior + (own ? loo : plain);
+      for (int t = 0; t < G; t++) {
+        own[t] = g >= 0 && (uint32_t)g == kb + t;
+        own_single |= own[t] && __builtin_isinf(lm1[t]);
       }
-      if (!has_k) s[0] = -INFINITY;
-      const int pick = sample_from_scores<1>(s, __shfl(u01, r, 64), lane, K);
+      // removing the row empties its group when that group has one member: one more empty group shares alpha
+      const float e_row = __builtin_amdgcn_ballot_w64(own_single) != 0ull ? le1 : le0;
+      const bool masked = (mbits >> r) & 1ull;
+      double x[D];
+#pragma unroll
+      for (int j = 0; j < D; j++)
+        x[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xd[j]), r), __builtin_amdgcn_readlane(__double2loint(xd[j]), r));
+      float s[G];
+#pragma unroll
+      for (int t = 0; t < G; t++) {
+        const float prior = own[t] ? (__builtin_isinf(lm1[t]) ? e_row : lm1[t]) : (__builtin_isinf(lc[t]) ? e_row : lc[t]);
+        float like = 0.f;                                  // masked vector: only the prior speaks
+        if (!masked) {
+          double q = 0.0;
+#pragma unroll
+          for (int i = 0; i < D; i++) {
+            double y = nb[t][i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) y = fma(w[t][i * (i + 1) / 2 + j], x[j], y);
+            q = fma(y, y, q);
+          }
+          const float qf = (float)q;
+          like = own[t] ? fmaf(b_loo[t], log1p_acc(-fminf(c_loo[t] * qf, 0.99999994f)), a_loo[t]) : fmaf(-c1[t], log1p_acc(qf), c0[t]);
+        }
+        s[t] = kb + t < K ? prior + like : -INFINITY;
+      }
+      const int pick = sample_from_scores<G>(s, __shfl(u01, r, 64), lane, K);
       if (lane == r) znew = pick;
     }
     if (has_row) z[rb + lane] = znew;
   }
 }
-template <int D>
+template <int D, int G>
 static void launch_sweep_niw1_t(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad, uint64_t row0,
                                 uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   int chunk_rows = 64;
@@ -343,24 +354,37 @@ static void launch_sweep_niw1_t(hipStream_t stream, int num_cus, const FeatDesc 
   uint64_t gx = ((nrows + chunk_rows - 1) / chunk_rows + 3) / 4;
   const uint64_t cap = (uint64_t)num_cus * 4;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(k_sweep_niw1<D>, dim3((unsigned)(gx ? gx : 1)), dim3(256), 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z,
-                     crp, rng, chunk_rows, zero);
+  hipLaunchKernelGGL((k_sweep_niw1<D, G>), dim3((unsigned)(gx ? gx : 1)), dim3(256), 0, stream, feats_dev, K, kpad, row0, nrows, row_id0,
+                     z, crp, rng, chunk_rows, zero);
 }
-// one niw feature, dim <= 8, K <= 64 (abi.cpp checks)
+// groups per lane the registers allow at a dimension: D (D + 3) / 2 doubles per group, up to 56 in all
+int sweep_niw1_max_groups(uint32_t dim) { return dim <= 4 ? 256 : dim == 5 ? 128 : dim <= 8 ? 64 : 0; }
+// one niw feature, K <= sweep_niw1_max_groups(dim)
 int launch_sweep_niw1(hipStream_t stream, int num_cus, uint32_t dim, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad,
                       uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng,
                       ZeroSpans zero) {
+  if ((int)K > sweep_niw1_max_groups(dim)) return -2;
+#define MSC_NIW1(Dv, Gv) launch_sweep_niw1_t<Dv, Gv>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero)
+#define MSC_NIW1_G(Dv)                \
+  if (K <= 64) MSC_NIW1(Dv, 1);       \
+  else if (K <= 128) MSC_NIW1(Dv, 2); \
+  else MSC_NIW1(Dv, 4)
   switch (dim) {
-    case 1: launch_sweep_niw1_t<1>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 2: launch_sweep_niw1_t<2>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 3: launch_sweep_niw1_t<3>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 4: launch_sweep_niw1_t<4>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 5: launch_sweep_niw1_t<5>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 6: launch_sweep_niw1_t<6>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 7: launch_sweep_niw1_t<7>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
-    case 8: launch_sweep_niw1_t<8>(stream, num_cus, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero); break;
+    case 1: MSC_NIW1_G(1); break;
+    case 2: MSC_NIW1_G(2); break;
+    case 3: MSC_NIW1_G(3); break;
+    case 4: MSC_NIW1_G(4); break;
+    case 5:
+      if (K <= 64) MSC_NIW1(5, 1);
+      else MSC_NIW1(5, 2);
+      break;
+    case 6: MSC_NIW1(6, 1); break;
+    case 7: MSC_NIW1(7, 1); break;
+    case 8: MSC_NIW1(8, 1); break;
     default: return -2;
   }
+#undef MSC_NIW1_G
+#undef MSC_NIW1
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -57,6 +57,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
+int sweep_niw1_max_groups(uint32_t dim);
 int launch_sweep_niw1(hipStream_t stream, int num_cus, uint32_t dim, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad,
                       uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng,
                       ZeroSpans zero);

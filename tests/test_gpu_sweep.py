@@ -212,7 +212,7 @@ def test_narrow_tiling_at_the_sizes_that_take_eight_steps_per_wave(gpu_ctx, N, K
     _check_agreement(got, want_z, scores, 5, 1, 0.998)
 
 
-@pytest.mark.parametrize("dim,K", [(1, 5), (2, 40), (3, 64), (8, 33), (5, 1)])
+@pytest.mark.parametrize("dim,K", [(1, 5), (2, 40), (3, 64), (8, 33), (5, 1), (2, 100), (4, 200), (5, 128), (3, 256)])
 def test_sweep_single_small_niw_feature_is_one_fused_kernel(gpu_ctx, dim, K):
     """one niw feature, dim <= 8, K <= 64 (a Gaussian mixture on low-dimensional vectors): k_sweep_niw1"""
     got, want, scores, _ = _run(gpu_ctx, [(orc.NIW, dim)], 3000, K, seed=100 * dim + K, sweep_idx=2, empty=min(2, K - 1))
