@@ -752,12 +752,18 @@ static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, u
     rows += 2 * vcap;                                   // (hi, lo) row pairs
   }
   if (meta != h.dm_meta || d.dm_meta == nullptr) {
-    if ((size_t)rows + 4 > h.tab_rows_cap) {           // grow the table buffer (the old one stays owned until destroy)
+    if ((size_t)rows + 4 > h.tab_rows_cap || h.loo64 == nullptr) {   // grow the table buffers (the old ones stay owned until destroy)
       float *t = nullptr;
       MSC_TRY(dev_alloc(st->owned, &t, ((size_t)rows + 4) * st->kpad));
       h.tab = t;
       h.tab_rows_cap = (size_t)rows + 4;
       d.tab = t;
+      // the leave-one-out twin of the tables ("count v against the group minus v"), one double per entry: read by
+      // k_loo_own only, once per row and stage
+      double *l = nullptr;
+      MSC_TRY(dev_alloc(st->owned, &l, ((size_t)rows / 2 + 1) * st->kpad));
+      h.loo64 = l;
+      d.loo64 = l;
     }
     h.dm_meta = meta;
     MSC_HIP(hipMemcpyAsync(h.dm_meta_dev, h.dm_meta.data(), sizeof(uint32_t) * meta.size(), hipMemcpyHostToDevice, s));
@@ -901,9 +907,8 @@ static bool gp_beyond_table(const msc_state *st, uint32_t f) {
 static bool loo_needs_heavy(const msc_state *st) {
   for (uint32_t f = 0; f < st->nfeat; f++) {
     const int fam = st->feats[f].family;
-    if (fam == MSC_DM) return true;
-    // (a count family's table covers 0 .. the bound column's maximum unless that exceeds the cap)
-    if (is_count_family(fam) && gp_beyond_table(st, f)) return true;
+    // (a count family's table covers 0 .. the bound column's maximum unless that exceeds the cap; dm likewise, by row total)
+    if ((is_count_family(fam) || fam == MSC_DM) && gp_beyond_table(st, f)) return true;
   }
   return false;
 }

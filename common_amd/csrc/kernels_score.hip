@@ -110,9 +110,14 @@ __global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__
   } else {
     for (uint32_t i = 0; i < fd.dim; i++) n += (double)fd.raw_u32[(size_t)i * kpad + k];
   }
+  double *tl = fd.loo64 != nullptr ? fd.loo64 + (size_t)(first / 2) * kpad + k : nullptr;   // entry v of this stage
   for (uint32_t v = blockIdx.z; v < rows; v += gridDim.z) {   // (table rows dealt out over the z-slices, as in k_prepare)
     const double term = sub < fd.dim ? dm_cat_term(a, n, (double)v) : dm_sum_term(fd.aux, n, (double)v);
     dm_split(term, t[(size_t)(2 * v) * kpad], t[(size_t)(2 * v + 1) * kpad]);
+    // the same count against the group without it (only read for a row that is in the group, so n >= v there)
+    if (tl != nullptr)
+      tl[(size_t)v * kpad] = n >= (double)v ? (sub < fd.dim ? dm_cat_term(a, n - (double)v, (double)v) : dm_sum_term(fd.aux, n - (double)v, (double)v))
+                                            : 0.0;
   }
 }
 
@@ -215,10 +220,20 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         if (v < fd.vcap) s += (double)fd.loo_tab[(size_t)v * kpad + g];
         else if (HEAVY) s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
       } break;
-      case MSC_DM:
-        if (HEAVY) s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad,
-                                        reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim, true);
-        break;
+      case MSC_DM: {
+        // dim + 1 lookups in the leave-one-out tables k_dm_prepare fills (it was 2 (dim + 1) lgamma per row); rows
+        // whose total is beyond the tables take the formula
+        const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
+        const uint32_t tot = fd.dm_tot[row];
+        if (tot < kGpMaxTable && fd.loo64 != nullptr && fd.dm_meta != nullptr) {
+          for (uint32_t i = 0; i <= fd.dim; i++) {
+            const uint32_t v = i < fd.dim ? (uint32_t)x[i] : tot;
+            if (v) s += fd.loo64[(size_t)(fd.dm_meta[2 * i] / 2 + v) * kpad + g];      // (entry 0 is exactly zero)
+          }
+        } else if (HEAVY) {
+          s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad, x, true);
+        }
+      } break;
       case MSC_DD: {
         int v = reinterpret_cast<const int32_t *>(fd.col)[row];
         v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
