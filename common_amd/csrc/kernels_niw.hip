@@ -301,6 +301,20 @@ MSC_DEV double shfl_xor_f64(double v, int mask) {
 }
 
 // HALF: dim <= 16 -- the lower 16 rows of W are zero, so is their half of the output: one MFMA chain instead of two
+// v + v[lane ^ 16], then that + its [lane ^ 32]: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows of
+// one register with the even rows of another, so (x, x) comes back as (the even partner, the odd partner) of every lane
+// -- two VALU instructions per 32-bit half where ds_bpermute needs an address and an LDS round trip.  Same additions
+// in the same order as the shuffles it replaces.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+MSC_DEV double xsum_rows_f64(double v) {
+  u32x2 a = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  u32x2 b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  const double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+  b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 template <int JB, bool LOO, bool ACCUM, bool HALF>
 __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict__ feats, uint32_t f,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
@@ -367,8 +381,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
         double qp = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) qp = HALF ? fma(acc0[i], acc0[i], qp) : fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
-        qp += shfl_xor_f64(qp, 16);
-        const double q = qp + shfl_xor_f64(qp, 32);
+        const double q = xsum_rows_f64(qp);       // over the four lanes c, c + 16, c + 32, c + 48
         if (mine) {
           if (slot == 0) qkeep[jb][0] = q;
           else if (slot == 1) qkeep[jb][1] = q;
