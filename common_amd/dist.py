@@ -3,8 +3,8 @@ over xGMI on ROCm), rows block-sharded, group tables replicated.
 
 The scoring pass has no collective.  A Gibbs sweep has exactly one exchange: the sum all-reduce
 of the additive suff-stat tables (int64 counts -> bit-exact, float64 sums) between sweeps; the
-payload is K * O(10) * 8 bytes, i.e. latency-bound, so it is issued as two plain all-reduces (one
-per dtype) and not bucketed or overlapped.
+payload is K * O(10) * 8 bytes, i.e. latency-bound, so both tables travel in one float64 all-reduce
+(counts below 2**53 add exactly as doubles) and nothing is bucketed or overlapped.
 """
 import torch
 import torch.distributed as dist
@@ -17,14 +17,29 @@ def shard_rows(nrows, world, rank):
     return lo, base + (1 if rank < rem else 0)
 
 
-def allreduce_tables(red_i64, red_f64, group=None):
-    """In-place SUM of the additive tables across ranks (no-op when not distributed)."""
+def allreduce_tables(red_i64, red_f64, group=None, pack=None):
+    """In-place SUM of the additive tables across ranks (no-op when not distributed).
+
+    The payload is a few KB, so the cost is the collective's latency: both tables travel in ONE float64
+    all-reduce.  The counts ride along as doubles -- integers below 2**53 add exactly and in any order, so they
+    come back bit-exact -- and are copied into the int64 table again.  `pack`: a float64 scratch tensor of
+    red_i64.numel() + red_f64.numel() elements to reuse (one is allocated otherwise)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    if red_i64.numel():
-        dist.all_reduce(red_i64, op=dist.ReduceOp.SUM, group=group)
-    if red_f64.numel():
-        dist.all_reduce(red_f64, op=dist.ReduceOp.SUM, group=group)
+    ni, nf = red_i64.numel(), red_f64.numel()
+    if ni == 0 or nf == 0:                      # only one kind of table: nothing to merge
+        if ni:
+            dist.all_reduce(red_i64, op=dist.ReduceOp.SUM, group=group)
+        if nf:
+            dist.all_reduce(red_f64, op=dist.ReduceOp.SUM, group=group)
+        return
+    if pack is None or pack.numel() != ni + nf or pack.device != red_f64.device:
+        pack = torch.empty(ni + nf, dtype=torch.float64, device=red_f64.device)
+    pack[:ni].copy_(red_i64)                    # int64 -> float64, exact for |count| < 2**53
+    pack[ni:].copy_(red_f64)
+    dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+    red_i64.copy_(pack[:ni])                    # integer-valued doubles -> int64, exact
+    red_f64.copy_(pack[ni:])
 
 
 class ShardedSweep(object):
@@ -35,11 +50,13 @@ class ShardedSweep(object):
         self.row_id0 = int(first_global_row)
         self.group = group
         self.red_i64, self.red_f64 = state.reduce_buffers()
+        self._pack = torch.empty(self.red_i64.numel() + self.red_f64.numel(), dtype=torch.float64,
+                                 device=self.red_f64.device)
 
     def rebuild_tables(self):
         """suff-stats of the global assignment: local accumulate, sum across ranks, commit."""
         self.state.accumulate(self.view, self.z, reset=True, commit=False)
-        allreduce_tables(self.red_i64, self.red_f64, self.group)
+        allreduce_tables(self.red_i64, self.red_f64, self.group, self._pack)
         self.state.commit_reduce()
 
     def _alone(self):

@@ -30,7 +30,7 @@ def _worker(rank, world, port, x, z, K, out):
     # additive tables of one NICH feature, laid out as msc_state_reduce_buffers documents:
     # int64 [group sizes | counts], float64 [sum x | sum x^2]
     cnt = np.bincount(zs, minlength=K).astype(np.int64)
-    red_i = torch.from_numpy(np.concatenate([cnt, cnt]))
+    red_i = torch.from_numpy(np.concatenate([cnt, cnt, np.array([2**45 + 3 * rank + 1], dtype=np.int64)]))   # (+ a count far beyond float32)
     red_f = torch.from_numpy(np.concatenate([np.bincount(zs, weights=xs, minlength=K),
                                              np.bincount(zs, weights=xs * xs, minlength=K)]))
     allreduce_tables(red_i, red_f)
@@ -53,7 +53,8 @@ def test_allreduce_of_sharded_tables_equals_whole_data(tmp_path):
     red_i, red_f = np.load(out + "_i.npy"), np.load(out + "_f.npy")
     F = orc.Family(orc.NICH, dict(mu=0., kappa=1., sigmasq=1., nu=1.), 0, "f64")
     ss = F.accumulate(K, x, z)
-    assert np.array_equal(red_i[:K], ss["count"]) and np.array_equal(red_i[K:], ss["count"])  # bit-exact
+    assert np.array_equal(red_i[:K], ss["count"]) and np.array_equal(red_i[K:2 * K], ss["count"])  # bit-exact
+    assert int(red_i[2 * K]) == 2 * 2**45 + 5      # the counts ride the float64 all-reduce: exact below 2**53
     n = ss["count"].astype(np.float64)
     mean = red_f[:K] / n
     ctv = red_f[K:] - n * mean * mean
