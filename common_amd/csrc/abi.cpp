@@ -1062,10 +1062,10 @@ static int commit(msc_state *st) {
 // sweep kernel did it); commit and prepare in one launch, which also moves the random stream on (msc_sweep_step)
 enum : uint32_t { kAccZeroed = 0x100, kAccThenPrepare = 0x200 };
 
-static int commit_and_prepare(msc_state *st) {
+static int commit_and_prepare(msc_state *st, bool bump_rng = true) {
   hipStream_t s = st->ctx->stream;
   if (launch_commit_prepare(s, st->desc_dev, (int)st->nfeat, st->K, st->kpad, st->red_i64, st->cnt_u32, st->alpha,
-                            st->logpc, st->rng_dev, prepare_value_slices(st)))
+                            st->logpc, bump_rng ? st->rng_dev : nullptr, prepare_value_slices(st)))
     return fail(MSC_EHIP, "k_commit_prepare launch failed");
   for (uint32_t f = 0; f < st->nfeat; f++) {
     const msc_feature_host &h = st->feats[f];
@@ -1393,7 +1393,8 @@ extern "C" int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n
 extern "C" int msc_state_commit_reduce(msc_state *st) {
   MSC_REQUIRE(st, "null state");
   MSC_HIP(hipSetDevice(st->ctx->device));
-  return commit(st);
+  // (what follows a reduce is the next sweep's scoring: commit and prepare in one launch, as in msc_sweep_step)
+  return commit_and_prepare(st, false);
 }
 
 extern "C" int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64_t *shape,
