@@ -80,6 +80,8 @@ _SIGS = {
                                    C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
     "msc_sweep_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                  C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "msc_sweep_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
     "msc_sweep_step_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "msc_state_reduce_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -1373,6 +1373,23 @@ extern "C" int msc_sweep_step(msc_state *st, const msc_dataview *view, const uin
   return MSC_OK;
 }
 
+// The row-sharded form of the step: everything up to the exchange.  msc_sweep_assign + msc_accumulate(RESET | NO_COMMIT)
+// with the step's fusions (the sweep kernel empties the additive tables; the sweep index moves on in the commit);
+// the caller all-reduces msc_state_reduce_buffers and calls msc_state_commit_reduce.
+extern "C" int msc_sweep_step_begin(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                                    uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep) {
+  MSC_REQUIRE(st && view && (z_dev || nrows == 0), "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  if (nrows == 0) return accumulate_impl(st, view, cols, row0, 0, z_dev, MSC_ACC_RESET | MSC_ACC_NO_COMMIT);
+  bool zeroed = false;
+  MSC_TRY(sweep_assign_impl(st, view, cols, row0, nrows, row_id0, z_dev, seed, sweep, &zeroed));
+  st->rng_valid = false;                                // (until the commit has moved the device's pair on)
+  st->rng_bump_pending = true;
+  st->rng_next_sweep = sweep + 1;
+  return accumulate_impl(st, view, cols, row0, nrows, z_dev,
+                         MSC_ACC_RESET | MSC_ACC_NO_COMMIT | (zeroed ? (uint32_t)kAccZeroed : 0u));
+}
+
 extern "C" int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *graph_steps) {
   MSC_REQUIRE(st, "null argument");
   if (eager_steps) *eager_steps = st->step_graph.n_eager;
@@ -1394,7 +1411,14 @@ extern "C" int msc_state_commit_reduce(msc_state *st) {
   MSC_REQUIRE(st, "null state");
   MSC_HIP(hipSetDevice(st->ctx->device));
   // (what follows a reduce is the next sweep's scoring: commit and prepare in one launch, as in msc_sweep_step)
-  return commit_and_prepare(st, false);
+  const bool bump = st->rng_bump_pending;
+  MSC_TRY(commit_and_prepare(st, bump));
+  if (bump) {
+    st->rng_bump_pending = false;
+    st->rng_valid = true;
+    st->rng_sweep = st->rng_next_sweep;
+  }
+  return MSC_OK;
 }
 
 extern "C" int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64_t *shape,

@@ -286,6 +286,8 @@ struct msc_state {
   uint64_t *rng_dev = nullptr;
   uint64_t rng_seed = 0, rng_sweep = 0;
   bool rng_valid = false;
+  bool rng_bump_pending = false;       // msc_sweep_step_begin left the increment of the sweep index to msc_state_commit_reduce
+  uint64_t rng_next_sweep = 0;
   // a whole sweep step (assign + accumulate + commit) captured as a graph for its steady state (abi.cpp msc_sweep_step)
   struct StepGraph {
     hipGraphExec_t exec = nullptr;

@@ -66,5 +66,6 @@ class ShardedSweep(object):
         if self._alone():         # nothing to exchange: the whole step is one library call (graph-replayed when it repeats)
             self.state.sweep_step(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
             return
-        self.state.sweep_assign(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
-        self.rebuild_tables()
+        self.state.sweep_step_begin(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
+        allreduce_tables(self.red_i64, self.red_f64, self.group, self._pack)
+        self.state.commit_reduce()

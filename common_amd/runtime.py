@@ -367,6 +367,15 @@ class State(object):
                                             row0 if row_id0 is None else row_id0,
                                             C.c_void_p(z.data_ptr()), int(seed), int(sweep)))
 
+    def sweep_step_begin(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
+        """the sharded step up to the exchange: follow with all-reduce of reduce_buffers() and commit_reduce()"""
+        n = view.nrows - row0 if nrows is None else nrows
+        if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
+            raise ValueError("z must be a contiguous int32 tensor of nrows entries")
+        L.check(self.ctx.lib.msc_sweep_step_begin(self._h, view._h, self._cols(cols), row0, n,
+                                                  row0 if row_id0 is None else row_id0,
+                                                  C.c_void_p(z.data_ptr()), int(seed), int(sweep)))
+
     def sweep_step_stats(self):
         """(steps run launch by launch, steps run as one graph launch)"""
         e, g = C.c_uint64(), C.c_uint64()

@@ -242,6 +242,13 @@ int msc_sweep_assign(msc_state *st, const msc_dataview *view, const uint32_t *co
  */
 int msc_sweep_step(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
                    uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep);
+/*
+ * The row-sharded form of the step, up to the exchange: msc_sweep_assign +
+ * msc_accumulate(MSC_ACC_RESET | MSC_ACC_NO_COMMIT) with the step's fusions.
+ * Then all-reduce msc_state_reduce_buffers and call msc_state_commit_reduce.
+ */
+int msc_sweep_step_begin(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                         uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep);
 /* how many msc_sweep_step calls on this state ran launch by launch / as a graph launch */
 int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *graph_steps);
 

@@ -106,3 +106,24 @@ def test_sharded_driver_uses_the_step_when_alone(gpu_ctx):
         drv.sweep(9, sweep)
         assert torch.equal(za, zg), sweep
     _same_tables(ea, gr, nfeat)
+
+
+@pytest.mark.parametrize("specs,N,K", [([(orc.NICH, 0)], 4000, 48), ([(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0)], 3000, 100),
+                                       ([(orc.NIW, 3)], 2000, 20), ([(orc.BB, 0), (orc.NICH, 0)], 1200, 400)])
+def test_sharded_form_of_the_step_equals_the_two_calls(gpu_ctx, specs, N, K):
+    """msc_sweep_step_begin + (all-reduce) + msc_state_commit_reduce: the step as a row shard runs it"""
+    view, (ea, za), (sh, zs), nfeat = _pair(gpu_ctx, specs, N, K, seed=7 * N + K)
+    for sweep in range(6):
+        ea.sweep_assign(view, za, seed=3, sweep=sweep)
+        ea.accumulate(view, za)
+        sh.sweep_step_begin(view, zs, seed=3, sweep=sweep)
+        sh.commit_reduce()
+        assert torch.equal(za, zs), sweep
+    _same_tables(ea, sh, nfeat)
+    # a jump in the sweep index and a plain two-call sweep in between are picked up
+    ea.sweep_assign(view, za, seed=3, sweep=40); ea.accumulate(view, za)
+    sh.sweep_assign(view, zs, seed=3, sweep=40); sh.accumulate(view, zs)
+    ea.sweep_assign(view, za, seed=3, sweep=41); ea.accumulate(view, za)
+    sh.sweep_step_begin(view, zs, seed=3, sweep=41); sh.commit_reduce()
+    assert torch.equal(za, zs)
+    _same_tables(ea, sh, nfeat)
