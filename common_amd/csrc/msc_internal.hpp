@@ -94,7 +94,7 @@ struct FeatDesc {
   double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
   double aux;              // dd: sum of the alphas
   uint32_t vcap;           // gp, bnb: rows of the exact table (min(column max + 1, kGpMaxTable))
-  uint32_t pad1;
+  uint32_t dm_rows;        // dm: rows of all its (hi, lo) count tables together (host: bind_dm_column), 0 otherwise
   const uint32_t *dm_meta;    // dm: [dim+1][2] per stage (device): {first table row, entries in the table};
                               //     count v of a stage occupies table rows first + 2v (hi) and first + 2v + 1 (lo)
   const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)

@@ -237,6 +237,60 @@ MSC_DEV void score_dm_feature(const FeatDesc &fd, uint32_t kpad, uint32_t kb, in
   }
 }
 
+// The same feature with its tables staged in LDS by the group (abi.cpp plan_groups does that when all dim + 1 of
+// them fit the slot: small counts).  Branch-free: what must not count -- a masked row, a row whose total is beyond
+// the tables (k_gp_large_fix scores it whole) -- reads entry 0, which is exactly zero; four rows' reads go out before
+// their adds.  (From L2 the lookups of 4 x dm(4) on 1M rows ran at 1.9 ms; staged, with the branches, 1.75; this: 1.38.)
+template <int R>
+MSC_DEV void score_dm_feature_staged(const FeatDesc &fd, int lane, uint64_t myrow, bool has_row,
+                                     const float4 *__restrict__ lds, float4 (&acc)[R]) {
+  const uint32_t nst = fd.dim + 1;
+  const unsigned long long mbits = fd.mask == nullptr ? 0ull : __builtin_amdgcn_ballot_w64(load_masked<true>(fd, myrow, has_row));
+  float4 hi[R], lo[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) hi[r] = lo[r] = make_float4(0, 0, 0, 0);
+  const uint32_t *xrow = reinterpret_cast<const uint32_t *>(fd.col) + myrow * fd.dim;
+  const uint32_t tot = (has_row && fd.col != nullptr) ? fd.dm_tot[myrow] : 0u;
+  const bool tabled = has_row && fd.col != nullptr && tot < kGpMaxTable;
+  for (uint32_t s0 = 0; s0 < nst; s0 += kDmBatch) {
+    uint32_t vals[kDmBatch];
+#pragma unroll
+    for (int j = 0; j < kDmBatch; j++) {
+      const uint32_t st = s0 + j;
+      vals[j] = 0u;
+      if (st < nst && tabled) vals[j] = st < fd.dim ? xrow[st] : tot;
+    }
+#pragma unroll
+    for (int j = 0; j < kDmBatch; j++) {
+      const uint32_t st = s0 + j;
+      if (st >= nst) break;
+      const uint32_t first_row = fd.dm_meta[2 * st], vcap = fd.dm_meta[2 * st + 1];
+      const float4 *stab = lds + (size_t)(fd.grp_off + first_row) * 64 + lane;
+#pragma unroll
+      for (int r0 = 0; r0 < R; r0 += 4) {
+        float4 th[4], tl[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          uint32_t vr = (uint32_t)lane_bcast((int)vals[j], r0 + q);
+          vr = (vr >= vcap || ((mbits >> (r0 + q)) & 1ull)) ? 0u : vr;
+          th[q] = stab[(2 * vr) * 64];
+          tl[q] = stab[(2 * vr + 1) * 64];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          add4(hi[r0 + q], th[q]);
+          add4(lo[r0 + q], tl[q]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    add4(hi[r], lo[r]);
+    add4(acc[r], hi[r]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // States without a dm feature.  The host packs consecutive features into groups whose table blocks
 // fit the 128 KiB LDS slot together (FeatDesc::grp_*, abi.cpp plan_groups); the workgroup copies a
@@ -336,7 +390,10 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
       const FeatDesc &fd = feats[f];
       if (fd.kind != MSC_KIND_GENERIC) continue;        // the next run starts here
       if (DM && fd.family == MSC_DM) {
-        if (fd.dm_meta != nullptr) score_dm_feature<R>(fd, kpad, kb, lane, myrow, has_row, acc);
+        if (fd.dm_meta != nullptr) {
+          if (fd.grp_rows != 0) score_dm_feature_staged<R>(fd, lane, myrow, has_row, lds, acc);
+          else score_dm_feature<R>(fd, kpad, kb, lane, myrow, has_row, acc);
+        }
         f++;
         continue;
       }
