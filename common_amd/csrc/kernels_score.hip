@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
       case MSC_BB:       // lookup families: the table k_prepare made of "this value against the group minus one of it"
         s += (double)fd.loo_tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
         break;
-      case MSC_BBNC:     // p does not move when a row leaves
-        s += log(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? (double)fd.raw_f32[g] : 1.0 - (double)fd.raw_f32[g]);
+      case MSC_BBNC:     // p does not move when a row leaves: the plain score's own table entry (a double log per row before)
+        s += (double)fd.tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
         break;
       case MSC_GP: {
         const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
