@@ -185,6 +185,7 @@ def run_sweep(a, ctx, st, view, z, world, rank, dist, sync_all):
     zs = z.clone()
     st.set_alpha(1.0)
     drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=rank * N)
+    drv.rebuild_tables()          # suff-stats of the global assignment (a no-op exchange on one rank)
 
     def one(sweep_idx):
         drv.sweep(seed=73, sweep_index=sweep_idx)
