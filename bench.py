@@ -1,17 +1,20 @@
 #!/usr/bin/env python
 """bench.py -- one JSON line for the driver (see the contract in the task statement).
 
-Workload at N=1: BASELINE.json configs[1] ("C2"): NICH scalar-Gaussian, N=1M rows,
-K=256 groups, D=1 feature.  One *step* = one full scoring pass: msc_score_value
-over every row x every group, the [N, K] float matrix materialised in HBM (the
-inner loop of entity_based_state_object::inplace_score_value for the whole
-dataset).  Inputs (column, group tables) are resident in HBM before timing.
+N = 1 (`python bench.py`): BASELINE.json configs[1] ("C2"): NICH scalar-Gaussian, N=1M rows, K=256 groups,
+  D=1 feature.  One *step* = one full scoring pass: msc_score_value over every row x every group, the [N, K] float
+  matrix materialised in HBM (the inner loop of entity_based_state_object::inplace_score_value for the whole dataset).
+  Inputs (column, group tables) are resident in HBM before timing; the derived tables are current (k_prepare, 9 us,
+  runs when suff-stats change, not per pass).  metric = score_value evals/sec = N*K*D / seconds per step.
+  Beside it, as extra objects on the same line: `sweep` (C2 as a Gibbs sweep), `c3`, `c4`, `c5_shard` (the other
+  BASELINE configs that fit one GPU, each with its own roofline figure), `cpu_baseline`.
 
-metric  score_value evals/sec = N*K*D*world / seconds-per-step    (weak scaling:
-        every rank owns its own N-row shard; the scoring pass has no collective)
-sweep   (extra object) rows/sec of one synchronous Gibbs sweep = fused
-        leave-one-out score + CRP prior + sample, suff-stat accumulate, and the
-        sum all-reduce of the additive tables across ranks (RCCL) + commit.
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[4] ("C5"): NICH, K=1024,
+  12.5 M rows per rank (N = 100 M at 8 ranks; weak scaling), rows block-sharded, group tables replicated.  One *step*
+  = one synchronous Gibbs sweep: fused leave-one-out score + CRP prior + sample (nothing materialised), suff-stat
+  accumulate, ONE sum all-reduce of the additive tables across ranks (RCCL over xGMI), commit + prepare -- all inside
+  the timed region.  metric = Gibbs-sweep rows/sec = rows of all ranks / seconds per step.  The N = 1 line carries the
+  same workload at one rank as `c5_shard`, so a weak-scaling ratio is value(N) / (N * c5_shard.value).
 """
 import argparse
 import json
@@ -23,7 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_F64_PEAK_TF = 78.6      # dense f64 matrix peak (MI355X spec; the table's dense figures, no sparsity)
+# vector-pipe issue roof for the kernels that are bound by it (C3 and the fused sweep): one wave
+# instruction per SIMD every 4 cycles (v_fma_f32 "one wave alone: 4", MI355X_MICROARCH.md per-instruction table),
+# 256 CUs x 4 SIMDs at the 2.4 GHz the guide's constants are quoted at = 2.46e11 wave-instructions/s
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
+C5_ROWS_PER_RANK = 12_500_000
+C5_GROUPS = 1024
 
 
 def parse():
@@ -33,17 +43,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--groups", type=int, default=256)
+    ap.add_argument("--c5-rows", type=int, default=C5_ROWS_PER_RANK, help="rows per rank of the C5 sweep")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c4 / c5_shard objects at N = 1")
+    ap.add_argument("--tune", action="store_true", help="msc_score_tune before the C2 pass (off: the default launch shape)")
     return ap.parse_args()
 
 
 def cpu_baseline(K, sample_rows):
     """oracle (float restatement, kind 'port') through the virtual group API on this host's cores."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])     # (a no-op when everything is current)
     exe = os.path.join(ROOT, "oracle", "perf_group_cpu")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = subprocess.check_output([exe, "c2", str(sample_rows), str(K), str(threads)]).decode()
     r = json.loads(out.strip().splitlines()[-1])
@@ -57,20 +69,48 @@ def cpu_baseline(K, sample_rows):
     }
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/*_pmc.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc passes)."""
+def pmc_entry(kernel_substr, key):
+    """(value per launch, file) of `key` for the kernel from the newest committed PMC summary (profiles/*_pmc.json,
+    written by tools/summarize_prof.py from separate rocprofv3 --pmc passes)."""
     import glob
-    best = None
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         for name, e in d.items():
-            if kernel_substr in name and "hbm_bytes_per_launch" in e:
-                best = (e["hbm_bytes_per_launch"]["total"], os.path.basename(f))
+            if kernel_substr in name and key in e:
+                v = e[key]
+                best = (v["total"] if "total" in v else v["avg"], os.path.basename(f))
     return best
+
+
+def timed(torch, fn, steps, warmup):
+    """HIP events on the stream the library launches on (torch's current stream is the context's stream)."""
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms = sorted(s.elapsed_time(e) for s, e in ev)
+    return wall * 1e3, sum(ms) / len(ms), ms[0]
+
+
+def c2_data(torch, dev, N, K, seed):
+    """mixture of K unit-variance normals, centres N(0, 10^2); z = the true component"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.randn(K, generator=g, device=dev) * 10.0
+    z = torch.randint(0, K, (N,), generator=g, device=dev, dtype=torch.int32)
+    x = (centres[z.long()] + torch.randn(N, generator=g, device=dev)).to(torch.float32).contiguous()
+    return x, z
 
 
 def main():
@@ -82,6 +122,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knob for a 1-GPU box: MSC_BENCH_BACKEND=gloo puts every rank on cuda:0
@@ -95,21 +136,7 @@ def main():
             dist.init_process_group(backend)
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
-
     ctx = common_amd.Context(device=local)
-    dev = ctx.torch_device
-    N, K = a.rows, a.groups
-
-    # synthetic C2 data: mixture of K unit-variance normals, centres N(0, 10^2)
-    g = torch.Generator(device=dev)
-    g.manual_seed(73 + rank)
-    centres = torch.randn(K, generator=g, device=dev) * 10.0
-    z = torch.randint(0, K, (N,), generator=g, device=dev, dtype=torch.int32)
-    x = (centres[z.long()] + torch.randn(N, generator=g, device=dev)).to(torch.float32).contiguous()
-    view = common_amd.DataView.from_tensors(ctx, [x])
-    st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)   # default hp mu=0,kappa=1,sigmasq=1,nu=1
-    st.accumulate(view, z)                                   # suff-stats from the true components
-    out = torch.empty((N, K), dtype=torch.float32, device=dev)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -117,9 +144,115 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # one-off setup outside warmup and timing: derived tables, and the launch-shape selection the library does at the
-    # first large pass of a context (abi.cpp run_score; ~10 ms)
-    st.score_value(view, out=out)
+    if world > 1:
+        line = run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all)
+    else:
+        line = run_c2(a, torch, dist, common_amd, ctx, sync_all)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: config C5, the row-sharded sweep
+# ---------------------------------------------------------------------------------------------------------------------
+def c5_setup(a, torch, common_amd, ctx, world, rank, nrows):
+    x, z = c2_data(torch, ctx.torch_device, nrows, C5_GROUPS, 73 + rank)
+    view = common_amd.DataView.from_tensors(ctx, [x])
+    st = common_amd.State(ctx, [(common_amd.NICH, 0)], C5_GROUPS)        # default hp mu=0,kappa=1,sigmasq=1,nu=1
+    st.set_alpha(1.0)
+    drv = common_amd.dist.ShardedSweep(st, view, z, first_global_row=rank * nrows)
+    drv.rebuild_tables()                     # suff-stats of the GLOBAL assignment: accumulate, all-reduce, commit
+    return x, z, view, st, drv
+
+
+def sweep_kernel_ms(torch, st, view, z, steps=5):
+    """average duration of the fused sweep kernel alone (k_sweep_nich1), HIP events around msc_sweep_assign on a copy
+    of z -- outside the timed region; the rocprof summary in profiles/ must agree"""
+    zc = z.clone()
+    _, avg, mn = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), steps, 2)
+    return avg, mn
+
+
+def sweep_roofline(nrows, K, kern_ms, kernel):
+    evals = float(nrows) * K
+    alg_bytes = 12.0 * nrows                                  # SURVEY 8d: x, z in, z out
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    insts, src = pmc_entry(kernel, "SQ_INSTS_VALU")
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": pmc_entry(kernel, "hbm_bytes_per_launch")[0] if nrows == C5_ROWS_PER_RANK else None,
+         "kernel": kernel, "kernel_avg_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+         "note": "the fused sweep materialises nothing: 12 B per row of HBM traffic, so HBM is not what binds it "
+                 "(SURVEY 8d: transcendental / vector issue rate); see valu_issue",
+         "evals_per_s": evals / (kern_ms * 1e-3)}
+    if insts is not None and nrows == C5_ROWS_PER_RANK:
+        # SQ_INSTS_VALU counts wave instructions; the roof is one per SIMD every 4 cycles
+        r["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "achieved": insts / (kern_ms * 1e-3),
+                           "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                           "frac": insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK}
+    return r
+
+
+def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
+    nrows = a.c5_rows
+    x, z, view, st, drv = c5_setup(a, torch, common_amd, ctx, world, rank, nrows)
+    idx = [0]
+
+    def one():
+        drv.sweep(seed=73, sweep_index=idx[0])
+        idx[0] += 1
+
+    for _ in range(a.warmup):
+        one()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one()
+    sync_all()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=ctx.torch_device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    kern_ms, kern_min = sweep_kernel_ms(torch, st, view, z)
+    # every rank holds the same tables after the exchange: group sizes sum to the global row count
+    total = int(st.get_group_counts().astype("int64").sum())
+    assert total == nrows * world, (total, nrows * world)
+    if rank != 0:
+        return None
+    ms = dt / a.steps * 1e3
+    return {
+        "metric": "Gibbs-sweep rows/sec", "value": float(nrows) * world / (dt / a.steps), "unit": "rows/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C5 NICH N=%d rows (%d per GPU) x K=%d groups, row-sharded synchronous Gibbs sweep: fused "
+                               "leave-one-out score + CRP prior + sample, accumulate, ONE sum all-reduce of the additive "
+                               "suff-stat tables (%s), commit + prepare" % (nrows * world, nrows, C5_GROUPS,
+                                                                            "RCCL" if backend == "nccl" else backend),
+                   "rows_per_gpu": nrows, "groups": C5_GROUPS, "features": 1, "parallelism": "row-shard x%d" % world,
+                   "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
+                   "backend": backend},
+        "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
+        "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1"),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N = 1: config C2 (the headline), plus the other single-GPU configs as extra objects
+# ---------------------------------------------------------------------------------------------------------------------
+def run_c2(a, torch, dist, common_amd, ctx, sync_all):
+    dev = ctx.torch_device
+    N, K = a.rows, a.groups
+    x, z = c2_data(torch, dev, N, K, 73)
+    view = common_amd.DataView.from_tensors(ctx, [x])
+    st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)   # default hp mu=0,kappa=1,sigmasq=1,nu=1
+    st.accumulate(view, z)                                   # suff-stats from the true components
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    tuned = None
+    if a.tune:
+        tuned = st.score_tune(view, out)                     # explicit and synchronous; never inside msc_score_value
+    st.score_value(view, out=out)                            # derived tables (k_prepare) are built here, once
     for _ in range(a.warmup):
         st.score_value(view, out=out)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -134,78 +267,140 @@ def main():
     kern_ms = sorted(s.elapsed_time(e) for s, e in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    sweep = None
+    ms = dt / a.steps * 1e3
+    evals = float(N) * K
+    alg_bytes = 4.0 * N + 4.0 * N * K          # 4.016 B per eval for C2
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_entry("k_score_nich1", "hbm_bytes_per_launch")
+    line = {
+        "metric": "score_value evals/sec", "value": evals / (dt / a.steps), "unit": "evals/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "C2 NICH scalar-Gaussian score_value pass, N=%d rows/GPU x K=%d groups x D=1, "
+                               "[N,K] f32 scores materialised; group tables prepared once before timing (k_prepare, "
+                               "9 us, runs when suff-stats change)" % (N, K),
+                   "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x1",
+                   "launch_shape": "msc_score_tune -> %s" % (tuned,) if tuned else "default (4 rows x 2 visits)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic if (N, K) == (1_000_000, 256) else None,
+                     "traffic_source": traffic_src,
+                     "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
+                     "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes,
+                     "out_va": "%#x" % out.data_ptr()},
+    }
     if not a.no_sweep:
-        try:
-            sweep = run_sweep(a, ctx, st, view, z, world, rank, dist, sync_all)
-        except common_amd.MicroscopesHipError as e:
-            if e.code != -4:
-                raise
-            sweep = {"error": str(e)}
-
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        ms = dt / a.steps * 1e3
-        evals = float(N) * K * 1 * world
-        alg_bytes = 4.0 * N + 4.0 * N * K          # 4.016 B per eval for C2
-        achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
-        line = {
-            "metric": "score_value evals/sec", "value": evals / (dt / a.steps), "unit": "evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "C2 NICH scalar-Gaussian score_value pass, N=%d rows/GPU x K=%d groups x D=1, "
-                                   "[N,K] f32 scores materialised" % (N, K),
-                       "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic("k_score_nich1") or (None, None))[0] if (N, K) == (1_000_000, 256) else None,
-                         "traffic_source": (pmc_traffic("k_score_nich1") or (None, None))[1],
-                         "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
-                         "kernel_min_ms": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes},
-        }
-        if sweep is not None:
-            line["sweep"] = sweep
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(K, a.cpu_sample_rows)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        line["sweep"] = c2_sweep(a, torch, common_amd, ctx, st, view, z)
+    del out
+    if not a.no_extra:
+        for name, fn in (("c3", extra_c3), ("c4", extra_c4), ("c5_shard", extra_c5)):
+            torch.cuda.empty_cache()
+            try:
+                line[name] = fn(a, torch, common_amd, ctx)
+            except Exception as e:                            # an extra object never takes the headline down
+                line[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(K, a.cpu_sample_rows)
+    return line
 
 
-def run_sweep(a, ctx, st, view, z, world, rank, dist, sync_all):
-    """rows/sec of one synchronous Gibbs sweep incl. the suff-stat all-reduce."""
-    import torch
-    import common_amd
+def c2_sweep(a, torch, common_amd, ctx, st, view, z):
+    """C2 as one synchronous Gibbs sweep on one rank (no exchange to do): rows/sec of msc_sweep_step."""
     N = view.nrows
     zs = z.clone()
     st.set_alpha(1.0)
-    drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=rank * N)
-    drv.rebuild_tables()          # suff-stats of the global assignment (a no-op exchange on one rank)
+    drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=0)
+    drv.rebuild_tables()
+    idx = [0]
 
-    def one(sweep_idx):
-        drv.sweep(seed=73, sweep_index=sweep_idx)
-
+    def one():
+        drv.sweep(seed=73, sweep_index=idx[0])
+        idx[0] += 1
     steps = max(1, min(a.steps, 20))
-    for i in range(2):
-        one(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(2 + i)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=ctx.torch_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return {"metric": "Gibbs-sweep rows/sec", "value": N * world / (dt / steps), "unit": "rows/s",
-            "ms_per_sweep": dt / steps * 1e3, "steps": steps,
-            "includes": "leave-one-out score + CRP prior + sample, accumulate, all-reduce(i64,f64), commit"}
+    wall_ms, avg, mn = timed(torch, one, steps, 2)
+    kern_ms, _ = sweep_kernel_ms(torch, st, view, zs)
+    return {"metric": "Gibbs-sweep rows/sec", "value": N / (wall_ms * 1e-3), "unit": "rows/s",
+            "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1", "kernel_avg_ms": kern_ms,
+            "includes": "leave-one-out score + CRP prior + sample (fused, nothing materialised), accumulate, "
+                        "commit + prepare; one rank: no exchange (msc_sweep_step)"}
+
+
+def extra_c3(a, torch, common_amd, ctx):
+    """BASELINE configs[2]: mixed bb+gp+dd32+nich x16, N=1M, K=256, D=64; scoring pass + sweep."""
+    from tools.bench_configs import make_columns
+    N, K = 1_000_000, 256
+    spec = [(common_amd.BB, 0), (common_amd.GP, 0), (common_amd.DD, 32), (common_amd.NICH, 0)] * 16
+    cols, z = make_columns(ctx, spec, N, K, 73)
+    view = common_amd.DataView.from_tensors(ctx, cols)
+    st = common_amd.State(ctx, spec, K)
+    st.accumulate(view, z)
+    out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
+    steps = max(3, min(a.steps, 10))
+    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 2)
+    rowbytes = sum(c.element_size() * (c.shape[1] if c.dim() > 1 else 1) for c in cols)
+    alg = float(N) * rowbytes + 4.0 * N * K
+    insts, src = pmc_entry("k_score_tile", "SQ_INSTS_VALU")
+    r = {"workload": "C3 mixed bb+gp+dd32+nich x16, N=1M, K=256, D=64, scoring pass", "ms": avg, "ms_min": mn,
+         "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": "k_score_tile",
+         "roofline": {"bound": "hbm", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                      "note": "not what binds it (SURVEY 8d): vector issue rate, see valu_issue"}}
+    if insts is not None:
+        r["roofline"]["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "peak": VALU_ISSUE_PEAK,
+                                       "achieved": insts / (avg * 1e-3), "frac": insts / (avg * 1e-3) / VALU_ISSUE_PEAK,
+                                       "unit": "wave-instructions/s"}
+    st.set_alpha(1.0)
+    zs = z.clone()
+    idx = [0]
+
+    def one():
+        st.sweep_step(view, zs, seed=73, sweep=idx[0])
+        idx[0] += 1
+    w, savg, smn = timed(torch, one, max(3, steps // 2), 1)
+    r["sweep_ms"] = savg
+    r["sweep_rows_per_s"] = N / (savg * 1e-3)
+    return r
+
+
+def extra_c4(a, torch, common_amd, ctx):
+    """BASELINE configs[3]: NIW dim 32, N=256k, K=128; scoring pass on the f64 matrix pipe (the 1e-6 path)."""
+    from tools.bench_configs import make_columns
+    N, K, d = 262_144, 128, 32
+    spec = [(common_amd.NIW, d)]
+    cols, z = make_columns(ctx, spec, N, K, 73)
+    view = common_amd.DataView.from_tensors(ctx, cols)
+    st = common_amd.State(ctx, spec, K)
+    st.accumulate(view, z)
+    out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
+    steps = max(3, min(a.steps, 10))
+    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 2)
+    flops = 2.0 * d * d * N * K                 # SURVEY 8d's count (the full d x d contraction per pair)
+    tf = flops / (avg * 1e-3) / 1e12
+    return {"workload": "C4 NIW dim=32, N=256k, K=128, scoring pass (f64 MFMA)", "ms": avg, "ms_min": mn,
+            "evals_per_s": float(N) * K / (avg * 1e-3), "kernel": "k_score_niw64",
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F64_PEAK_TF, "algorithmic_flops_per_launch": flops,
+                         "note": "flops counted as SURVEY 8d does (2 d^2 per pair); the kernel skips the zero "
+                                 "upper-right block of the triangular factor, so the matrix pipe executes fewer"}}
+
+
+def extra_c5(a, torch, common_amd, ctx):
+    """BASELINE configs[4] at one rank: the 12.5 M-row shard, K=1024, the sweep step of the N > 1 bench."""
+    nrows = a.c5_rows
+    x, z, view, st, drv = c5_setup(a, torch, common_amd, ctx, 1, 0, nrows)
+    idx = [0]
+
+    def one():
+        drv.sweep(seed=73, sweep_index=idx[0])
+        idx[0] += 1
+    steps = max(3, min(a.steps, 10))
+    wall_ms, avg, mn = timed(torch, one, steps, 2)
+    kern_ms, _ = sweep_kernel_ms(torch, st, view, z)
+    return {"workload": "C5 shard: NICH %d rows x K=%d, one rank's sweep step (no exchange at one rank)" % (nrows, C5_GROUPS),
+            "metric": "Gibbs-sweep rows/sec", "value": nrows / (wall_ms * 1e-3), "unit": "rows/s", "ms_per_sweep": wall_ms,
+            "evals_per_s": float(nrows) * C5_GROUPS / (wall_ms * 1e-3),
+            "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1")}
 
 
 if __name__ == "__main__":

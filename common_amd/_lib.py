@@ -73,6 +73,8 @@ _SIGS = {
     "msc_state_get_group_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "msc_score_value": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                   C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "msc_score_tune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "msc_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                  C.c_void_p, C.c_uint32]),
     "msc_score_data": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -450,7 +450,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->red_i64, n_i64))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->red_f64, n_f64))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->cnt_u32, kpad))) return bail(rc);
-  if ((rc = dev_alloc(st->owned, &st->logpc, 2 * kpad + 4))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->logpc, crp_floats(st->kpad)))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
@@ -595,8 +595,8 @@ extern "C" int msc_state_set_ss(msc_state *st, uint32_t feature, uint32_t first_
   MSC_REQUIRE(st && host_records, "null argument");
   MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
   msc_feature_host &h = st->feats[feature];
-  MSC_REQUIRE(first_group + ngroups <= st->K && ngroups > 0, "groups [%u,%u) outside [0,%u)",
-              first_group, first_group + ngroups, st->K);
+  MSC_REQUIRE(ngroups > 0 && first_group <= st->K && ngroups <= st->K - first_group,      // (no 32-bit wrap of the sum)
+              "groups [%u,%llu) outside [0,%u)", first_group, (unsigned long long)first_group + ngroups, st->K);
   const size_t rec = msc_ss_bytes(h.family, h.dim);
   MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
   MSC_HIP(hipSetDevice(st->ctx->device));
@@ -647,8 +647,8 @@ extern "C" int msc_state_get_ss(msc_state *st, uint32_t feature, uint32_t first_
   MSC_REQUIRE(st && host_records, "null argument");
   MSC_REQUIRE(feature < st->nfeat, "feature %u out of range", feature);
   msc_feature_host &h = st->feats[feature];
-  MSC_REQUIRE(first_group + ngroups <= st->K && ngroups > 0, "groups [%u,%u) outside [0,%u)",
-              first_group, first_group + ngroups, st->K);
+  MSC_REQUIRE(ngroups > 0 && first_group <= st->K && ngroups <= st->K - first_group,      // (no 32-bit wrap of the sum)
+              "groups [%u,%llu) outside [0,%u)", first_group, (unsigned long long)first_group + ngroups, st->K);
   const size_t rec = msc_ss_bytes(h.family, h.dim);
   MSC_REQUIRE(nbytes == rec * ngroups, "expected %zu bytes of records, got %zu", rec * ngroups, nbytes);
   MSC_HIP(hipSetDevice(st->ctx->device));
@@ -944,6 +944,21 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
   return L;
 }
 
+// k_score_nich1's launch shape for a pass of `nrows` x K into `out`: what msc_score_tune remembered for this very
+// buffer, else for this size, else the default.  (profiles/r02_placement_study.txt: the shape moves the rate by <= 4 %
+// either way; what decides between 5.6 and 7.0 TB/s is where the driver placed the buffer.)
+static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, uint32_t K) {
+  static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_SHAPE"); return e ? std::atoi(e) : -1; }();
+  if (fixed >= 0 && fixed < kNich1NumShapes) return fixed;
+  int by_size = -1;
+  for (const msc_context::ShapeEntry &e : ctx->nich1_shapes) {
+    if (e.nrows != nrows || e.K != K) continue;
+    if (e.out == out) return e.shape;
+    if (by_size < 0) by_size = e.shape;
+  }
+  return by_size < 0 ? 0 : by_size;
+}
+
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
                      bool niw_f32, float *out_dev, uint64_t ld_out) {
   hipStream_t s = st->ctx->stream;
@@ -972,50 +987,11 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
       return launch_score(s, st->ctx->num_cus, path, shape, descs, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
                           nrows, z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out);
     };
-    // The single-nich pass is bound by the HBM write stream, and which launch shape (rows per visit, visits per
-    // wave = write fronts) suits it differs by up to 20 % from box to box and with where the score buffer landed
-    // (profiles/r01_nich1_variants.txt: the same shape runs at 7.0 TB/s into one buffer and at 5.6 into the next).
-    // Settle it the first time a context sees a large pass into a given output buffer:
-    // every shape of kNich1Shapes, six launches each on the caller's own buffers (~10 ms once; every run writes
-    // the same values).  MSC_NICH1_SHAPE fixes it.
-    int shape = -1;
-    const bool tunable = path == MSC_PATH_NICH1 && nrows * (uint64_t)st->K >= (64ull << 20);
-    auto &memo = st->ctx->nich1_shapes;
-    if (tunable)
-      for (size_t i = 0; i < memo.size(); i++)
-        if (memo[i].out == out_dev && memo[i].nrows == nrows && memo[i].K == st->K) {
-          shape = memo[i].shape;
-          if (i) std::swap(memo[i], memo[0]);
-          break;
-        }
-    if (tunable && shape < 0) {
-      static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_SHAPE"); return e ? std::atoi(e) : -1; }();
-      if (fixed >= 0 && fixed < kNich1NumShapes) shape = fixed;
-      else {
-        hipEvent_t e0, e1;
-        MSC_HIP(hipEventCreate(&e0));
-        MSC_HIP(hipEventCreate(&e1));
-        float best = 0.f;
-        for (int cand = 0; cand < kNich1NumShapes; cand++) {
-          if (launch(cand)) return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-          MSC_HIP(hipEventRecord(e0, s));
-          for (int r = 0; r < 6; r++) (void)launch(cand);
-          MSC_HIP(hipEventRecord(e1, s));
-          MSC_HIP(hipEventSynchronize(e1));
-          float ms = 0.f;
-          MSC_HIP(hipEventElapsedTime(&ms, e0, e1));
-          if (shape < 0 || ms < best) {
-            best = ms;
-            shape = cand;
-          }
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-      }
-      memo.insert(memo.begin(), msc_context::ShapeEntry{out_dev, nrows, st->K, shape});
-      if (memo.size() > 16) memo.pop_back();
-    }
-    if (launch(shape < 0 ? 0 : shape))
+    // The single-nich pass is bound by the HBM write stream; its launch shape (rows per visit, visits per wave =
+    // write fronts) is the default (4 rows, 2 visits) unless msc_score_tune settled another one for passes like this
+    // (same buffer first, else same size), or MSC_NICH1_SHAPE fixes it.  Nothing here waits for the device.
+    const int shape = path == MSC_PATH_NICH1 ? nich1_shape_for(st->ctx, out_dev, nrows, st->K) : 0;
+    if (launch(shape))
       return fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     written = true;
     for (uint32_t f = 0; f < st->nfeat; f++)
@@ -1053,6 +1029,64 @@ extern "C" int msc_score_value(msc_state *st, const msc_dataview *view, const ui
   const bool crp = (flags & MSC_SCORE_CRP_PRIOR) != 0;
   if (crp) MSC_TRY(ensure_crp(st));
   return run_score(st, row0, nrows, z_dev, crp, (flags & MSC_SCORE_NIW_F32) != 0, out_dev, ld_out);
+}
+
+// Settle the launch shape of the single-nich scoring pass for passes of this size: every shape of kNich1Shapes, one
+// warm-up and six timed launches each into the caller's buffer (every run writes the same values), the fastest is
+// remembered per context for (this buffer, nrows, K) and, as the fallback, for (nrows, K).  SYNCHRONOUS (~10 ms): it
+// waits on events, so never call it on a capturing stream.  States that do not take the single-nich kernel return
+// MSC_OK and remember nothing.
+extern "C" int msc_score_tune(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                              uint64_t nrows, float *out_dev, uint64_t ld_out, int *shape_out, float *ms_out) {
+  MSC_REQUIRE(st && view && out_dev, "null argument");
+  MSC_REQUIRE(ld_out >= st->K, "ld_out %llu < ngroups %u", (unsigned long long)ld_out, st->K);
+  if (shape_out) *shape_out = -1;
+  if (ms_out) *ms_out = 0.f;
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(bind_view(st, view, cols, row0, nrows));
+  uint32_t narrow_rows = 0;
+  const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH && narrow_lanes(st, &narrow_rows) == 0;
+  if (!nich1 || nrows == 0) return MSC_OK;
+  MSC_TRY(ensure_derived(st));
+  hipStream_t s = st->ctx->stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(MSC_EINVAL, "msc_score_tune waits for the device: not on a capturing stream");
+  auto launch = [&](int shape) {
+    return launch_score(s, st->ctx->num_cus, MSC_PATH_NICH1, shape, st->desc_dev, 1, (int)st->tile_split, st->K, st->kpad, row0,
+                        nrows, nullptr, nullptr, nullptr, out_dev, ld_out);
+  };
+  hipEvent_t e0, e1;
+  MSC_HIP(hipEventCreate(&e0));
+  MSC_HIP(hipEventCreate(&e1));
+  float best = 0.f;
+  int shape = -1, rc = MSC_OK;
+  for (int cand = 0; cand < kNich1NumShapes && rc == MSC_OK; cand++) {
+    if (launch(cand)) { rc = fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    hipError_t e = hipEventRecord(e0, s);
+    for (int r = 0; r < 6 && e == hipSuccess; r++) (void)launch(cand);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) { rc = fail(MSC_EHIP, "timing failed: %s", hipGetErrorString(e)); break; }
+    if (shape < 0 || ms < best) {
+      best = ms;
+      shape = cand;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  MSC_TRY(rc);
+  auto &memo = st->ctx->nich1_shapes;
+  for (size_t i = 0; i < memo.size();)                      // one entry per (buffer, size); the newest size entry leads
+    if (memo[i].out == out_dev && memo[i].nrows == nrows && memo[i].K == st->K) memo.erase(memo.begin() + i);
+    else i++;
+  memo.insert(memo.begin(), msc_context::ShapeEntry{out_dev, nrows, st->K, shape});
+  if (memo.size() > 16) memo.pop_back();
+  if (shape_out) *shape_out = shape;
+  if (ms_out) *ms_out = best / 6.f;
+  return MSC_OK;
 }
 
 static int commit(msc_state *st) {

@@ -812,12 +812,10 @@ __global__ __launch_bounds__(1024) void k_niw_accumulate_small(const FeatDesc *_
 template <int D>
 static void launch_niw_accumulate_small(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t K,
                                         uint64_t row0, uint64_t nrows, const int32_t *z, int sign, size_t lds) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (first_use_on_device(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_niw_accumulate_small<D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   uint64_t blocks = (nrows + 4095) / 4096;
   if (blocks < (uint64_t)num_cus) blocks = (nrows + 1023) / 1024;
   if (blocks > (uint64_t)num_cus * 2) blocks = (uint64_t)num_cus * 2;

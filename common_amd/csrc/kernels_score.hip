@@ -121,26 +121,35 @@ __global__ __launch_bounds__(256) void k_dm_prepare(const FeatDesc *__restrict__
   }
 }
 
-// crp layout: [0,kpad) log(cnt) or -inf when empty; [kpad,2kpad) log(cnt-1) or -inf;
-// [2kpad] = log(alpha / n_empty), [2kpad+1] = log(alpha / (n_empty+1)).  One block.
+// crp layout (float): [0,kpad) log(cnt) or -inf when empty; [kpad,2kpad) log(cnt-1) or -inf;
+// [2kpad] = log(alpha / n_empty), [2kpad+1] = log(alpha / (n_empty+1)).  Every term is a (hi, lo) pair: the float above
+// is hi and lo = the rest of the double value sits at [2kpad+2], [2kpad+3] for the two "empty" terms, at
+// [2kpad+4, 3kpad+4) for log(cnt) and at [3kpad+4, 4kpad+4) for log(cnt-1) (msc_internal.hpp crp_lo_*).  A group of
+// 40k rows has log(cnt) = 10.6 while likelihood + prior is O(1): the float alone is off by up to 4.8e-7 of that
+// result, the pair by 1e-14.  One block.
+MSC_DEV void crp_split(double v, float &hi, float &lo) {
+  hi = (float)v;
+  lo = __builtin_isinf(hi) ? 0.f : (float)(v - (double)hi);
+}
 MSC_DEV void crp_prepare_block(const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
                                float *__restrict__ crp) {
   __shared__ uint32_t s_empty;
   if (threadIdx.x == 0) s_empty = 0;
   __syncthreads();
   uint32_t mine = 0;
+  float *lo0 = crp + crp_lo_cnt(kpad), *lo1 = crp + crp_lo_cntm1(kpad);
   for (uint32_t k = threadIdx.x; k < kpad; k += 256) {
     const uint32_t c = k < K ? cnt[k] : 0;
-    crp[k] = c ? (float)log((double)c) : -INFINITY;
-    crp[kpad + k] = c > 1 ? (float)log((double)c - 1.0) : -INFINITY;
+    crp_split(c ? log((double)c) : -(double)INFINITY, crp[k], lo0[k]);
+    crp_split(c > 1 ? log((double)c - 1.0) : -(double)INFINITY, crp[kpad + k], lo1[k]);
     if (k < K && c == 0) mine++;
   }
   atomicAdd(&s_empty, mine);
   __syncthreads();
   if (threadIdx.x == 0) {
     const double ne = s_empty;
-    crp[2 * (size_t)kpad] = ne > 0 ? (float)log((double)alpha / ne) : -INFINITY;
-    crp[2 * (size_t)kpad + 1] = (float)log((double)alpha / (ne + 1.0));
+    crp_split(ne > 0 ? log((double)alpha / ne) : -(double)INFINITY, crp[2 * (size_t)kpad], crp[2 * (size_t)kpad + 2]);
+    crp_split(log((double)alpha / (ne + 1.0)), crp[2 * (size_t)kpad + 1], crp[2 * (size_t)kpad + 3]);
   }
 }
 __global__ __launch_bounds__(256) void k_crp_prepare(const uint32_t *__restrict__ cnt, uint32_t K,
@@ -198,7 +207,8 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   double s = 0.0;
   if (crp) {
     const float lm1 = crp[kpad + g];
-    s = __builtin_isinf(lm1) ? crp[2 * (size_t)kpad + 1] : lm1;
+    s = __builtin_isinf(lm1) ? (double)crp[2 * (size_t)kpad + 1] + (double)crp[2 * (size_t)kpad + 3]
+                             : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + g];
   }
   for (int f = 0; f < nfeat; f++) {
     const FeatDesc fd = feats[f];
@@ -277,12 +287,15 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   const float4 mh = ld4(tab + (size_t)NICH_MU_HI * kpad), ml = ld4(tab + (size_t)NICH_MU_LO * kpad),
                c0 = ld4(tab + (size_t)NICH_C0 * kpad), c1l = ld4(tab + (size_t)NICH_C1LN2 * kpad),
                c1 = ld4(tab + (size_t)NICH_C1 * kpad), c2 = ld4(tab + (size_t)NICH_C2 * kpad);
-  float4 logcnt = make_float4(0, 0, 0, 0);
-  float le0 = 0, le1 = 0;
+  float4 logcnt = make_float4(0, 0, 0, 0), logcnt_lo = make_float4(0, 0, 0, 0);
+  float le0 = 0, le1 = 0, le0_lo = 0, le1_lo = 0;
   if (CRP) {
     logcnt = ld4(crp + kb);
+    logcnt_lo = ld4(crp + crp_lo_cnt(kpad) + kb);
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
+    le0_lo = crp[2 * (size_t)kpad + 2];
+    le1_lo = crp[2 * (size_t)kpad + 3];
   }
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const bool tile_full = (kt + 1) * kGroupTile <= K;
@@ -296,11 +309,14 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   const unsigned long long mbits_all =
       __builtin_amdgcn_ballot_w64(fd.mask != nullptr && mine && fd.mask[row0 + myrow] != 0);
   int gz = -1;
-  float sloo = 0, erow = le0;
+  float sloo = 0, erow = le0, erow_lo = le0_lo;
   if (LOO && mine) {
     gz = z[myrow];
     sloo = own[myrow];
-    if (CRP && gz >= 0) erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+    if (CRP && gz >= 0 && __builtin_isinf(crp[kpad + gz])) {
+      erow = le1;
+      erow_lo = le1_lo;
+    }
   }
   for (uint32_t k = 0; k < nvis; k++) {
     const uint64_t rb = (slot + (uint64_t)k * nslots) * Q;
@@ -317,7 +333,10 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
         s.y = nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
         s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
         s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
+        if (CRP) {                                             // lo first: the last add then rounds the result once
+          add4(s, crp_prior4_lo(logcnt, logcnt_lo, LOO ? lane_bcast(erow_lo, l0 + r) : le0_lo));
+          add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
+        }
         if (LOO) {
           const int g = lane_bcast(gz, l0 + r);
           if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, l0 + r));
@@ -337,7 +356,10 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
           s.z = nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
           s.w = nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
         }
-        if (CRP) add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
+        if (CRP) {                                             // lo first: the last add then rounds the result once
+          add4(s, crp_prior4_lo(logcnt, logcnt_lo, LOO ? lane_bcast(erow_lo, l0 + r) : le0_lo));
+          add4(s, crp_prior4(logcnt, LOO ? lane_bcast(erow, l0 + r) : le0));
+        }
         if (LOO) {
           const int g = lane_bcast(gz, l0 + r);
           if (g >= 0) replace_own(s, kb, g, lane_bcast(sloo, l0 + r));
@@ -377,37 +399,49 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * R;       // relative to row0
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
     float4 acc[R];
-    {
-      float erow = le0;
-      if (LOO && CRP && lane < nr) {
-        const int g0 = z[rb + lane];
-        if (g0 >= 0) erow = __builtin_isinf(crp[kpad + g0]) ? le1 : le0;
-      }
+    // The prior is a (hi, lo) pair per group: the accumulators start from lo (~1e-7) and hi (log count, ~10 for a
+    // large group) is added after the last feature -- the likelihood terms largely cancel it, and a sum that starts at
+    // 10 rounds every one of its steps relative to 10 instead of to the result (1.4-1.6e-6 of it measured).
+    int single = 0;                                       // lane r: removing row r empties its group (kept in a VGPR:
+    if (LOO && CRP && lane < nr) {                        //  the tile scorer leaves no SGPR pair free across its call)
+      const int g0 = z[rb + lane];
+      single = g0 >= 0 && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
+    }
+    if (CRP) {
+      const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
+      const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (CRP) acc[r] = crp_prior4(logcnt, LOO ? lane_bcast(erow, r) : le0);
-        else acc[r] = make_float4(0, 0, 0, 0);
-      }
+      for (int r = 0; r < R; r++) acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
     }
     score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
-    if (LOO) {
-      // The own group's entry becomes the row's pre-computed leave-one-out value (k_loo_own): row by row through a
-      // KiB of LDS that belongs to the wave (beyond the table slot, so no barrier) -- park the row, one lane
-      // overwrites the entry, read the row back.  Ways that cost more: merging the value into the owning lane's float4
-      // in registers (replace_own per row; the tiling has no SGPRs / VGPRs left: 60-100 bytes of scratch per lane,
-      // C3 +13 %); a 4-byte store after the row stores (needs a fence and cached stores, +45 %); a pass of its own
-      // over the finished matrix (a million random read-modify-writes in HBM, +12 %); all rows parked in the table
-      // slot (one more barrier per chunk, +8 %).
-      float4 *mine = lds + (size_t)kGrpRows * 64 + (size_t)wave * 64;
-      int gz = -1;
-      float sloo = 0.f;
-      if (lane < nr) {
-        gz = z[rb + lane];
-        sloo = own[rb + lane];
-      }
-      if (gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+    // epilogue, row by row (one pass, so nothing of one row outlives its store): + hi of the prior; then the own
+    // group's entry becomes the row's pre-computed leave-one-out value (k_loo_own) through a KiB of LDS that belongs
+    // to the wave (beyond the table slot, so no barrier) -- park the row, one lane overwrites the entry, read the row
+    // back.  Ways that cost more: merging the value into the owning lane's float4 in registers (replace_own per row;
+    // the tiling has no SGPRs / VGPRs left: 60-100 bytes of scratch per lane, C3 +13 %); a 4-byte store after the
+    // row stores (needs a fence and cached stores, +45 %); a pass of its own over the finished matrix (a million
+    // random read-modify-writes in HBM, +12 %); all rows parked in the table slot (one more barrier per chunk, +8 %).
+    float4 *mine = lds + (size_t)kGrpRows * 64 + (size_t)wave * 64;
+    int gz = -1;
+    float sloo = 0.f;
+    float4 hi = make_float4(0, 0, 0, 0);
+    if (CRP) {                                            // fetched again (an L2 hit per chunk) rather than held across
+      const float *again = crp;                           // the tile scorer: 4 VGPRs and 4 SGPR pairs of isinf masks
+      asm volatile("" : "+s"(again));
+      hi = ld4(again + kb);
+    }
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+    }
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
 #pragma unroll
-      for (int r = 0; r < R; r++) {
+    for (int r = 0; r < R; r++) {
+      if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
+      if (LOO) {
         const int g = lane_bcast(gz, r);
         if (g >= 0) {                                     // (wave-uniform)
           mine[lane] = acc[r];
@@ -416,9 +450,6 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
           acc[r] = mine[lane];
         }
       }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
       if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
     }
   }

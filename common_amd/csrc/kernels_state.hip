@@ -494,12 +494,10 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
                        feats_dev, K, kpad, row0, nrows, z, sign, cnt_acc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (first_use_on_device(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   uint64_t blocks = (nrows + 4095) / 4096;          // >= 4 rows per thread
   if (blocks < (uint64_t)num_cus) {                 // too few rows to fill the chip that way: down to 1 row per thread
     const uint64_t per = std::max<uint64_t>(1024, (nrows + num_cus - 1) / num_cus);

@@ -505,12 +505,17 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
   constexpr int kRowsPerStep = 64 / L;
   const uint32_t kb = 4 * q;
   const bool loo = z != nullptr, pri = crp != nullptr;
-  float4 logcnt = make_float4(0, 0, 0, 0);
-  float le0 = 0.f, le1 = 0.f;
+  // the prior as (hi, lo) pairs (kernels_score.hip crp_prepare_block): an accumulator starts from lo and takes hi
+  // after the last feature, so that no step of the sum rounds relative to log(count)
+  float4 logcnt = make_float4(0, 0, 0, 0), logcnt_lo = make_float4(0, 0, 0, 0);
+  float le0 = 0.f, le1 = 0.f, le0_lo = 0.f, le1_lo = 0.f;
   if (pri) {
     logcnt = ld4(crp + kb);
+    logcnt_lo = ld4(crp + crp_lo_cnt(kpad) + kb);
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
+    le0_lo = crp[2 * (size_t)kpad + 2];
+    le1_lo = crp[2 * (size_t)kpad + 3];
   }
   const uint64_t seed = SWEEP ? rng[0] : 0, sweep = SWEEP ? rng[1] : 0;
   const bool vec_ok = !SWEEP && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -524,18 +529,19 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
     uint64_t nn[S];
     bool has[S];
     int gzs[S];
+    bool single[S];                                        // removing the row empties its group
     float4 accs[S];
 #pragma unroll
     for (int i = 0; i < S; i++) {
       nn[i] = (batch * S + i) * kRowsPerStep + sub;        // relative to row0
       has[i] = nn[i] < nrows;
       gzs[i] = -1;
-      float erow = le0;
+      single[i] = false;
       if (loo && has[i]) {
         gzs[i] = z[nn[i]];
-        if (pri && gzs[i] >= 0) erow = __builtin_isinf(crp[kpad + gzs[i]]) ? le1 : le0;
+        single[i] = pri && gzs[i] >= 0 && __builtin_isinf(crp[kpad + gzs[i]]);
       }
-      accs[i] = pri ? crp_prior4(logcnt, erow) : make_float4(0, 0, 0, 0);
+      accs[i] = pri ? crp_prior4_lo(logcnt, logcnt_lo, single[i] ? le1_lo : le0_lo) : make_float4(0, 0, 0, 0);
     }
     uint32_t off = 0;
     for (int f = 0; f < nfeat; f++) {
@@ -593,6 +599,7 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
     const bool has_row = has[si];
     const int gz = gzs[si];
     float4 acc = accs[si];
+    if (pri) add4(acc, crp_prior4(logcnt, single[si] ? le1 : le0));
     if (loo && gz >= 0 && (uint32_t)gz / 4 == (uint32_t)q) {     // this lane holds the row's own group
       const float v = own[n];
       const int c = gz & 3;

@@ -4,6 +4,17 @@
 
 namespace msc {
 
+// A function attribute (dynamic LDS beyond 64 KiB) is per device: `seen` is the launcher's own bit set of devices that
+// have it.  True the first time the current device asks.
+inline bool first_use_on_device(unsigned long long &seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
+
 struct UnpackFeat {
   void *dst;
   uint8_t *dst_mask;     // may be null

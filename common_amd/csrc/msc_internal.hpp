@@ -46,6 +46,11 @@ int fail(int code, const char *fmt, ...);
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
+// the CRP table (msc_state::logpc; kernels_score.hip crp_prepare_block): float offsets of the low halves
+__host__ __device__ inline size_t crp_lo_cnt(uint32_t kpad) { return 2 * (size_t)kpad + 4; }     // lo of log(cnt)
+__host__ __device__ inline size_t crp_lo_cntm1(uint32_t kpad) { return 3 * (size_t)kpad + 4; }   // lo of log(cnt - 1)
+inline size_t crp_floats(uint32_t kpad) { return 4 * (size_t)kpad + 4; }
+
 // ---- device-visible feature descriptor -------------------------------------
 // One per state feature; lives in a small device array rebuilt when the (view,
 // cols) binding changes.  All tables are struct-of-arrays with row stride kpad

@@ -47,6 +47,15 @@ MSC_DEV float4 crp_prior4(float4 logcnt, float e_row) {
   p.w = __builtin_isinf(logcnt.w) ? e_row : logcnt.w;
   return p;
 }
+// the low halves of the same terms (kernels_score.hip crp_prepare_block): where hi is -inf the group is empty
+MSC_DEV float4 crp_prior4_lo(float4 logcnt_hi, float4 logcnt_lo, float e_row_lo) {
+  float4 p;
+  p.x = __builtin_isinf(logcnt_hi.x) ? e_row_lo : logcnt_lo.x;
+  p.y = __builtin_isinf(logcnt_hi.y) ? e_row_lo : logcnt_lo.y;
+  p.z = __builtin_isinf(logcnt_hi.z) ? e_row_lo : logcnt_lo.z;
+  p.w = __builtin_isinf(logcnt_hi.w) ? e_row_lo : logcnt_lo.w;
+  return p;
+}
 // (g is wave-uniform: one vector compare finds the lane, the component is picked by scalar conditions -- keeps
 // kb + 1 .. kb + 3 out of the registers of kernels that have none to spare)
 MSC_DEV void replace_own(float4 &s, uint32_t kb, int g, float v) {

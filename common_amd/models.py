@@ -10,6 +10,8 @@ import itertools as it
 import numpy as np
 
 from . import _lib as L
+from . import wire
+from .scalar_functions import log_exponential, log_noninformative_beta_prior, log_normal
 
 
 class c_model(object):
@@ -28,13 +30,27 @@ class c_model(object):
 
 
 class py_model(object):
-    """dtype carrier (microscopes/models.pyx:53-66); the protobuf converters are out of scope."""
+    """dtype carrier and dict <-> protobuf-bytes converters (microscopes/models.pyx:53-94).  `dtype` is the column
+    dtype the device kernels read (the reference takes it from the absent library's `Value`)."""
 
-    def __init__(self, dtype):
+    def __init__(self, name, dtype):
+        self._name = name
         self._dtype = np.dtype(dtype)
 
     def get_np_dtype(self):
         return self._dtype
+
+    def shared_dict_to_bytes(self, raw):
+        return wire.dumps(self._name + ".shared", raw)
+
+    def shared_bytes_to_dict(self, raw):
+        return wire.loads(self._name + ".shared", raw)
+
+    def group_dict_to_bytes(self, raw):
+        return wire.dumps(self._name + ".group", raw)
+
+    def group_bytes_to_dict(self, raw):
+        return wire.loads(self._name + ".group", raw)
 
 
 class model_descriptor(object):
@@ -106,29 +122,31 @@ def _nich_grid():
             for m, s in it.product(np.linspace(-2., 2., num=100), np.logspace(-1, 1, num=100))]
 
 
-bb = model_descriptor("bb", py_model(np.bool_), c_model(L.BB), {"alpha": 1., "beta": 1.}, {},
-                      _grid2("alpha", "beta"))
-bnb = model_descriptor("bnb", py_model(np.uint32), c_model(L.BNB), {"alpha": 1., "beta": 1., "r": 1}, {},
-                       bb._default_partial_hypergrid)
-gp = model_descriptor("gp", py_model(np.uint32), c_model(L.GP), {"alpha": 1., "inv_beta": 1.}, {},
-                      _grid2("alpha", "inv_beta"))
-nich = model_descriptor("nich", py_model(np.float32), c_model(L.NICH),
-                        {"mu": 0., "kappa": 1., "sigmasq": 1., "nu": 1.}, {}, _nich_grid())
-bbnc = model_descriptor("bbnc", py_model(np.bool_), c_model(L.BBNC), bb._default_hyperparams, {},
-                        bb._default_partial_hypergrid)
-noop = model_descriptor("noop", py_model(np.bool_), c_model(L.NOOP), {}, {}, [])
+# default hyper-priors as microscopes/models.pyx:185-229 lists them (callables; test/test_imports.py:32-70 pins their values)
+bb = model_descriptor("bb", py_model("bb", np.bool_), c_model(L.BB), {"alpha": 1., "beta": 1.},
+                      {("alpha", "beta"): log_noninformative_beta_prior}, _grid2("alpha", "beta"))
+bnb = model_descriptor("bnb", py_model("bnb", np.uint32), c_model(L.BNB), {"alpha": 1., "beta": 1., "r": 1},
+                       {("alpha", "beta"): log_noninformative_beta_prior}, bb._default_partial_hypergrid)
+gp = model_descriptor("gp", py_model("gp", np.uint32), c_model(L.GP), {"alpha": 1., "inv_beta": 1.},
+                      {"alpha": log_exponential(1.), "inv_beta": log_exponential(1.)}, _grid2("alpha", "inv_beta"))
+nich = model_descriptor("nich", py_model("nich", np.float32), c_model(L.NICH),
+                        {"mu": 0., "kappa": 1., "sigmasq": 1., "nu": 1.},
+                        {"mu": log_normal(0., 1.), "sigmasq": log_exponential(1.)}, _nich_grid())
+bbnc = model_descriptor("bbnc", py_model("bbnc", np.bool_), c_model(L.BBNC), bb._default_hyperparams,
+                        bb._default_hyperpriors, bb._default_partial_hypergrid)
+noop = model_descriptor("noop", py_model("noop", np.bool_), c_model(L.NOOP), {}, {}, [])
 
 
 def dd(size):
     if size <= 0:
         raise ValueError("size must be positive")
-    return model_descriptor("dd", py_model(np.int32), c_model(L.DD, size), {"alphas": [1.] * size}, {}, [])
+    return model_descriptor("dd", py_model("dd", np.int32), c_model(L.DD, size), {"alphas": [1.] * size}, {}, [])
 
 
 def niw(dim):
     if dim <= 0:
         raise ValueError("dim must be positive")
-    return model_descriptor("niw", py_model(np.dtype((np.float32, (dim,)))), c_model(L.NIW, dim),
+    return model_descriptor("niw", py_model("niw", np.dtype((np.float32, (dim,)))), c_model(L.NIW, dim),
                             {"mu": np.array([0.] * dim), "kappa": 1.0, "psi": np.eye(dim),
                              "nu": float(dim)}, {}, [])
 
@@ -136,5 +154,6 @@ def niw(dim):
 def dm(categories):
     if categories <= 0:
         raise ValueError("categories must be positive")
-    return model_descriptor("dm", py_model(np.dtype((np.int32, (categories,)))), c_model(L.DM, categories),
-                            {"alphas": [1.] * categories}, {}, [])
+    d = dd(categories)
+    return model_descriptor("dm", py_model("dm", np.dtype((np.int32, (categories,)))), c_model(L.DM, categories),
+                            d._default_hyperparams, d._default_hyperpriors, d._default_partial_hypergrid)

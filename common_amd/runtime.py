@@ -335,6 +335,17 @@ class State(object):
                                              C.c_void_p(out.data_ptr()), ld))
         return out
 
+    def score_tune(self, view, out, row0=0, nrows=None, cols=None):
+        """Settle the single-nich pass's launch shape for passes like this one (synchronous, ~10 ms; msc_score_tune).
+        -> (shape index or -1, ms per pass)."""
+        n = view.nrows - row0 if nrows is None else nrows
+        if out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[0] < n:
+            raise ValueError("out must be a row-major float32 [nrows, >=K] tensor")
+        shape, ms = C.c_int(-1), C.c_float(0)
+        L.check(self.ctx.lib.msc_score_tune(self._h, view._h, self._cols(cols), row0, n, C.c_void_p(out.data_ptr()),
+                                            out.stride(0) if out.dim() == 2 else self.K, C.byref(shape), C.byref(ms)))
+        return shape.value, ms.value
+
     def accumulate(self, view, z, row0=0, nrows=None, reset=True, subtract=False, commit=True, cols=None):
         n = view.nrows - row0 if nrows is None else nrows
         if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:

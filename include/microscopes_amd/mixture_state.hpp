@@ -52,6 +52,8 @@ public:
       if (!hypers_[f]->device_spec(specs[f], hp)) throw std::runtime_error("component model has no device family");
       col_types.push_back(int32_t(models[f]->get_runtime_type().t()));     // convert at upload (runtime_type.hpp:153-161)
       hp_pushed_.push_back(std::vector<float>());
+      nonconj_.push_back(specs[f].family == MSC_BBNC);   // the group carries a parameter of its own (bbnc.cpp:22-73)
+      any_nonconj_ = any_nonconj_ || nonconj_.back();
     }
     view_ = data.to_device(ctx_, &col_types);
     check(msc_state_create(ctx_, specs.data(), uint32_t(specs.size()), uint32_t(kmax_), &st_));
@@ -135,7 +137,7 @@ public:
     sync();
     if (gm_.assignments().at(eid) != -1) throw std::runtime_error("entity must be removed before it is scored");
     mixture_state *self = const_cast<mixture_state *>(this);
-    self->push_params();
+    self->push_params(true);
     check(msc_score_value(st_, view_, nullptr, eid, 1, nullptr, 0, row_dev_, kmax_));
     std::vector<float> row(kmax_);
     check(msc_device_download(ctx_, row.data(), row_dev_, 4 * kmax_));
@@ -210,11 +212,15 @@ public:
   // assignment vector the next time something looks at it (sync(): slots that gained their first member get a group
   // id, groups that lost every member stay as empty groups -- delete_group them if unwanted), so a run of sweeps costs
   // the host nothing.
-  void gibbs_sweep(uint64_t seed, uint64_t sweep, common::rng_t &) {
+  void gibbs_sweep(uint64_t seed, uint64_t sweep, common::rng_t &rng) {
+    if (any_nonconj_) {
+      sync();                                           // (which slots are free is host knowledge)
+      refresh_free_slots(rng);
+    }
     if (!stale_)                                        // (after a sweep every entity is assigned)
       for (size_t e = 0; e < n_; e++)
         if (gm_.assignments()[e] == -1) throw std::runtime_error("gibbs_sweep wants every entity assigned");
-    push_params();
+    push_params(true);
     check(msc_sweep_step(st_, view_, nullptr, 0, n_, 0, z_dev_, seed, sweep));
     stale_ = true;      // the host partition follows when somebody looks at it: sweep after sweep costs the host nothing
   }
@@ -245,24 +251,60 @@ private:
         if (pos == self->free_slots_.end()) throw std::runtime_error("device drew a slot the host does not know");
         std::swap(*pos, self->free_slots_.back());
         common::rng_t rng;
-        slot_gid[slot] = ssize_t(self->create_group_unsynced(rng));
+        slot_gid[slot] = ssize_t(self->create_group_unsynced(rng, true));
       }
       a[e] = slot_gid[slot];
     }
     self->gm_.reassign_all(a);
   }
-  size_t create_group_unsynced(common::rng_t &) {
+  // keep_record: the slot was on offer during a sweep and rows were scored against (and added to) what it holds --
+  // its record already is the group's
+  size_t create_group_unsynced(common::rng_t &rng, bool keep_record = false) {
     if (free_slots_.empty()) throw std::runtime_error("all max_groups device slots are in use");
     auto r = gm_.create_group();
     r.second = free_slots_.back();
     free_slots_.pop_back();
+    if (!keep_record) init_slot(r.second, rng);
     return r.first;
+  }
+  // What mixturemodel's create_group does per component (hypers::create_group, base.hpp:48): the model's own initial
+  // group goes into the slot.  For the conjugate families that record is all zero, which is what a slot holds once its
+  // group has emptied (and what it is created with), so nothing is written; a non-conjugate model draws its
+  // parameter here (bbnc: p ~ Beta(alpha, beta), bbnc.cpp:129-133) and the slot must not keep the previous occupant's.
+  void init_slot(size_t slot, common::rng_t &rng) {
+    for (size_t c = 0; c < hypers_.size(); c++) {
+      if (!nonconj_[c]) continue;
+      auto g = hypers_[c]->create_group(rng);
+      std::vector<uint8_t> rec;
+      g->device_record_get(*hypers_[c], rec);
+      if (!rec.empty()) check(msc_state_set_ss(st_, uint32_t(c), uint32_t(slot), 1, rec.data(), rec.size()));
+    }
+  }
+  // Every free slot is an empty group on offer in a sweep; for a non-conjugate component each gets a fresh draw of
+  // its parameter first (one read-modify-write of the component's table, only for such components).
+  void refresh_free_slots(common::rng_t &rng) {
+    if (free_slots_.empty()) return;
+    for (size_t c = 0; c < hypers_.size(); c++) {
+      if (!nonconj_[c]) continue;
+      msc_feature_spec spec;
+      std::vector<float> hp;
+      hypers_[c]->device_spec(spec, hp);
+      const size_t rb = msc_ss_bytes(spec.family, spec.dim);
+      std::vector<uint8_t> all(rb * kmax_), rec;
+      check(msc_state_get_ss(st_, uint32_t(c), 0, uint32_t(kmax_), all.data(), all.size()));
+      for (size_t slot : free_slots_) {
+        auto g = hypers_[c]->create_group(rng);
+        g->device_record_get(*hypers_[c], rec);
+        if (rec.size() == rb) std::copy(rec.begin(), rec.end(), all.begin() + rb * slot);
+      }
+      check(msc_state_set_ss(st_, uint32_t(c), 0, uint32_t(kmax_), all.data(), all.size()));
+    }
   }
   mutable bool stale_ = false;
 
   // hyper-parameters can change behind our back (mutators are raw pointers), so what the device holds is
   // compared with the hypers objects before every device call; a handful of floats per component
-  void push_params() {
+  void push_params(bool need_alpha = false) {
     for (size_t f = 0; f < hypers_.size(); f++) {
       msc_feature_spec spec;
       std::vector<float> hp;
@@ -273,8 +315,14 @@ private:
       }
     }
     const float alpha = gm_.get_hp_mutator("alpha").accessor().get<float>(0);
+    // group_manager.hpp:78 asserts alpha > 0 where it is used; the device would otherwise keep its default of 1 and
+    // draw under another concentration than the host's pseudocount() / score_assignment()
+    if (!(alpha > 0.f)) {
+      if (need_alpha) throw std::runtime_error("cluster hyper-parameter alpha must be set (> 0) before scoring or sweeping");
+      return;                                           // (membership edits and likelihoods do not read it)
+    }
     if (alpha != alpha_pushed_) {
-      if (alpha > 0.f) check(msc_state_set_alpha(st_, alpha));
+      check(msc_state_set_alpha(st_, alpha));
       alpha_pushed_ = alpha;
     }
   }
@@ -304,6 +352,8 @@ private:
   common::group_manager<size_t> gm_;                   // group data = the group's device slot
   std::vector<models::hypers_shared_ptr> hypers_;
   std::vector<std::vector<float>> hp_pushed_;
+  std::vector<bool> nonconj_;                          // per component: does a new group start from a draw?
+  bool any_nonconj_ = false;
   float alpha_pushed_ = -1.f;
   std::vector<size_t> free_slots_;
   std::vector<int32_t> z_host_;                        // the assignment vector as slots, mirror of z_dev_

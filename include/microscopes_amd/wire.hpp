@@ -85,7 +85,7 @@ inline std::vector<field> parse(const std::string &s) {
     else if (f.wire_type == 5) f.f32 = detail::read_f32(s, i);
     else if (f.wire_type == 2) {
       const uint64_t n = detail::read_varint(s, i);
-      if (i + n > s.size()) throw std::runtime_error("truncated bytes field");
+      if (n > s.size() - i) throw std::runtime_error("truncated bytes field");   // (i <= size; no wrap for a huge n)
       f.bytes = s.substr(i, n);
       i += n;
     } else throw std::runtime_error("unsupported wire type");

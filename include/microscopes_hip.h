@@ -196,6 +196,17 @@ int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *col
                     uint64_t nrows, const int32_t *z_dev, uint32_t flags, float *out_dev,
                     uint64_t ld_out);
 
+/*
+ * Optional and SYNCHRONOUS (about 10 ms): settle the launch shape of the single-NICH scoring pass (the HBM-write-bound
+ * kernel of config C2 / C5) for passes of nrows rows into out_dev -- eight shapes, seven launches each into the
+ * caller's own buffer (every run writes the same scores).  The winner is remembered in the context for (out_dev,
+ * nrows, ngroups) and, as the fallback, for (nrows, ngroups); msc_score_value itself never times anything and never
+ * waits.  *shape_out (nullable) = index of the chosen shape or -1 when the state does not take that kernel,
+ * *ms_out (nullable) = its time per pass.  Not on a capturing stream.
+ */
+int msc_score_tune(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                   uint64_t nrows, float *out_dev, uint64_t ld_out, int *shape_out, float *ms_out);
+
 #define MSC_ACC_RESET 0x1u    /* zero the tables first (then: suff-stats := f(z)) */
 #define MSC_ACC_SUBTRACT 0x2u /* remove_value instead of add_value */
 #define MSC_ACC_NO_COMMIT 0x4u /* leave the sums in the reduce buffer (all-reduce follows) */

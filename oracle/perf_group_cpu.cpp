@@ -12,8 +12,11 @@
 //                    models/noop.hpp:13-53)
 // The real reference cannot be built here, so this is kind "port".
 // Prints one JSON line.  Usage:
-//   perf_group_cpu <config> <N> <K> <threads> [seed]
+//   perf_group_cpu <config> <N> <K> <threads> [seed] [dump-file]
 //     config: c1 (bb x8) | c2 (nich x1) | c3 (bb,gp,dd32,nich x16) | nich | bb | gp | dd
+//     dump-file: the generated inputs are written there (int32 z[N], then every feature's column, raw) so that a
+//     test can score the same data through another entry of the oracle; "score_sum" in the JSON is the double sum
+//     of every float score of the single-thread score pass
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -108,6 +111,7 @@ int main(int argc, char **argv) {
   const size_t N = std::strtoull(argv[2], nullptr, 10), K = std::strtoull(argv[3], nullptr, 10);
   const unsigned threads = (unsigned)std::strtoul(argv[4], nullptr, 10);
   const uint64_t seed = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 73;   // perf_group.cpp:19
+  const char *dump = argc > 6 ? argv[6] : nullptr;
 
   std::vector<std::pair<int, unsigned>> spec;
   if (config == "c1") spec.assign(8, {ORC_BB, 0});
@@ -161,6 +165,14 @@ int main(int argc, char **argv) {
     for (size_t n = 0; n < N; n++) ft.groups[z[n]]->add_value(*ft.hp, value_ref{&ft.column[n * ft.vsize]});
   }
 
+  if (dump) {
+    FILE *fh = std::fopen(dump, "wb");
+    if (!fh) { std::fprintf(stderr, "cannot write %s\n", dump); return 2; }
+    std::fwrite(z.data(), sizeof(int32_t), N, fh);
+    for (size_t f = 0; f < D; f++) std::fwrite(feats[f].column.data(), 1, feats[f].column.size(), fh);
+    std::fclose(fh);
+  }
+
   const double evals = (double)N * (double)K * (double)D;
   float sink = 0.f;
 
@@ -185,17 +197,23 @@ int main(int argc, char **argv) {
   const double t_pg = now() - t0;
 
   // score pass: 1 thread, then `threads` threads over row blocks
-  auto score_rows = [&](size_t lo, size_t hi, float *out) {
+  double score_sum = 0.0;                 // of the single-thread pass (a test compares it with the batch oracle)
+  auto score_rows = [&](size_t lo, size_t hi, float *out, double *exact) {
     float s = 0.f;
+    double e = 0.0;
     for (size_t n = lo; n < hi; n++)
       for (size_t k = 0; k < K; k++)
-        for (size_t f = 0; f < D; f++)
-          s += feats[f].groups[k]->score_value(*feats[f].hp, value_ref{&feats[f].column[n * feats[f].vsize]});
+        for (size_t f = 0; f < D; f++) {
+          const float v = feats[f].groups[k]->score_value(*feats[f].hp, value_ref{&feats[f].column[n * feats[f].vsize]});
+          s += v;
+          e += (double)v;
+        }
     *out = s;
+    if (exact) *exact = e;
   };
   t0 = now();
   float s1 = 0.f;
-  score_rows(0, N, &s1);
+  score_rows(0, N, &s1, &score_sum);
   const double t_s1 = now() - t0;
   sink += s1;
 
@@ -205,7 +223,7 @@ int main(int argc, char **argv) {
     std::vector<float> part(threads, 0.f);
     t0 = now();
     for (unsigned t = 0; t < threads; t++)
-      pool.emplace_back(score_rows, N * t / threads, N * (t + 1) / threads, &part[t]);
+      pool.emplace_back(score_rows, N * t / threads, N * (t + 1) / threads, &part[t], (double *)nullptr);
     for (auto &th : pool) th.join();
     t_sn = now() - t0;
     for (float p : part) sink += p;
@@ -214,8 +232,9 @@ int main(int argc, char **argv) {
   std::printf("{\"config\": \"%s\", \"N\": %zu, \"K\": %zu, \"D\": %zu, \"evals\": %.0f, "
               "\"noop_s\": %.6f, \"perf_group_s\": %.6f, \"score_1core_s\": %.6f, "
               "\"score_ncore_s\": %.6f, \"threads\": %u, \"perf_group_evals_per_s\": %.6g, "
-              "\"score_evals_per_s_1core\": %.6g, \"score_evals_per_s_ncore\": %.6g, \"ignore\": %g}\n",
+              "\"score_evals_per_s_1core\": %.6g, \"score_evals_per_s_ncore\": %.6g, \"score_sum\": %.17g, "
+              "\"ignore\": %g}\n",
               config.c_str(), N, K, D, evals, t_noop, t_pg, t_s1, t_sn, threads, evals / t_pg,
-              evals / t_s1, threads > 1 ? evals / t_sn : 0.0, (double)sink);
+              evals / t_s1, threads > 1 ? evals / t_sn : 0.0, score_sum, (double)sink);
   return 0;
 }

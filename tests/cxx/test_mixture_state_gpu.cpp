@@ -294,6 +294,54 @@ int main() {
     vs.set_suffstats(0, gb, bag);
     CHECK(close_to(vs.score_likelihood(0, gb, rng), vs.score_likelihood(0, ga, rng), 1e-6));
   }
+  // a non-conjugate component (bbnc: every group carries its own p ~ Beta(alpha, beta), bbnc.cpp:129-133):
+  // create_group must put the model's initial group into the slot, a recycled slot must not keep its previous
+  // occupant's p, and the free slots a sweep offers as empty groups need a p of their own
+  {
+    const size_t M = 64;
+    std::vector<uint8_t> bits(M);
+    for (size_t i = 0; i < M; i++) bits[i] = uint8_t(std::bernoulli_distribution(i % 2 ? 0.85 : 0.15)(gen));
+    const std::vector<runtime_type> bt = {runtime_type(TYPE_B)};
+    recarray::row_major_dataview bdata(bits.data(), nullptr, M, bt);
+    std::vector<models::model_shared_ptr> bm = {std::make_shared<models::bbnc_model>()};
+    hip::mixture_state bs(bm, bdata, 6);
+    auto p_of = [&](size_t gid) {
+      auto g = bm[0]->create_hypers()->create_group(rng);
+      g->set_ss(bs.get_suffstats(0, gid));
+      return static_cast<models::bbnc_group *>(g.get())->repr_.p;
+    };
+    bool threw_alpha = false;                                 // alpha unset (0): scoring must refuse, not draw under alpha = 1
+    const size_t ga = bs.create_group(rng), gb = bs.create_group(rng);
+    try { (void)bs.score_value(0, rng); } catch (const std::runtime_error &) { threw_alpha = true; }
+    CHECK(threw_alpha);
+    bs.get_cluster_hp_mutator("alpha").set<float>(1.f);
+    const float pa = p_of(ga), pb = p_of(gb);
+    CHECK(pa > 0.f && pa < 1.f && pb > 0.f && pb < 1.f && pa != pb);
+    auto sc = bs.score_value(0, rng);
+    CHECK(sc.second.size() == 2);
+    for (size_t i = 0; i < 2; i++) {                          // log(alpha / 2) + log p(v | p of that group)
+      const float pg = sc.first[i] == ga ? pa : pb;
+      CHECK(std::isfinite(sc.second[i]));
+      CHECK(close_to(sc.second[i], std::log(0.5) + std::log(bits[0] ? double(pg) : 1.0 - double(pg))));
+    }
+    bs.delete_group(gb);                                      // the slot goes back ...
+    const size_t gc = bs.create_group(rng);                   // ... and comes out again with a p of its own
+    const float pc = p_of(gc);
+    CHECK(pc > 0.f && pc < 1.f && pc != pb);
+    std::vector<size_t> labels(M);
+    bs.delete_group(gc);
+    bs.delete_group(ga);
+    for (size_t i = 0; i < M; i++) labels[i] = i % 2;
+    bs.assign_all(labels, rng);
+    for (int sw = 0; sw < 4; sw++) bs.gibbs_sweep(3, uint64_t(sw), rng);
+    size_t tot = 0;
+    for (size_t gid : bs.groups()) {
+      const float pg = p_of(gid);
+      CHECK(pg > 0.f && pg < 1.f);                            // incl. groups born from free slots during a sweep
+      tot += bs.groupsize(gid);
+    }
+    CHECK(tot == M);
+  }
   std::printf("test_mixture_state_gpu ok\n");
   return 0;
 }

@@ -25,6 +25,23 @@ def test_host_api_cpu():
     assert "test_host_api ok" in subprocess.check_output([exe]).decode()
 
 
+def test_plugin_layer_writes_protobufs_own_bytes_for_the_in_tree_messages(golden):
+    """get_hp / get_ss of bbnc and dm, group_manager::get_hp and ::serialize (the reference's own
+    test_group_manager.cpp:22-66 scenario) against tests/golden/wire.json -- bytes from Google's protobuf runtime
+    (microscopes/io/schema.proto:3-46).  Host-side only."""
+    exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_wire_golden.cpp"), "test_wire_golden", LINK)
+    got = {}
+    for line in subprocess.check_output([exe]).decode().splitlines():
+        name, idx, hx = line.split("\t")
+        got.setdefault(name, {})[int(idx)] = hx
+    want = {}
+    for vec in golden("wire"):
+        want.setdefault(vec["message"], []).append(vec["hex"])
+    for name in ("CRP", "BetaBernoulliNonConj.Shared", "BetaBernoulliNonConj.Group", "DirichletMultinomial.Shared",
+                 "DirichletMultinomial.Group", "GroupManager"):
+        assert [got[name][i] for i in range(len(want[name]))] == want[name], name
+
+
 def test_library_exports_every_symbol_the_header_declares():
     import re
     import common_amd

@@ -125,33 +125,63 @@ def test_c4_niw_256k_rows_dim32(gpu_ctx):
     assert rel_err(fast[torch.from_numpy(rows).to(gpu_ctx.torch_device)].cpu().numpy(), want).max() <= 2e-5
 
 
-def test_c5_shard_shape_k1024_sweep_only(gpu_ctx):
-    """one GPU's share of config C5 in shape (K = 1024), rows cut to 2M: fused sweep, no score matrix"""
+def test_c5_full_shard_12_5m_rows_k1024_fused_sweep(gpu_ctx):
+    """one GPU's share of config C5 at its real size: 12.5 M rows x K = 1024, the fused sweep step (no score matrix):
+    counts bit-exact against bincount, sampled rows against the oracle's draw with every disagreement proven to sit on
+    a CDF step, and the whole step equal to assign + accumulate done separately"""
     import common_amd
-    N, K = 2_000_000, 1024
+    from tests.gpu_helpers import crp_prior_matrix
+    N, K, seed, alpha = 12_500_000, 1024, 3, 1.0
     dev = gpu_ctx.torch_device
     g = torch.Generator(device=dev)
     g.manual_seed(11)
-    centres = torch.randn(K, generator=g, device=dev) * 30
+    centres = torch.randn(K, generator=g, device=dev) * 10
     z = torch.randint(0, K, (N,), generator=g, device=dev, dtype=torch.int32)
     x = (centres[z.long()] + torch.randn(N, generator=g, device=dev)).float().contiguous()
     view = common_amd.DataView.from_tensors(gpu_ctx, [x])
     st = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    st.set_alpha(alpha)
     zs = z.clone()
     drv = common_amd.dist.ShardedSweep(st, view, zs, first_global_row=0)
     drv.rebuild_tables()
-    drv.sweep(seed=3, sweep_index=0)
+    zh = z.cpu().numpy()
+    cnt0 = np.bincount(zh, minlength=K)
+    assert np.array_equal(st.get_group_counts(), cnt0) and np.array_equal(st.get_ss(0)["count"], cnt0)
+    rec0 = st.get_ss(0)                                    # the float state the sweep scores against
+    drv.sweep(seed=seed, sweep_index=0)
     zn = zs.cpu().numpy()
     assert zn.min() >= 0 and zn.max() < K
-    assert np.array_equal(st.get_group_counts(), np.bincount(zn, minlength=K))
-    # the fused kernel agrees with sampling the materialised leave-one-out scores of the same rows
-    st2 = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
-    st2.accumulate(view, z)
-    rows = slice(100_000, 100_512)
-    sc = st2.score_value(view, row0=100_000, nrows=512, z=z[rows].contiguous(), crp_prior=True).cpu().numpy()
+    cnt1 = np.bincount(zn, minlength=K)
+    assert np.array_equal(st.get_group_counts(), cnt1) and np.array_equal(st.get_ss(0)["count"], cnt1)   # bit-exact
+    # float suff-stats of the new assignment against a float64 two-pass computation
+    xh = x.cpu().numpy().astype(np.float64)
+    rec1 = st.get_ss(0)
+    mean = np.bincount(zn, weights=xh, minlength=K) / np.maximum(cnt1, 1)
+    ctv = np.bincount(zn, weights=(xh - mean[zn]) ** 2, minlength=K)
+    assert rel_err(rec1["mean"], mean).max() <= TOL and rel_err(rec1["count_times_variance"], ctv).max() <= TOL
+    # sampled rows (the first, the last, and 510 in between) against the oracle's draw
+    rows = np.concatenate([[0, N - 1], np.random.default_rng(5).choice(N, 510, replace=False)])
+    hp = dict(mu=0., kappa=1., sigmasq=1., nu=1.)
+    scores = _oracle_rows(orc.NICH, 0, hp, rec0, x.cpu().numpy(), rows, zh) + crp_prior_matrix(cnt0, alpha, zh[rows])
     mism = 0
-    for i in range(512):
-        p = orc.scores_to_probs(sc[i].astype(np.float64))
-        pick = orc.sample_discrete(p, orc.uniform01(3, 0, 100_000 + i))
-        mism += int(pick != zn[100_000 + i])
-    assert mism <= 3, mism
+    for i, n in enumerate(rows):
+        p = orc.scores_to_probs(scores[i])
+        u = orc.uniform01(seed, 0, int(n))
+        pick = orc.sample_discrete(p, u)
+        if pick != zn[n]:
+            mism += 1
+            cdf = np.cumsum(p)
+            lo, hi = sorted((int(zn[n]), int(pick)))
+            assert abs(cdf[lo] - u) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, (n, lo, hi, cdf[lo], u)
+    assert mism <= 0.01 * len(rows), mism
+    # the fused step = msc_sweep_assign + msc_accumulate(RESET) on a second state, bit for bit in z and in the counts
+    st2 = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    st2.set_alpha(alpha)
+    st2.accumulate(view, z)
+    z2 = z.clone()
+    st2.sweep_assign(view, z2, seed=seed, sweep=0)
+    assert torch.equal(z2, zs)
+    st2.accumulate(view, z2)
+    assert np.array_equal(st2.get_group_counts(), cnt1)
+    # rows move, but far less than uniformly at random
+    assert 1.0 / K < (zn == zh).mean() < 1.0

@@ -201,10 +201,25 @@ def test_narrow_tiling_at_the_sizes_that_take_eight_steps_per_wave(gpu_ctx, N, K
     loo = st.score_value(view, z=zt, crp_prior=True)
     prior = crp_prior_matrix(counts, 1.7, z[rows])
     want = oracle_scores(feats, fs, z=z, rows=rows) + prior
-    # groups of ~40k rows: the prior term is log(40k) = 10.6 and the likelihood terms cancel most of it, so the float
-    # sum rounds relative to its terms, not to the result (either tiling: 1.4e-6 / 1.6e-6 of the result measured)
-    err = np.abs(loo[rt].cpu().numpy() - want) / np.maximum(1.0, np.maximum(np.abs(want), np.abs(prior)))
-    assert err.max() <= TOL
+    # The north-star gate is on the float log-score, i.e. on the likelihood part: leave-one-out WITHOUT the prior at
+    # the standard gate.
+    like_want = oracle_scores(feats, fs, z=z, rows=rows)
+    like = st.score_value(view, z=zt)
+    assert rel_err(like[rt].cpu().numpy(), like_want).max() <= TOL
+    # With the prior: groups of ~40k rows have log(count) = 10.6 and likelihoods near -10, so the sum is O(1) while
+    # the likelihood, a float, is only known to ulp(10) = 9.5e-7 (measured budget at (600000, 16): per-feature float
+    # scores 1.2e-6 abs, their float accumulation 1.4e-6 more; profiles/r02_crp_error_budget.txt).  The prior must add
+    # NOTHING to that: the kernels carry it as a (hi, lo) pair -- exact to 1e-14 -- and add hi after the last feature,
+    # so the error of likelihood + prior is the error of the likelihood, gated relative to the likelihood ...
+    got = loo[rt].cpu().numpy().astype(np.float64)
+    err = np.abs(got - want)
+    assert (err / np.maximum(1.0, np.maximum(np.abs(want), np.abs(like_want)))).max() <= TOL
+    # ... and where the row's own group is concerned (one double evaluation per row, k_loo_own) relative to the result
+    own = np.zeros(want.shape, dtype=bool)
+    for r, n in enumerate(rows):
+        if z[n] >= 0:
+            own[r, z[n]] = True
+    assert (err / np.maximum(1.0, np.abs(want)))[own].max() <= TOL
     st.sweep_assign(view, zt, seed=5, sweep=1)
     got = zt.cpu().numpy()
     feats_o = [(F, ss64, f["values"]) for f, (F, ss64, _) in zip(feats, fs)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condense rocprofv3 CSV output (gpurun_out/prof/...) into the small summaries kept under profiles/.
 
-usage: tools/summarize_prof.py <round-tag> <kernel-trace-dir> [<pmc-dir> ...]
+usage: tools/summarize_prof.py <round-tag> <kernel-trace-dir> [<pmc-dir> ...]      (MSC_PROFILES_DIR overrides profiles/)
 Writes profiles/<tag>_kernel_stats.csv (name truncated to 90 chars, our msc:: kernels first) and
 profiles/<tag>_pmc.json with per-kernel per-launch averages of every counter found, plus the HBM
 traffic per launch derived as MI355X_MICROARCH.md prescribes for gfx950:
@@ -26,7 +26,7 @@ def short(name):
 
 def main():
     tag, ktdir = sys.argv[1], sys.argv[2]
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    out = os.environ.get("MSC_PROFILES_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     stats = glob.glob(os.path.join(ktdir, "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
