@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c4 / c5_shard objects at N = 1")
     ap.add_argument("--tune", action="store_true", help="msc_score_tune before the C2 pass (off: the default launch shape)")
+    ap.add_argument("--probe-alloc", type=int, default=12, help="candidates of msc_device_alloc_probed for the C2 score matrix")
+    ap.add_argument("--no-probe-alloc", action="store_true", help="plain torch allocation for the score matrix")
     return ap.parse_args()
 
 
@@ -248,7 +250,14 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     view = common_amd.DataView.from_tensors(ctx, [x])
     st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)   # default hp mu=0,kappa=1,sigmasq=1,nu=1
     st.accumulate(view, z)                                   # suff-stats from the true components
-    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    # the [N, K] matrix is caller-owned; where the driver places it decides between ~5.6 and ~7.0 TB/s for the same
+    # kernel (profiles/r02_placement_study.txt), so the library offers a probed allocation: the best of a dozen
+    placement = {"allocator": "torch.empty"}
+    if a.no_probe_alloc or a.probe_alloc <= 1:
+        out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    else:
+        out, rates, kept = ctx.alloc_probed((N, K), torch.float32, candidates=a.probe_alloc)
+        placement = {"allocator": "msc_device_alloc_probed", "candidates_fill_GBps": [round(r, 1) for r in rates], "kept": kept}
     tuned = None
     if a.tune:
         tuned = st.score_tune(view, out)                     # explicit and synchronous; never inside msc_score_value
@@ -281,7 +290,8 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                                "[N,K] f32 scores materialised; group tables prepared once before timing (k_prepare, "
                                "9 us, runs when suff-stats change)" % (N, K),
                    "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x1",
-                   "launch_shape": "msc_score_tune -> %s" % (tuned,) if tuned else "default (4 rows x 2 visits)"},
+                   "launch_shape": "msc_score_tune -> %s" % (tuned,) if tuned else "default (4 rows x 2 visits)",
+                   "score_matrix": placement},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic if (N, K) == (1_000_000, 256) else None,

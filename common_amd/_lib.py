@@ -45,6 +45,8 @@ _SIGS = {
     "msc_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_context_synchronize": (C.c_int, [C.c_void_p]),
     "msc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "msc_device_alloc_probed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "msc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "msc_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

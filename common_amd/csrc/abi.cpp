@@ -83,7 +83,7 @@ extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  ctx->mailbox_bytes = 64 * 1024;
+  ctx->mailbox_bytes = 192 * 1024;       // niw at dim 128: a 66 KB record + a 66 KB hp block
   MSC_HIP(hipHostMalloc(&ctx->mailbox_host, ctx->mailbox_bytes, hipHostMallocMapped));
   MSC_HIP(hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox_host, 0));
   *out = ctx.release();
@@ -123,6 +123,60 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
     return fail(MSC_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
   }
   *out = p;
+  return MSC_OK;
+}
+extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out,
+                                       float *rates_gbps, uint32_t *chosen) {
+  MSC_REQUIRE(ctx && out, "null argument");
+  MSC_REQUIRE(candidates >= 1 && candidates <= 64, "candidates %u outside 1..64", candidates);
+  *out = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(MSC_EINVAL, "msc_device_alloc_probed waits for the device: not on a capturing stream");
+  std::vector<void *> bufs;
+  std::vector<float> rate;
+  auto release = [&](int keep) {
+    for (size_t i = 0; i < bufs.size(); i++)
+      if ((int)i != keep) (void)hipFree(bufs[i]);
+  };
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MSC_EHIP, "hipEventCreate failed");
+  int rc = MSC_OK;
+  const int reps = nbytes >= (256u << 20) ? 3 : 8;
+  for (uint32_t i = 0; i < candidates; i++) {
+    void *p = nullptr;
+    if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) {        // out of memory: settle for what there is
+      (void)hipGetLastError();
+      break;
+    }
+    bufs.push_back(p);
+    hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);          // (zero-filled, like msc_device_alloc)
+    if (e == hipSuccess && launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps && e == hipSuccess; r++)
+      if (launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) { rc = fail(MSC_EHIP, "placement probe failed: %s", hipGetErrorString(e)); break; }
+    rate.push_back(ms > 0.f ? (float)((double)nbytes * reps / (ms * 1e-3) / 1e9) : 0.f);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != MSC_OK || bufs.empty() || rate.size() != bufs.size()) {
+    release(-1);
+    return rc != MSC_OK ? rc : fail(MSC_ENOMEM, "hipMalloc of %zu bytes failed", nbytes);
+  }
+  int best = 0;
+  for (size_t i = 1; i < rate.size(); i++)
+    if (rate[i] > rate[best]) best = (int)i;
+  release(best);
+  if (rates_gbps)
+    for (uint32_t i = 0; i < candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
+  if (chosen) *chosen = (uint32_t)best;
+  *out = bufs[best];
   return MSC_OK;
 }
 extern "C" int msc_device_free(msc_context *ctx, void *dev) {
@@ -433,8 +487,8 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
                   h.dim, kMaxDDDim);
     if (h.family == MSC_DM && (h.dim == 0 || h.dim > kMaxDDDim))
       return fail(MSC_EUNSUPPORTED, "feature %u: dm categories %u outside 1..%u", f, h.dim, kMaxDDDim);
-    if (h.family == MSC_NIW && (h.dim == 0 || h.dim > 32))
-      return fail(MSC_EUNSUPPORTED, "feature %u: niw dim %u outside 1..32 (one 32x32 MFMA tile)", f, h.dim);
+    if (h.family == MSC_NIW && (h.dim == 0 || h.dim > kMaxNiwDim))
+      return fail(MSC_EUNSUPPORTED, "feature %u: niw dim %u outside 1..%u", f, h.dim, kMaxNiwDim);
     h.i64_off = n_i64;
     h.i64_len = acc_i64_rows(h.family, h.dim) * kpad;
     n_i64 += h.i64_len;
@@ -472,10 +526,12 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
       h.dm_meta.assign(2 * ((size_t)h.dim + 1), 0u);
     }
     if (h.family == MSC_NIW) {
-      if ((rc = dev_alloc(st->owned, &h.niw_w, (size_t)ngroups * 32 * 32))) return bail(rc);
-      if ((rc = dev_alloc(st->owned, &h.niw_b, (size_t)ngroups * 64))) return bail(rc);
-      if ((rc = dev_alloc(st->owned, &h.niw_w64, (size_t)ngroups * 32 * 32))) return bail(rc);
-      if ((rc = dev_alloc(st->owned, &h.niw_mu64, (size_t)ngroups * 32))) return bail(rc);
+      if (h.dim <= (uint32_t)kNiwPad) {                    // operands of the f32 MFMA kernel (MSC_SCORE_NIW_F32), dim <= 32 only
+        if ((rc = dev_alloc(st->owned, &h.niw_w, (size_t)ngroups * kNiwPad * kNiwPad))) return bail(rc);
+        if ((rc = dev_alloc(st->owned, &h.niw_b, (size_t)ngroups * 2 * kNiwPad))) return bail(rc);
+      }
+      if ((rc = dev_alloc(st->owned, &h.niw_w64, (size_t)ngroups * niw_w_stream(h.dim)))) return bail(rc);
+      if ((rc = dev_alloc(st->owned, &h.niw_mu64, (size_t)ngroups * niw_b_stream(h.dim)))) return bail(rc);
       if ((rc = dev_alloc(st->owned, &h.niw_c64, (size_t)ngroups * 8))) return bail(rc);
     }
     if (!h.hp.empty()) {
@@ -1494,7 +1550,7 @@ extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, i
   MSC_REQUIRE(op == MSC_OP_SCORE_DATA || host_value, "null value");
   MSC_REQUIRE(op <= MSC_OP_REMOVE || score, "null score");
   if (family == MSC_DD) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dd dim %u outside 1..%u", dim, kMaxDDDim);
-  if (family == MSC_NIW) MSC_REQUIRE(dim >= 1 && dim <= 32, "niw dim %u outside 1..32", dim);
+  if (family == MSC_NIW) MSC_REQUIRE(dim >= 1 && dim <= kMaxNiwDim, "niw dim %u outside 1..%u", dim, kMaxNiwDim);
   if (family == MSC_DM) MSC_REQUIRE(dim >= 1 && dim <= kMaxDDDim, "dm categories %u outside 1..%u", dim, kMaxDDDim);
   const size_t hp_bytes = msc_hp_floats(family, dim) * sizeof(float), ss_bytes = msc_ss_bytes(family, dim);
   const size_t v_bytes = (family == MSC_BB || family == MSC_BBNC) ? 1 : (family == MSC_NIW || family == MSC_DM) ? 4 * (size_t)dim : 4;

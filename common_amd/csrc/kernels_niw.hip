@@ -1,19 +1,25 @@
-// kernels_niw.hip -- Normal-Inverse-Wishart (distributions.hpp:87-91,481-509), dim <= 32.
+// kernels_niw.hip -- Normal-Inverse-Wishart (distributions.hpp:87-91,481-509: NormalInverseWishart<-1>, the
+// dimension is a run-time value), dim <= 128.
 //
 //   k_niw_prepare   one wave per group: posterior (kappa_n, nu_n, mu_n, Psi_n) in double,
-//                   Cholesky Psi_n = L L^T and L^-1 in LDS, then
-//                     W_k = L^-1 * sqrt(kappa_n / (kappa_n + 1))        (float, [32][32], zero padded)
+//                   Cholesky Psi_n = L L^T and L^-1 as packed triangles in LDS, then
+//                     W_k = L^-1 * sqrt(kappa_n / (kappa_n + 1))
 //                   so that the multivariate-t predictive is
 //                     score(x) = c0_k - c1_k * log1p(|W_k (x - mu_k)|^2)
-//                   (the reference refactors Sigma for every (row, group) pair).
+//                   (the reference refactors Sigma for every (row, group) pair).  W_k is lower
+//                   triangular and is written as the operand stream of the f64 kernel: 16 x 16 blocks, only those
+//                   on or below the diagonal (msc_internal.hpp niw_w_index).
 //   k_score_niw     the only dense contraction on the path -> fp32 MFMA
 //                   (v_mfma_f32_32x32x2_f32, exact f32 fma chains): per group, A = W_k
 //                   (32 x 32), B = (X_tile - mu_k)^T (32 features x 32 rows); |.|^2 over the
 //                   output rows is an in-register sum + one cross-half shuffle; lane <-> data row.
 //   k_score_niw64   the default: the same contraction on the f64 matrix pipe
-//                   (v_mfma_f64_16x16x4_f64).  In float the score error is c1 * eps(q) with
-//                   c1 >= dim/2, which breaks the 1e-6 gate for small groups at dim 32; the f32
-//                   kernel stays available behind MSC_SCORE_NIW_F32 at twice the matrix rate.
+//                   (v_mfma_f64_16x16x4_f64), block by block of the triangle: component block b meets feature
+//                   blocks 0 .. b only, so dim 32 costs 12 matrix instructions per (16 rows, group) instead of
+//                   the 16 of the full square, and any dimension up to 128 is NB (NB + 1) / 2 chunks of four.
+//                   In float the score error is c1 * eps(q) with c1 >= dim/2, which breaks the 1e-6 gate for
+//                   small groups at dim 32; the f32 kernel (dim <= 32) stays available behind MSC_SCORE_NIW_F32
+//                   at twice the matrix rate.
 //   k_niw_bucket_*, k_niw_group_sums   sum_x, sum_xxT by group: rows bucketed by group, summed in registers
 //
 // Leave-one-out needs no second factorisation: with u = x - mu_n, t = u^T Psi_n^-1 u,
@@ -37,15 +43,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (NIW_* table rows and kNiwPad: msc_internal.hpp)
 
 // hp layout: {kappa, nu, mu[d], psi[d*d]}; raw_f32 per group: {sum_x[d], sum_xxT[d*d]}
+// LDS: A (Psi_n -> L) and Li (L^-1) as packed lower triangles, tri(i, j) = i (i + 1) / 2 + j, then mu_n[d], (W mu)[d]
+MSC_DEV size_t tri(uint32_t i, uint32_t j) { return (size_t)i * (i + 1u) / 2u + j; }
 __global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__ feats, uint32_t f,
                                                      uint32_t K, uint32_t kpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FeatDesc fd = feats[f];
   const uint32_t d = fd.dim, k = blockIdx.x;     // k == K: the prior (n = 0), for score_data
   const int t = threadIdx.x;
-  double *A = reinterpret_cast<double *>(smem);   // [d][d] Psi_n -> L
-  double *Li = A + (size_t)d * d;                 // [d][d] L^-1
-  double *mun = Li + (size_t)d * d;               // [d]
+  const size_t ntri = (size_t)d * (d + 1u) / 2u;
+  double *A = reinterpret_cast<double *>(smem);   // packed: Psi_n -> L
+  double *Li = A + ntri;                          // packed: L^-1
+  double *mun = Li + ntri;                        // [d]
+  double *wmu = mun + d;                          // [d] (L^-1 mu_n)
   const double kappa = fd.hp[0], nu = fd.hp[1];
   const float *mu = fd.hp + 2, *psi = fd.hp + 2 + d;
   const bool prior = k >= K;
@@ -56,34 +66,34 @@ __global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__
   __syncthreads();
   for (uint32_t idx = t; idx < d * d; idx += 64) {
     const uint32_t i = idx / d, j = idx - i * d;
-    A[idx] = (double)psi[idx] + (prior ? 0.0 : (double)sxx[idx]) + kappa * (double)mu[i] * (double)mu[j] -
-             kn * mun[i] * mun[j];
+    if (j > i) continue;
+    A[tri(i, j)] = (double)psi[idx] + (prior ? 0.0 : (double)sxx[idx]) + kappa * (double)mu[i] * (double)mu[j] -
+                   kn * mun[i] * mun[j];
   }
   __syncthreads();
   // right-looking Cholesky, lower triangle
   double logdet = 0;
   for (uint32_t j = 0; j < d; j++) {
-    const double ljj = sqrt(A[(size_t)j * d + j]);
+    const double ljj = sqrt(A[tri(j, j)]);
     logdet += 2.0 * log(ljj);
     __syncthreads();
-    for (uint32_t i = j + 1 + t; i < d; i += 64) A[(size_t)i * d + j] /= ljj;
-    if (t == 0) A[(size_t)j * d + j] = ljj;
+    for (uint32_t i = j + 1 + t; i < d; i += 64) A[tri(i, j)] /= ljj;
+    if (t == 0) A[tri(j, j)] = ljj;
     __syncthreads();
     const uint32_t m = d - j - 1;
     for (uint32_t idx = t; idx < m * m; idx += 64) {
       const uint32_t i = j + 1 + idx / m, c = j + 1 + idx % m;
-      if (c <= i) A[(size_t)i * d + c] -= A[(size_t)i * d + j] * A[(size_t)c * d + j];
+      if (c <= i) A[tri(i, c)] -= A[tri(i, j)] * A[tri(c, j)];
     }
     __syncthreads();
   }
   // L^-1 by columns: lane c solves L y = e_c
   for (uint32_t c = t; c < d; c += 64) {
-    for (uint32_t i = 0; i < c; i++) Li[(size_t)i * d + c] = 0.0;
-    Li[(size_t)c * d + c] = 1.0 / A[(size_t)c * d + c];
+    Li[tri(c, c)] = 1.0 / A[tri(c, c)];
     for (uint32_t i = c + 1; i < d; i++) {
       double s = 0;
-      for (uint32_t m = c; m < i; m++) s += A[(size_t)i * d + m] * Li[(size_t)m * d + c];
-      Li[(size_t)i * d + c] = -s / A[(size_t)i * d + i];
+      for (uint32_t m = c; m < i; m++) s += A[tri(i, m)] * Li[tri(m, c)];
+      Li[tri(i, c)] = -s / A[tri(i, i)];
     }
   }
   __syncthreads();
@@ -93,31 +103,45 @@ __global__ __launch_bounds__(64) void k_niw_prepare(const FeatDesc *__restrict__
     return;
   }
   const double scale = sqrt(kn / (kn + 1.0));
-  float *W = fd.niw_w + (size_t)k * kNiwPad * kNiwPad;
-  for (uint32_t idx = t; idx < kNiwPad * kNiwPad; idx += 64) {
-    const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
-    W[idx] = (i < d && j <= i) ? (float)(Li[(size_t)i * d + j] * scale) : 0.0f;
+  // the operand stream of the f64 kernel: every slot of every chunk (zeros above the diagonal and beyond dim)
+  {
+    double *W = fd.niw_w64 + (size_t)k * niw_w_stream(d);
+    const uint32_t nb = niw_blocks(d);
+    for (uint32_t b = 0; b < nb; b++)
+      for (uint32_t s4 = 0; s4 <= b; s4++) {
+        double *chunk = W + (size_t)(b * (b + 1u) / 2u + s4) * 256u;
+        for (uint32_t slot = t; slot < 256u; slot += 64) {
+          const uint32_t lane = slot >> 2, e = slot & 3u, i = 16u * b + (lane & 15u), j = 16u * s4 + 4u * e + (lane >> 4);
+          chunk[slot] = (i < d && j <= i) ? Li[tri(i, j)] * scale : 0.0;
+        }
+      }
+    // b = W mu_n in the accumulator layout (register r of the lanes with kk = i % 4 holds row 4 r + kk of a block), so
+    // that W x - b starts from acc = -b
+    for (uint32_t i = t; i < d; i += 64) {
+      double bsum = 0.0;
+      for (uint32_t j = 0; j <= i; j++) bsum += Li[tri(i, j)] * mun[j];
+      wmu[i] = bsum * scale;
+    }
+    __syncthreads();
+    double *B = fd.niw_mu64 + (size_t)k * niw_b_stream(d);
+    for (uint32_t slot = t; slot < nb * 256u; slot += 64) {
+      const uint32_t b = slot >> 8, lane = (slot >> 2) & 63u, r = slot & 3u, i = 16u * b + 4u * r + (lane >> 4);
+      B[slot] = i < d ? wmu[i] : 0.0;
+    }
   }
-  double *W64 = fd.niw_w64 + (size_t)k * kNiwPad * kNiwPad;
-  for (uint32_t idx = t; idx < kNiwPad * kNiwPad; idx += 64) {
-    const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
-    W64[idx] = (i < d && j <= i) ? Li[(size_t)i * d + j] * scale : 0.0;
-  }
-  // b = W mu_n, stored in the order the f64 kernel's accumulator wants it: slot [kk][r] holds
-  // row kk + 4r (r < 4) or 16 + kk + 4(r-4) of the whitened mean, so W x - b starts from acc = -b
-  for (uint32_t slot = t; slot < kNiwPad; slot += 64) {
-    const uint32_t kk = slot >> 3, r = slot & 7, i = r < 4 ? kk + 4 * r : 16 + kk + 4 * (r - 4);
-    double b = 0.0;
-    if (i < d)
-      for (uint32_t j = 0; j <= i; j++) b += Li[(size_t)i * d + j] * mun[j];
-    fd.niw_mu64[(size_t)k * kNiwPad + slot] = b * scale;
-  }
-  float *B = fd.niw_b + (size_t)k * 2 * kNiwPad;      // mu hi[32] | lo[32]
-  for (uint32_t i = t; i < kNiwPad; i += 64) {
-    float hi = 0.f, lo = 0.f;
-    if (i < d) split_hi_lo(mun[i], hi, lo);
-    B[i] = hi;
-    B[kNiwPad + i] = lo;
+  if (d <= (uint32_t)kNiwPad && fd.niw_w != nullptr) {            // operands of the f32 kernel
+    float *W = fd.niw_w + (size_t)k * kNiwPad * kNiwPad;
+    for (uint32_t idx = t; idx < kNiwPad * kNiwPad; idx += 64) {
+      const uint32_t i = idx / kNiwPad, j = idx % kNiwPad;
+      W[idx] = (i < d && j <= i) ? (float)(Li[tri(i, j)] * scale) : 0.0f;
+    }
+    float *B = fd.niw_b + (size_t)k * 2 * kNiwPad;      // mu hi[32] | lo[32]
+    for (uint32_t i = t; i < kNiwPad; i += 64) {
+      float hi = 0.f, lo = 0.f;
+      if (i < d) split_hi_lo(mun[i], hi, lo);
+      B[i] = hi;
+      B[kNiwPad + i] = lo;
+    }
   }
   if (t == 0) {
     const double dd = d, dof = nun - dd + 1.0;
@@ -289,9 +313,13 @@ __global__ __launch_bounds__(256) void k_score_niw(const FeatDesc *__restrict__ 
 // ---------------------------------------------------------------------------
 // f64 matrix pipe.  v_mfma_f64_16x16x4_f64 maps (cdna_hip_programming.md section 3): lane
 // l = (c = l & 15, kk = l >> 4): A[i = c][k = kk], B[k = kk][j = c],
-// D[i = kk + 4 reg][j = c], reg in [0,4).  i = whitened component (two 16-blocks for dim 32),
-// j = data row.  Step s of the contraction pairs features (s, 8+s, 16+s, 24+s), so lane
-// (c, kk) needs the 8 contiguous values [8kk, 8kk+8) of its W row and of its x row.
+// D[i = kk + 4 reg][j = c], reg in [0,4).  i = whitened component within a 16-block, j = data row.
+// W_k is lower triangular, so component block b (rows 16b .. 16b+15) only meets feature blocks 0 .. b: a chunk (b, s4)
+// is four steps, step e contracting features 16 s4 + 4 e + kk -- lane (c, kk) holds x[row c][4 s + kk] for every step
+// s, as floats, widened on the way into the matrix instruction (one v_cvt per 64-cycle MFMA).  The A operands of a
+// chunk arrive as one 32-byte read per lane from the stream k_niw_prepare wrote in exactly this order, the
+// accumulators of a block start from -(W mu) in their own layout.  dim 32: 12 matrix instructions per (16 rows,
+// group) where the full square took 16.
 // ---------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -300,7 +328,6 @@ MSC_DEV double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-// HALF: dim <= 16 -- the lower 16 rows of W are zero, so is their half of the output: one MFMA chain instead of two
 // v + v[lane ^ 16], then that + its [lane ^ 32]: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows of
 // one register with the even rows of another, so (x, x) comes back as (the even partner, the odd partner) of every lane
 // -- two VALU instructions per 32-bit half where ds_bpermute needs an address and an LDS round trip.  Same additions
@@ -315,11 +342,46 @@ MSC_DEV double xsum_rows_f64(double v) {
   return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
-template <int JB, bool LOO, bool ACCUM, bool HALF>
+// log(u) for u >= 1 in double without the library routine's branches and tables: u = m 2^e with m in [1/sqrt2, sqrt2),
+// log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716, as an odd series to s^15 (next term 2 s^17 / 17 < 2e-14);
+// the quotient through v_rcp_f64 and two Newton steps.  ~30 double instructions.
+MSC_DEV double log_ge1_f64(double u) {
+  int hi = __double2hiint(u);
+  int e = (hi >> 20) - 1023;
+  double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(u));      // [1, 2)
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    e += 1;
+  }
+  const double den = m + 1.0;
+  double y = __builtin_amdgcn_rcp(den);
+  y = y * fma(-den, y, 2.0);
+  y = y * fma(-den, y, 2.0);
+  const double sq = (m - 1.0) * y, s2 = sq * sq;
+  double p = 1.0 / 15.0;
+  p = fma(p, s2, 1.0 / 13.0);
+  p = fma(p, s2, 1.0 / 11.0);
+  p = fma(p, s2, 1.0 / 9.0);
+  p = fma(p, s2, 1.0 / 7.0);
+  p = fma(p, s2, 1.0 / 5.0);
+  p = fma(p, s2, 1.0 / 3.0);
+  p = fma(p, s2, 1.0);
+  return fma((double)e, 0.69314718055994530942, 2.0 * sq * p);
+}
+// score = c0 - c1 log1p(q) of the MFMA kernel, all in double.  A float logarithm (1e-7 of the term) is not enough here:
+// with tiny groups in high dimension c0 and the term cancel (c0 = +130, c1 log1p(q) = 129.2 at dim 48 with five rows in
+// the group), and 1e-7 of the term is 1e-5 of the score.  The series above costs ~2 % of the matrix work it follows; a
+// branch to the library log1p for the cancelling lanes only cost 25 % (C4 1.01 -> 1.27 ms: its registers).
+MSC_DEV double niw_score_from_q(double c0, double c1, double q) { return c0 - c1 * log_ge1_f64(1.0 + q); }
+
+// NB = 16-blocks of the dimension (1 .. 8), JB = 16-row blocks a wave carries
+template <int NB, int JB, bool LOO, bool ACCUM>
 __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict__ feats, uint32_t f,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
                                                       double *__restrict__ qown, float *__restrict__ out, uint64_t ld) {
+  constexpr int NS = 4 * NB;                                   // steps of the padded dimension
+  constexpr int NCH = NB * (NB + 1) / 2;
   const FeatDesc fd = feats[f];
   const uint32_t d = fd.dim;
   const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
@@ -330,23 +392,16 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
     const uint64_t rb = blk * 16 * JB;
-    double xd[JB][8];            // this lane's 8 features of its row, widened once
+    float xf[JB][NS];            // this lane's feature of every step, for its row of each block
     int gz[JB];
     bool live[JB], msk[JB];
 #pragma unroll
     for (int jb = 0; jb < JB; jb++) {
       const uint64_t row = rb + 16 * jb + c;
       live[jb] = row < nrows;
-      const float *xp = X + (row0 + (live[jb] ? row : 0)) * d + 8 * kk;
-      if (d == 32) {
-        const float4 v0 = live[jb] ? ld4(xp) : make_float4(0, 0, 0, 0);
-        const float4 v1 = live[jb] ? ld4(xp + 4) : make_float4(0, 0, 0, 0);
-        xd[jb][0] = v0.x; xd[jb][1] = v0.y; xd[jb][2] = v0.z; xd[jb][3] = v0.w;
-        xd[jb][4] = v1.x; xd[jb][5] = v1.y; xd[jb][6] = v1.z; xd[jb][7] = v1.w;
-      } else {
+      const float *xp = X + (row0 + (live[jb] ? row : 0)) * d + kk;
 #pragma unroll
-        for (int s = 0; s < 8; s++) xd[jb][s] = (live[jb] && (uint32_t)(8 * kk + s) < d) ? (double)xp[s] : 0.0;
-      }
+      for (int s = 0; s < NS; s++) xf[jb][s] = (live[jb] && (uint32_t)(4 * s + kk) < d) ? xp[4 * s] : 0.0f;
       gz[jb] = (LOO && live[jb]) ? z[row] : -1;
       msk[jb] = false;
       if (live[jb] && fd.mask != nullptr)
@@ -354,34 +409,47 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
     }
     double qkeep[JB][4];         // |W(x - mu)|^2 of the 4 groups this lane finalises per batch of 16
     for (uint32_t k = 0; k < K; k++) {
-      // (a register double buffer prefetching group k+1's operands was measured slower: 249 VGPRs)
-      const double *Wk = fd.niw_w64 + ((size_t)k * kNiwPad + c) * kNiwPad + 8 * kk;
-      const double *Bk = fd.niw_mu64 + (size_t)k * kNiwPad + 8 * kk;
-      double a0[8], a1[8], nb[8];
+      const double *Wk = fd.niw_w64 + (size_t)k * (NCH * 256) + lane * 4;
+      const double *Bk = fd.niw_mu64 + (size_t)k * (NB * 256) + lane * 4;
+      double qp[JB];
 #pragma unroll
-      for (int s = 0; s < 8; s += 2) {
-        const double2 p0 = *reinterpret_cast<const double2 *>(Wk + s);
-        const double2 pb = *reinterpret_cast<const double2 *>(Bk + s);
-        a0[s] = p0.x; a0[s + 1] = p0.y; nb[s] = -pb.x; nb[s + 1] = -pb.y;
-        if (!HALF) {
-          const double2 p1 = *reinterpret_cast<const double2 *>(Wk + 16 * kNiwPad + s);
-          a1[s] = p1.x; a1[s + 1] = p1.y;
+      for (int jb = 0; jb < JB; jb++) qp[jb] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const double2 b01 = *reinterpret_cast<const double2 *>(Bk + b * 256), b23 = *reinterpret_cast<const double2 *>(Bk + b * 256 + 2);
+        f64x4 acc[JB];
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++) acc[jb] = f64x4{-b01.x, -b01.y, -b23.x, -b23.y};   // W x - W mu
+#pragma unroll
+        for (int s4 = 0; s4 <= b; s4++) {
+          const double *wc = Wk + (b * (b + 1) / 2 + s4) * 256;
+          const double2 a01 = *reinterpret_cast<const double2 *>(wc), a23 = *reinterpret_cast<const double2 *>(wc + 2);
+          const double a[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            // (steps of a partial last block whose features lie beyond dim multiply zeros: a run-time skip cuts every
+            //  chunk into basic blocks and costs far more than the <= 3 spare steps -- C4 with the skip 1.46 ms, without 1.01)
+#pragma unroll
+            for (int jb = 0; jb < JB; jb++) {
+              float xv = xf[jb][4 * s4 + e];
+              // beyond dim 32 the widened copies of a wave's features (4 NB doubles per row block) would not fit
+              // the register file if they were made once per row block: the value is opaque here, so the
+              // conversion stays next to its matrix instruction (one v_cvt_f64_f32 per 64-cycle MFMA)
+              if (NB > 2) asm volatile("" : "+v"(xv));
+              acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], (double)xv, acc[jb], 0, 0, 0);
+            }
+          }
         }
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) qp[jb] = fma(acc[jb][i], acc[jb][i], qp[jb]);
       }
       const uint32_t slot = k & 3;
       const bool mine = (int)((k >> 2) & 3) == kk;
 #pragma unroll
       for (int jb = 0; jb < JB; jb++) {
-        f64x4 acc0 = {nb[0], nb[1], nb[2], nb[3]}, acc1 = {nb[4], nb[5], nb[6], nb[7]};   // W x - W mu
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], xd[jb][s], acc0, 0, 0, 0);
-          if (!HALF) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], xd[jb][s], acc1, 0, 0, 0);
-        }
-        double qp = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) qp = HALF ? fma(acc0[i], acc0[i], qp) : fma(acc0[i], acc0[i], fma(acc1[i], acc1[i], qp));
-        const double q = xsum_rows_f64(qp);       // over the four lanes c, c + 16, c + 32, c + 48
+        const double q = xsum_rows_f64(qp[jb]);       // over the four lanes c, c + 16, c + 32, c + 48
         if (mine) {
           if (slot == 0) qkeep[jb][0] = q;
           else if (slot == 1) qkeep[jb][1] = q;
@@ -402,9 +470,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 #pragma unroll
           for (int jb = 0; jb < JB; jb++) {
             const double q = valid ? qkeep[jb][i] : 0.0;
-            // q is accurate (f64 contraction); its logarithm only has to be relatively accurate, and the
-            // compensated float log1p is (1e-7 of a term of the score's own size) at a tenth of the double routine
-            double sc = c0 - c1 * (double)log1p_acc((float)q);
+            double sc = niw_score_from_q(c0, c1, q);
             if (LOO && valid && gz[jb] == (int)kg) {       // the own group: its value comes from k_niw_loo_patch
               qown[rb + 16 * jb + c] = q;
               sc = 0.0;
@@ -462,8 +528,8 @@ __global__ __launch_bounds__(256) void k_score_niw_small(const FeatDesc *__restr
 #pragma unroll
   for (int i = 0; i < D; i++) {
 #pragma unroll
-    for (int j = 0; j <= i; j++) w[i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
-    nb[i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];       // (the f64 MFMA kernel's slot order, k_niw_prepare)
+    for (int j = 0; j <= i; j++) w[i * (i + 1) / 2 + j] = fd.niw_w64[kc * niw_w_stream(D) + niw_w_index(i, j)];
+    nb[i] = -fd.niw_mu64[kc * niw_b_stream(D) + niw_b_index(i)];       // (the f64 MFMA kernel's operand streams, k_niw_prepare)
   }
   const double c0 = fd.niw_c64[kc * 8], c1 = fd.niw_c64[kc * 8 + 1];
   const float *X = reinterpret_cast<const float *>(fd.col);
@@ -506,6 +572,8 @@ __global__ __launch_bounds__(256) void k_score_niw_small(const FeatDesc *__restr
         for (int j = 0; j <= i; j++) y = fma(w[i * (i + 1) / 2 + j], x[j], y);
         q = fma(y, y, q);
       }
+      // (dim <= 8: c0 and the term stay small, the compensated float log1p -- 1e-7 of the term -- is enough, and this
+      //  kernel is bound by its vector arithmetic)
       double sc = c0 - c1 * (double)log1p_acc((float)q);
       const int g = __builtin_amdgcn_readlane(gz, r);
       if (g >= 0 && (uint32_t)g == k) {                   // the own group: its value comes from k_niw_loo_patch
@@ -628,13 +696,16 @@ __global__ __launch_bounds__(256) void k_niw_bucket_scatter(const FeatDesc *__re
     if (niw_row_counts(fd, K, row0 + n, g)) idx[base[g] + atomicAdd(&cnt[g], 1u)] = (uint32_t)n;
   }
 }
-// grid (K, splits); the 4 waves of a block take the group's rows round-robin
+// grid (K, splits, tiles): the 4 waves of a block take the group's rows round-robin; blockIdx.z = a 32 x 32 tile
+// (ti, tj) of sum_xxT (one tile up to dim 32, 16 at dim 128).  Lane (i, half) keeps rows 32 ti + i, columns
+// 32 tj + 16 half .. + 15 in sixteen doubles; the tiles of the first column also keep sum_x
 __global__ __launch_bounds__(256) void k_niw_group_sums(const FeatDesc *__restrict__ feats, uint32_t f, uint32_t K,
                                                          uint64_t row0, const uint32_t *__restrict__ scratch, int sign) {
-  __shared__ float xs[4][32];
+  __shared__ float xs[4][2][32];                       // per wave: the row's values of the tile's row range | column range
   __shared__ double red[4][17][64];
   const FeatDesc fd = feats[f];
   const uint32_t d = fd.dim, k = blockIdx.x;
+  const uint32_t nt = (d + 31u) / 32u, ti = blockIdx.z / nt, tj = blockIdx.z % nt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t i = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;
   const uint32_t beg = scratch[k], end = scratch[k + 1];
@@ -645,11 +716,12 @@ __global__ __launch_bounds__(256) void k_niw_group_sums(const FeatDesc *__restri
   for (int j = 0; j < 16; j++) sxx[j] = 0.0;
   for (uint32_t p = beg + blockIdx.y * 4 + wave; p < end; p += gridDim.y * 4) {
     const float *x = X + (row0 + idx[p]) * d;
-    xs[wave][lane & 31] = ((uint32_t)(lane & 31) < d) ? x[lane & 31] : 0.f;      // (both halves write the same value)
-    const double xi = (double)xs[wave][i];
+    const uint32_t e = (uint32_t)(lane & 31), src = 32u * (lane < 32 ? ti : tj) + e;
+    xs[wave][lane >> 5][e] = src < d ? x[src] : 0.f;
+    const double xi = (double)xs[wave][0][i];
     if (half == 0) sx += xi;
 #pragma unroll
-    for (int j = 0; j < 16; j++) sxx[j] = fma(xi, (double)xs[wave][half * 16 + j], sxx[j]);
+    for (int j = 0; j < 16; j++) sxx[j] = fma(xi, (double)xs[wave][1][half * 16 + j], sxx[j]);
   }
   // the four waves' partial sums, then one atomic per element and block
 #pragma unroll
@@ -660,17 +732,17 @@ __global__ __launch_bounds__(256) void k_niw_group_sums(const FeatDesc *__restri
   const size_t stride = d + (size_t)d * d;
   double *dst = fd.acc_f64 + (size_t)k * stride;
   for (uint32_t e = threadIdx.x; e < 17 * 64; e += 256) {
-    const uint32_t j = e >> 6, l = e & 63, ii = l >> 1, hh = l & 1u;
+    const uint32_t j = e >> 6, l = e & 63, ii = 32u * ti + (l >> 1), hh = l & 1u;
     const double v = red[0][j][l] + red[1][j][l] + red[2][j][l] + red[3][j][l];
     if (ii >= d) continue;
     if (j == 16) {
-      if (hh == 0 && v != 0.0) atomicAdd(&dst[ii], (double)sign * v);
+      if (tj == 0 && hh == 0 && v != 0.0) atomicAdd(&dst[ii], (double)sign * v);
     } else {
-      const uint32_t col = hh * 16 + j;
+      const uint32_t col = 32u * tj + hh * 16 + j;
       if (col < d && v != 0.0) atomicAdd(&dst[d + (size_t)ii * d + col], (double)sign * v);
     }
   }
-  if (blockIdx.y == 0 && threadIdx.x == 0)
+  if (blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
     atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[k]), (unsigned long long)((long long)sign * (long long)(end - beg)));
 }
 
@@ -693,7 +765,10 @@ __global__ __launch_bounds__(256) void k_niw_commit(const FeatDesc *__restrict__
 // ---------------------------------------------------------------------------
 int launch_niw_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
                        uint32_t kpad) {
-  const size_t lds = sizeof(double) * (2 * (size_t)dim * dim + dim);
+  const size_t lds = sizeof(double) * ((size_t)dim * (dim + 1) + 2 * (size_t)dim);     // two packed triangles, mu_n, W mu_n
+  static unsigned long long attr_devices = 0;
+  if (lds > 64u * 1024u && first_use_on_device(attr_devices))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_niw_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_niw_prepare, dim3(K + 1), dim3(64), lds, stream, feats_dev, f, K, kpad);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -704,8 +779,13 @@ int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+template <int NB, bool LOO, bool ACCUM>
+static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc *feats_dev, uint32_t f, uint32_t K, uint32_t kpad,
+                            uint64_t row0, uint64_t nrows, const int32_t *z, double *qown, float *out, uint64_t ld) {
+  hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), grid, dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+}
 template <bool LOO, bool ACCUM>
-static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, bool half, const FeatDesc *feats_dev,
+static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, uint32_t dim, const FeatDesc *feats_dev,
                                uint32_t f, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                const int32_t *z, double *qown, float *out, uint64_t ld) {
   constexpr int kRowsPerWave = 64;             // 2 tiles of 32 (f32) or 4 blocks of 16 (f64)
@@ -714,13 +794,19 @@ static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, b
   const uint64_t cap = (uint64_t)num_cus * 8;
   if (gx > cap) gx = cap;
   const dim3 grid((unsigned)(gx ? gx : 1)), block(256);
-  if (f32_fast)
+  if (f32_fast && dim <= (uint32_t)kNiwPad)
     hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
   else {
-    if (half)
-      hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM, true>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-    else
-      hipLaunchKernelGGL((k_score_niw64<4, LOO, ACCUM, false>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    switch (niw_blocks(dim)) {
+      case 1: launch_niw64_nb<1, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 2: launch_niw64_nb<2, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 3: launch_niw64_nb<3, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 4: launch_niw64_nb<4, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 5: launch_niw64_nb<5, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 6: launch_niw64_nb<6, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      case 7: launch_niw64_nb<7, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+      default: launch_niw64_nb<8, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
+    }
     if (LOO)
       hipLaunchKernelGGL(k_niw_loo_patch, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, f, K, row0,
                          nrows, z, qown, out, ld);
@@ -758,10 +844,10 @@ int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev,
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
-  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, dim <= 16, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  if (z && accum) launch_niw_score_t<true, true>(stream, num_cus, f32_fast, dim, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (z) launch_niw_score_t<true, false>(stream, num_cus, f32_fast, dim, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if (accum) launch_niw_score_t<false, true>(stream, num_cus, f32_fast, dim, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else launch_niw_score_t<false, false>(stream, num_cus, f32_fast, dim, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -854,7 +940,8 @@ int launch_niw_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats
   if (splits > by_rows) splits = (uint32_t)(by_rows ? by_rows : 1);
   if (splits == 0) splits = 1;
   if (splits > 65535u) splits = 65535u;
-  hipLaunchKernelGGL(k_niw_group_sums, dim3(K, splits), dim3(256), 0, stream, feats_dev, f, K, row0, scratch_dev, sign);
+  const uint32_t nt = (dim + 31u) / 32u;
+  hipLaunchKernelGGL(k_niw_group_sums, dim3(K, splits, nt * nt), dim3(256), 0, stream, feats_dev, f, K, row0, scratch_dev, sign);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

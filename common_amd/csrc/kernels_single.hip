@@ -68,8 +68,9 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
       for (uint32_t idx = t; idx < d * d; idx += 64) sxx[idx] += sg * x[idx / d] * x[idx % d];
       if (t == 0) su[0] += op == MSC_OP_ADD ? 1u : 0xffffffffu;
     } else {
-      double *A = reinterpret_cast<double *>(smem), *P0 = A + (size_t)d * d, *mun = P0 + (size_t)d * d,
-             *y = mun + d;
+      // LDS: one d x d matrix (Psi_n, then -- for score_data -- the prior's Psi in the same place), mu_n[d], y[d]:
+      // 130 KB at dim 128
+      double *A = reinterpret_cast<double *>(smem), *mun = A + (size_t)d * d, *y = mun + d;
       const double kappa = hp[0], nu = hp[1], n = su[0];
       const float *mu = hp + 2, *psi = hp + 2 + d;
       const double kn = kappa + n, nun = nu + n;
@@ -78,7 +79,6 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
       for (uint32_t idx = t; idx < d * d; idx += 64) {
         const uint32_t i = idx / d, j = idx % d;
         A[idx] = (double)psi[idx] + (double)sxx[idx] + kappa * (double)mu[i] * (double)mu[j] - kn * mun[i] * mun[j];
-        P0[idx] = psi[idx];
       }
       __syncthreads();
       const double ldn = chol_lds(A, d, t);
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
                   0.5 * (ldn + dd * log(s)) - 0.5 * (dof + dd) * log1p(q / dof);
         }
       } else {
-        const double ld0 = chol_lds(P0, d, t);
+        __syncthreads();
+        for (uint32_t idx = t; idx < d * d; idx += 64) A[idx] = psi[idx];
+        __syncthreads();
+        const double ld0 = chol_lds(A, d, t);
         if (t == 0)
           score = n == 0.0 ? 0.0
                            : lmultigamma_d(d, 0.5 * nun) - lmultigamma_d(d, 0.5 * nu) + 0.5 * nu * ld0 -
@@ -194,7 +197,10 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
 }
 
 int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int family) {
-  const size_t lds = family == MSC_NIW ? sizeof(double) * (2 * (size_t)dim * dim + 2 * dim) : 0;
+  const size_t lds = family == MSC_NIW ? sizeof(double) * ((size_t)dim * dim + 2 * dim) : 0;
+  static unsigned long long attr_devices = 0;
+  if (lds > 64u * 1024u && first_use_on_device(attr_devices))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_value_op), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_value_op, dim3(1), dim3(64), lds, stream, static_cast<unsigned char *>(mailbox_dev));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -538,6 +538,28 @@ int launch_zero64(hipStream_t stream, void *a, size_t na, void *b, size_t nb) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// msc_device_alloc_probed's probe: zeros written the way the score kernels write -- a wave owns a slot and visits two
+// blocks of four 1 KiB rows, waves numbered so that the resident ones form two dense fronts; non-temporal
+__global__ __launch_bounds__(256) void k_stream_fill(float4 *__restrict__ out, size_t nrows, size_t nslots) {
+  const int lane = threadIdx.x & 63;
+  const size_t slot = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= nslots) return;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (size_t rb = slot * 4; rb < nrows; rb += nslots * 4)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (rb + r < nrows) __builtin_nontemporal_store(zero, reinterpret_cast<f32x4 *>(out + (rb + r) * 64 + lane));
+}
+int launch_stream_fill(hipStream_t stream, int num_cus, void *buf, size_t nbytes) {
+  (void)num_cus;
+  const size_t nrows = nbytes / 1024;                    // whole KiB rows (the tail, < 1 KiB, is left to the memset)
+  if (nrows == 0) return 0;
+  const size_t nslots = (nrows / 4 + 1) / 2 ? (nrows / 4 + 1) / 2 : 1;
+  hipLaunchKernelGGL(k_stream_fill, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, stream, static_cast<float4 *>(buf), nrows, nslots);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,
                 long long *cnt_acc, const uint32_t *cnt_u32, int lift_cnt) {
   hipLaunchKernelGGL(k_lift, dim3((kpad + 255) / 256, nfeat + 1), dim3(256), 0, stream, feats_dev, nfeat,

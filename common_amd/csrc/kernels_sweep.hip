@@ -70,7 +70,8 @@ MSC_DEV float wave_incl_scan(float v, int) {
 // BOUND: `bound` is a wave-uniform upper bound of the scores the caller knows without looking at them; it stands in
 // for the maximum (6 DPP steps + 4 compares saved per row) whenever the total it leads to is a comfortably normal float,
 // and the exact maximum is taken otherwise (an outlier row far below the bound, or a bound that was not one).
-template <int G, bool LOG2 = false, bool BOUND = false>
+// SHIFTED (with BOUND and LOG2): the caller already subtracted the bound from the scores (it folded it into constants)
+template <int G, bool LOG2 = false, bool BOUND = false, bool SHIFTED = false>
 MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_t K, float bound = 0.f) {
   float p[G], sum = 0.f, incl = 0.f, total = 0.f;
   bool done = false;
@@ -78,7 +79,7 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
     sum = 0.f;
 #pragma unroll
     for (int j = 0; j < G; j++) {
-      p[j] = __builtin_amdgcn_exp2f(LOG2 ? s[j] - bound : (s[j] - bound) * 1.44269504088896340736f);
+      p[j] = __builtin_amdgcn_exp2f(SHIFTED ? s[j] : LOG2 ? s[j] - bound : (s[j] - bound) * 1.44269504088896340736f);
       sum += p[j];
     }
     incl = wave_incl_scan(sum, lane);
@@ -180,21 +181,29 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
   // per lane: c0' = (c0 + log count) log2e (or -inf beyond K), c1 ln2 log2e = c1, c1' = c1 log2e, and
   // the prior of an empty group enters as emp * e with emp = log2e there and 0 elsewhere.
   constexpr float kLog2e = 1.44269504088896340736f;
-  float c0s[G], c1s[G], emp[G];
+  // ... and so is everything else that does not depend on the row: an empty group's prior log(alpha / n_empty) (when
+  // that is -inf no group is empty and the value is never used), and minus the wave-uniform bound that stands in for
+  // the row maximum in the draw, so that a row's unnormalised probability is exp2(score) with nothing in between.
+  // A row that is its group's only member leaves one more empty group behind: every empty group's prior moves by
+  // dle = log2(n_empty / (n_empty + 1)) for that row (wave-uniform side path, rare).
+  const bool any_empty = !__builtin_isinf(le0);
+  const float dle = any_empty ? (le1 - le0) * kLog2e : 0.f;
+  float c0s[G], c1s[G];
+  unsigned emask = 0u;                                  // bit j: group kb + j is empty
+  float bound = -INFINITY;
 #pragma unroll
   for (int j = 0; j < G; j++) {
     const bool empty = __builtin_isinf(lc[j]);
-    c0s[j] = (kb + j >= K) ? -INFINITY : (c0[j] + (empty ? 0.f : lc[j])) * kLog2e;
+    if (empty && kb + j < K) emask |= 1u << j;
+    c0s[j] = (kb + j >= K) ? -INFINITY : (c0[j] + (empty ? le0 : lc[j])) * kLog2e;
     c1s[j] = c1[j] * kLog2e;
-    emp[j] = empty ? kLog2e : 0.f;
+    if (kb + j < K) bound = fmaxf(bound, c0s[j]);
   }
-  // no score exceeds its c0' (log1p >= 0) plus what the empty-group prior can add; the own group's leave-one-out
-  // value and a masked row's prior-only scores may, by a little: 16 bits of headroom, and sample_from_scores checks
-  float bound = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < G; j++)
-    if (kb + j < K) bound = fmaxf(bound, c0s[j] + emp[j] * fmaxf(0.f, fmaxf(__builtin_isinf(le0) ? 0.f : le0, le1)));
+  // no score exceeds its c0' (log1p >= 0); the own group's leave-one-out value, a masked row's prior-only scores and a
+  // singleton row's empty groups may, by a little: 16 bits of headroom, and sample_from_scores checks
   bound = wave_max(bound) + 16.f;
+#pragma unroll
+  for (int j = 0; j < G; j++) c0s[j] -= bound;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
   // a wave takes chunk_rows (<= 64) rows at a time, one per lane for the per-row setup, then scores them one after
   // the other: the rows of a chunk are a serial chain, so few rows want short chunks spread over many waves
@@ -210,40 +219,45 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     const unsigned long long mbits =
         __builtin_amdgcn_ballot_w64(fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0);
-    float sloo = 0.f, erow = le0;
+    float sloo = 0.f;
+    bool single = false;
     if (gz >= 0) {
       // leave-one-out score + prior of the row's own group, in double (what k_loo_own does for the other
       // kernels; here every lane has a row of its own, so it costs ~2 % on top of the 64 x K evaluations)
       const float lm1 = crp[kpad + gz];
-      const bool empties = __builtin_isinf(lm1);              // the row is its group's only member
-      erow = empties ? le1 : le0;
-      double s = empties ? (double)le1 : (double)lm1;
+      single = __builtin_isinf(lm1);                          // the row is its group's only member
+      double s = single ? (double)le1 + (double)crp[2 * (size_t)kpad + 3] : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + gz];
       if (!((mbits >> lane) & 1ull))
         s += nich_loo_tab(fd.hp, fd.loo64 + gz, kpad, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
-      sloo = (float)s * kLog2e;
+      sloo = (float)s * kLog2e - bound;
     }
+    // rows that leave the straight path: masked ones, and singletons while other groups are empty
+    const unsigned long long singles = any_empty ? __builtin_amdgcn_ballot_w64(single) : 0ull;
+    const unsigned long long odd = mbits | singles;
     int znew = gz;
     for (int r = 0; r < nr; r++) {
-      const float x = lane_bcast(xv, r), e_raw = lane_bcast(erow, r), sl = lane_bcast(sloo, r);
-      // log(alpha / n_empty) is -inf when no group is empty; then no emp[j] is set either, and 0 * inf must not happen
-      const float e = __builtin_isinf(e_raw) ? 0.f : e_raw;
+      const float x = lane_bcast(xv, r), sl = lane_bcast(sloo, r);
       const int g = lane_bcast(gz, r);
       float s[G];
-      if ((mbits >> r) & 1ull) {                          // masked value: only the prior speaks
 #pragma unroll
-        for (int j = 0; j < G; j++)
-          s[j] = (kb + j >= K) ? -INFINITY : (__builtin_isinf(lc[j]) ? e_raw : lc[j]) * kLog2e;
-      } else {
+      for (int j = 0; j < G; j++) s[j] = nich_eval(x, mh[j], ml[j], c0s[j], c1[j], c1s[j], c2[j]);
+      if ((odd >> r) & 1ull) {                            // (wave-uniform, rare)
+        if ((mbits >> r) & 1ull) {                        // masked value: only the prior speaks
+          const float e_raw = ((singles >> r) & 1ull) ? le1 : le0;
 #pragma unroll
-        for (int j = 0; j < G; j++)
-          s[j] = fmaf(emp[j], e, nich_eval(x, mh[j], ml[j], c0s[j], c1[j], c1s[j], c2[j]));
+          for (int j = 0; j < G; j++)
+            s[j] = (kb + j >= K) ? -INFINITY : (__builtin_isinf(lc[j]) ? e_raw : lc[j]) * kLog2e - bound;
+        } else {                                          // one more empty group shares alpha for this row
+#pragma unroll
+          for (int j = 0; j < G; j++) s[j] += ((emask >> j) & 1u) ? dle : 0.f;
+        }
       }
       if (g >= 0 && lane == g / G) {                       // the own group: its leave-one-out value
 #pragma unroll
         for (int j = 0; j < G; j++)
           if (j == g % G) s[j] = sl;
       }
-      const int pick = sample_from_scores<G, true, true>(s, lane_bcast(u01, r), lane, K, bound);
+      const int pick = sample_from_scores<G, true, true, true>(s, lane_bcast(u01, r), lane, K);
       if (lane == r) znew = pick;
     }
     if (has_row) z[rb + lane] = znew;
@@ -276,8 +290,8 @@ __global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__
 #pragma unroll
     for (int i = 0; i < D; i++) {
 #pragma unroll
-      for (int j = 0; j <= i; j++) w[t][i * (i + 1) / 2 + j] = fd.niw_w64[(kc * kNiwPad + i) * kNiwPad + j];
-      nb[t][i] = -fd.niw_mu64[kc * kNiwPad + (i & 3) * 8 + (i >> 2)];
+      for (int j = 0; j <= i; j++) w[t][i * (i + 1) / 2 + j] = fd.niw_w64[kc * niw_w_stream(D) + niw_w_index(i, j)];
+      nb[t][i] = -fd.niw_mu64[kc * niw_b_stream(D) + niw_b_index(i)];
     }
     c0[t] = fd.tab[(size_t)NIW_C0 * kpad + kc];
     c1[t] = fd.tab[(size_t)NIW_C1 * kpad + kc];

@@ -92,10 +92,11 @@ struct FeatDesc {
   float *raw_f32;
   long long *acc_i64;
   double *acc_f64;
-  float *niw_w;            // niw only: [K][d][d] whitening matrix (row-major), scaled
-  float *niw_b;            // niw only: [K][2][32] posterior mean, hi | lo floats
-  double *niw_w64;         // niw only: the same whitening matrix, unrounded
-  double *niw_mu64;        // niw only: [K][32] posterior mean
+  float *niw_w;            // niw, dim <= 32 only (the f32 MFMA kernel): [K][32][32] whitening matrix (row-major), scaled
+  float *niw_b;            // niw, dim <= 32 only: [K][2][32] posterior mean, hi | lo floats
+  double *niw_w64;         // niw: W_k = L^-1 sqrt(kn/(kn+1)) as the operand stream of the f64 MFMA kernel,
+                           //      [K][niw_w_stream(dim)] (niw_w_index; kernels_niw.hip)
+  double *niw_mu64;        // niw: W_k mu_k in the accumulator layout of that kernel, [K][niw_b_stream(dim)] (niw_b_index)
   double *niw_c64;         // niw only: [K][8] {c0, c1, A_loo, B_loo, C_loo}
   double aux;              // dd: sum of the alphas
   uint32_t vcap;           // gp, bnb: rows of the exact table (min(column max + 1, kGpMaxTable))
@@ -200,7 +201,27 @@ size_t primitive_size(int t);
 // rows of a niw feature's float table (k_niw_prepare fills them) and the padded width of its W matrices
 enum { NIW_C0 = 0, NIW_C1 = 1, NIW_A_LOO = 2, NIW_B_LOO = 3, NIW_C_LOO = 4, NIW_LOGDET_HI = 5, NIW_LOGDET_LO = 6,
        NIW_ROWS = 7 };   // row NIW_ROWS holds the prior's ln det Psi (hi, lo) in its first two slots
-constexpr int kNiwPad = 32;
+constexpr int kNiwPad = 32;                 // the f32 kernel's padded matrix width (dim <= 32)
+constexpr unsigned kMaxNiwDim = 128;        // what the prepare kernel's packed LDS triangles hold (2 x 66 KB)
+
+// The f64 contraction works on 16-blocks: component block b (rows 16b .. 16b+15 of the lower-triangular W) meets
+// feature blocks s4 = 0 .. b only.  A chunk = one (b, s4) pair = four MFMA steps; step e of the chunk contracts
+// features 16 s4 + 4 e + kk (kk = lane / 16).  Per group the chunks are stored in the order the kernel walks them,
+// 64 lanes x 4 doubles each, so a chunk is one coalesced 2 KiB read per wave.
+__host__ __device__ inline uint32_t niw_blocks(uint32_t d) { return (d + 15u) / 16u; }
+__host__ __device__ inline uint32_t niw_chunks(uint32_t d) { return niw_blocks(d) * (niw_blocks(d) + 1u) / 2u; }
+__host__ __device__ inline size_t niw_w_stream(uint32_t d) { return (size_t)niw_chunks(d) * 256u; }   // doubles per group
+__host__ __device__ inline size_t niw_b_stream(uint32_t d) { return (size_t)niw_blocks(d) * 256u; }
+// where W[i][j] (j <= i) sits in a group's stream: lane (c = i % 16, kk = j % 4), slot e = (j % 16) / 4 of chunk (i / 16, j / 16)
+__host__ __device__ inline size_t niw_w_index(uint32_t i, uint32_t j) {
+  const uint32_t b = i >> 4, s4 = j >> 4;
+  return (size_t)(b * (b + 1u) / 2u + s4) * 256u + (size_t)((i & 15u) + 16u * (j & 3u)) * 4u + ((j & 15u) >> 2);
+}
+// where (W mu)[i] sits: accumulator register r = (i % 16) / 4 of the lanes with kk = i % 4 (every c holds the same value;
+// this is the c = 0 copy)
+__host__ __device__ inline size_t niw_b_index(uint32_t i) {
+  return (size_t)(i >> 4) * 256u + (size_t)(16u * (i & 3u)) * 4u + ((i & 15u) >> 2);
+}
 
 }  // namespace msc
 

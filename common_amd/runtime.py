@@ -102,6 +102,19 @@ class Context(object):
                                              C.byref(score)))
         return float(score.value)
 
+    def alloc_probed(self, shape, dtype=torch.float32, candidates=8):
+        """A zero-filled device tensor in the best-placed of `candidates` allocations (msc_device_alloc_probed; the
+        write stream of a large score matrix runs 5.6 or 7.0 TB/s depending on where the driver put it).
+        -> (tensor, [GB/s of every candidate], index kept).  The tensor owns the buffer (freed with it)."""
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        p, rates, chosen = C.c_void_p(), (C.c_float * candidates)(), C.c_uint32()
+        L.check(self.lib.msc_device_alloc_probed(self._h, nbytes, candidates, C.byref(p), rates, C.byref(chosen)))
+        t = _alias_tensor(p.value, n, dtype, self.torch_device, owner=_DeviceBuffer(self, p.value)).reshape(*shape)
+        return t, [float(r) for r in rates], int(chosen.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.msc_context_destroy(self._h)
@@ -416,18 +429,34 @@ class State(object):
             pass
 
 
+class _DeviceBuffer(object):
+    """owner of a msc_device_alloc* buffer: freed when the last tensor aliasing it is gone"""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self.ptr and getattr(self.ctx, "_h", None):
+                self.ctx.lib.msc_device_free(self.ctx._h, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
 class _CudaArrayView(object):
-    def __init__(self, ptr, n, typestr):
+    def __init__(self, ptr, n, typestr, owner=None):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
                                          "version": 2, "strides": None}
+        self._owner = owner          # (torch keeps this object alive as long as the tensor's storage)
 
 
-def _alias_tensor(ptr, n, dtype, device):
+def _alias_tensor(ptr, n, dtype, device, owner=None):
     if n == 0:
         return torch.empty(0, dtype=dtype, device=device)
     typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4",
                torch.int32: "<i4"}[dtype]
-    return torch.as_tensor(_CudaArrayView(ptr, n, typestr), device=device)
+    return torch.as_tensor(_CudaArrayView(ptr, n, typestr, owner), device=device)
 
 
 class RelationView(object):

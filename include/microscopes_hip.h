@@ -70,7 +70,7 @@ typedef struct msc_runtime_type {
 
 typedef struct msc_feature_spec {
   int32_t family; /* msc_family */
-  uint32_t dim;   /* dd: number of categories (<=128); niw: dimension; dm: categories (<=128); else 0 */
+  uint32_t dim;   /* dd: number of categories (<=128); niw: dimension (<=128); dm: categories (<=128); else 0 */
 } msc_feature_spec;
 
 typedef struct msc_context msc_context;
@@ -94,6 +94,16 @@ int msc_context_synchronize(msc_context *ctx);
  * the context's stream and complete before they return.
  */
 int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out_dev);
+/*
+ * A large, long-lived output buffer (the [N, K] score matrix) placed where the write stream runs fastest: the same
+ * 1 GB stream takes 5.6 TB/s into most allocations and 7.0 TB/s into some, decided by where the driver put the pages
+ * (profiles/r02_placement_study.txt), and no allocator argument selects that.  Up to `candidates` buffers are
+ * allocated side by side, each is stream-filled a few times on the context's stream, the fastest is returned and the
+ * rest are freed.  SYNCHRONOUS (about 1 ms per candidate and GB).  rates_gbps (nullable, `candidates` floats) receives
+ * every candidate's fill rate, *chosen (nullable) the index kept.  Free with msc_device_free.
+ */
+int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out_dev,
+                            float *rates_gbps, uint32_t *chosen);
 int msc_device_free(msc_context *ctx, void *dev);
 int msc_device_upload(msc_context *ctx, void *dst_dev, const void *src_host, size_t nbytes);
 int msc_device_download(msc_context *ctx, void *dst_host, const void *src_dev, size_t nbytes);
@@ -179,7 +189,8 @@ int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, uint32_t ng
 
 /* ---- the hot path ------------------------------------------------------ */
 #define MSC_SCORE_CRP_PRIOR 0x1u /* add log(pseudocount(gid)), group_manager.hpp:274-283 */
-#define MSC_SCORE_NIW_F32 0x2u   /* niw Mahalanobis on the f32 matrix pipe: 2x the rate, ~1e-5 instead of 1e-6 */
+#define MSC_SCORE_NIW_F32 0x2u   /* niw (dim <= 32) Mahalanobis on the f32 matrix pipe: 2x the rate, ~1e-5 instead of 1e-6;
+                                    ignored for wider features */
 
 /*
  * score_value for nrows rows x all groups x all features of the state:

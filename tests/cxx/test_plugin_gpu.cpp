@@ -133,8 +133,7 @@ static void test_dd_and_niw() {
     const int v0 = 2;
     CHECK(g2->score_value(*h, value_accessor(&v0), r) == g->score_value(*h, value_accessor(&v0), r));
   }
-  {
-    const unsigned d = 4;
+  for (const unsigned d : {4u, 40u, 128u}) {     // NormalInverseWishart<-1>: the dimension is a run-time value (distributions.hpp:87-91)
     models::distributions_model_niwv m(d);
     CHECK(m.get_runtime_type() == runtime_type(TYPE_F32, d));
     auto h = m.create_hypers();     // default hp: mu = 0, kappa = 1, psi = I, nu = d
@@ -147,7 +146,7 @@ static void test_dd_and_niw() {
     std::normal_distribution<float> nd(1.f, 2.f);
     const runtime_type vt(TYPE_F32, d);
     std::vector<std::vector<float>> xs;
-    for (int i = 0; i < 15; i++) {
+    for (int i = 0; i < (d > 32 ? 6 : 15); i++) {
       xs.emplace_back(d);
       for (auto &x : xs.back()) x = nd(r);
       g->add_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(xs.back().data()), nullptr, vt), r);

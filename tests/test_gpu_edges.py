@@ -107,7 +107,7 @@ def test_bad_arguments_are_refused_with_a_message(gpu_ctx):
     with pytest.raises(MicroscopesHipError):
         common_amd.State(gpu_ctx, [(orc.DD, 0)], 3)              # dd needs 1..128 categories
     with pytest.raises(MicroscopesHipError):
-        common_amd.State(gpu_ctx, [(orc.NIW, 33)], 3)            # one 32x32 tile
+        common_amd.State(gpu_ctx, [(orc.NIW, 129)], 3)           # the prepare kernel's LDS triangles hold 128
     with pytest.raises(MicroscopesHipError):
         common_amd.State(gpu_ctx, [(99, 0)], 3)                  # unknown family
     with pytest.raises(MicroscopesHipError):
@@ -120,3 +120,24 @@ def test_bad_arguments_are_refused_with_a_message(gpu_ctx):
     st2 = common_amd.State(gpu_ctx, [(orc.NICH, 0), (orc.BB, 0)], 2)
     with pytest.raises(MicroscopesHipError):
         st2.score_value(view)                                    # the view has one column, the state two features
+
+
+def test_probed_allocation_is_zero_filled_usable_and_outlives_its_handle(gpu_ctx):
+    """msc_device_alloc_probed: the best-placed of a few candidate buffers, as a tensor that owns it"""
+    import gc
+    import common_amd
+    t, rates, kept = gpu_ctx.alloc_probed((4096, 256), torch.float32, candidates=3)
+    assert t.shape == (4096, 256) and t.dtype == torch.float32 and len(rates) == 3 and 0 <= kept < 3
+    assert all(r > 0 for r in rates) and rates[kept] == max(rates)
+    assert float(t.abs().sum()) == 0.0
+    x = torch.randn(4096, device=gpu_ctx.torch_device)
+    view = common_amd.DataView.from_tensors(gpu_ctx, [x])
+    st = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], 256)
+    st.score_value(view, out=t)
+    want = st.score_value(view)
+    assert torch.equal(t, want)
+    keep = t[5].clone()
+    gc.collect()
+    assert torch.equal(t[5], keep)                      # the owner rides on the tensor's storage
+    with pytest.raises(common_amd.MicroscopesHipError):
+        gpu_ctx.alloc_probed((4,), torch.float32, candidates=0)

@@ -9,7 +9,7 @@ from tests.gpu_helpers import (TOL, load_state, make_feature, recarray_of, rel_e
 
 pytestmark = pytest.mark.gpu
 
-SPECS = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0), (orc.NIW, 4), (orc.NIW, 32)]
+SPECS = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.DD, 128), (orc.NICH, 0), (orc.NIW, 4), (orc.NIW, 32), (orc.NIW, 45)]
 
 
 def _check_ss(st, fs, int_exact=True):
