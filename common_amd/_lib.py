@@ -79,6 +79,7 @@ _SIGS = {
                                  C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "msc_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                  C.c_void_p, C.c_uint32]),
+    "msc_entity_op": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]),
     "msc_score_data": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_sweep_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
@@ -92,6 +93,8 @@ _SIGS = {
     "msc_state_commit_reduce": (C.c_int, [C.c_void_p]),
     "msc_value_op_single": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "msc_relation_slice_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64]),
     "msc_relation_blocks": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p]),
 }

@@ -1233,6 +1233,41 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
   return accumulate_impl(st, view, cols, row0, nrows, z_dev, flags);
 }
 
+extern "C" int msc_entity_op(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row, uint32_t group,
+                             int sign, int32_t *z_dev) {
+  MSC_REQUIRE(st && view, "null argument");
+  MSC_REQUIRE(sign != 0, "sign must be +1 (join) or -1 (leave)");
+  MSC_REQUIRE(group < st->K, "group %u outside [0,%u)", group, st->K);
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(bind_view(st, view, cols, row, 1));
+  hipStream_t s = st->ctx->stream;
+  bool scalar_only = true;
+  for (const auto &h : st->feats) scalar_only &= h.family != MSC_NIW && h.family != MSC_DM;
+  if (!scalar_only) {
+    // general path: the group travels through a one-entry assignment vector of the state's own
+    if (!st->one_z) MSC_TRY(dev_alloc(st->owned, &st->one_z, 1));
+    if (launch_set_i32(s, st->one_z, (int32_t)group)) return fail(MSC_EHIP, "k_set_i32 launch failed");
+    MSC_TRY(accumulate_impl(st, view, cols, row, 1, st->one_z, sign < 0 ? (uint32_t)MSC_ACC_SUBTRACT : 0u));
+    if (z_dev && launch_set_i32(s, z_dev + row, sign > 0 ? (int32_t)group : -1)) return fail(MSC_EHIP, "k_set_i32 launch failed");
+    return MSC_OK;
+  }
+  // every table current before, every table current after
+  MSC_TRY(ensure_raw(st));
+  for (uint32_t f = 0; f < st->nfeat; f++)
+    if (!st->feats[f].additive_valid && launch_lift(s, st->desc_dev + f, 1, st->kpad, st->red_i64, st->cnt_u32, 0))
+      return fail(MSC_EHIP, "k_lift launch failed");
+  if (!st->cnt_additive_valid && launch_lift(s, st->desc_dev, 0, st->kpad, st->red_i64, st->cnt_u32, 1))
+    return fail(MSC_EHIP, "k_lift launch failed");
+  for (auto &h : st->feats) h.additive_valid = true;
+  st->cnt_additive_valid = true;
+  MSC_TRY(ensure_derived(st));
+  MSC_TRY(ensure_crp(st));
+  if (launch_entity_op(s, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row, group, sign > 0 ? 1 : -1, st->red_i64, st->cnt_u32,
+                       st->alpha, st->logpc, z_dev ? z_dev + row : nullptr))
+    return fail(MSC_EHIP, "k_entity_op launch failed");
+  return MSC_OK;
+}
+
 extern "C" int msc_score_data(msc_state *st, float *out_dev) {
   MSC_REQUIRE(st && out_dev, "null argument");
   MSC_HIP(hipSetDevice(st->ctx->device));
@@ -1533,6 +1568,28 @@ extern "C" int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64
   MSC_HIP(hipSetDevice(ctx->device));
   if (launch_relation_blocks(ctx->stream, ndim, shape, z_dev, ngroups, positions_dev, ncells, z_cell_dev))
     return fail(MSC_EHIP, "k_relation_blocks launch failed");
+  return MSC_OK;
+}
+
+extern "C" int msc_relation_slice_scores(msc_context *ctx, const float *scores_dev, uint64_t ld, uint32_t ndim,
+                                         const uint64_t *shape, uint32_t dim, const uint32_t *seg_dev,
+                                         const uint32_t *ids_dev, const int32_t *off_dev, uint32_t ncand,
+                                         uint32_t cand_stride, uint64_t nent, float *out_dev, uint64_t ld_out) {
+  MSC_REQUIRE(ctx && shape && off_dev, "null argument");
+  MSC_REQUIRE(ndim >= 1 && ndim <= 8 && dim < ndim, "dimension %u of a %u-dimensional relation", dim, ndim);
+  MSC_REQUIRE((seg_dev == nullptr) == (ids_dev == nullptr), "seg_dev and ids_dev come together (sparse) or not at all (dense)");
+  MSC_REQUIRE(nent == 0 || ncand == 0 || (scores_dev && out_dev), "null scores / output");
+  MSC_REQUIRE(ld_out >= ncand, "ld_out %llu < candidates %u", (unsigned long long)ld_out, ncand);
+  MSC_REQUIRE(ncand == 0 || (uint64_t)(ncand - 1) * cand_stride < ld, "candidate %u x stride %u runs past the score row (%llu)",
+              ncand, cand_stride, (unsigned long long)ld);
+  for (uint32_t d = 0; d < ndim; d++) MSC_REQUIRE(shape[d] > 0, "dimension %u is empty", d);
+  MSC_REQUIRE(seg_dev != nullptr || nent <= shape[dim], "%llu entities on a dimension of %llu", (unsigned long long)nent,
+              (unsigned long long)shape[dim]);
+  MSC_REQUIRE(nent < (1ull << 31), "too many entities for one launch");
+  MSC_HIP(hipSetDevice(ctx->device));
+  if (launch_relation_slice_scores(ctx->stream, scores_dev, ld, ndim, shape, dim, seg_dev, ids_dev, off_dev, ncand, cand_stride,
+                                   nent, out_dev, ld_out))
+    return fail(MSC_EHIP, "k_relation_slice_scores launch failed");
   return MSC_OK;
 }
 

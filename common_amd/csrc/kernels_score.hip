@@ -182,6 +182,66 @@ __global__ __launch_bounds__(256) void k_commit_prepare(const FeatDesc *__restri
 }
 
 // ---------------------------------------------------------------------------
+// One entity joins (sign > 0) or leaves (sign < 0) one group, the group given by value: group_manager::add_value /
+// remove_value plus the component models' add_value / remove_value for that row (entity_state.hpp:57-68), with every
+// table left current -- the additive sums, the reference's fields and the score constants of that one (feature, group),
+// the group sizes and the CRP terms -- in ONE launch (the per-entity Gibbs move of hip::mixture_state was a 4-byte
+// upload, accumulate, commit, and a prepare pass over all groups at the next score: three stream synchronisations).
+// Block f < nfeat: feature f (its count / categorical table rows dealt out over the block); block nfeat: the counts.
+// Scalar families only (niw and dm have prepare kernels of their own: the host takes the general path for them).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_entity_op(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad,
+                                                    uint64_t row, uint32_t g, int sign, long long *__restrict__ cnt_acc,
+                                                    uint32_t *__restrict__ cnt_u32, float alpha, float *__restrict__ crp,
+                                                    int32_t *__restrict__ z_slot) {
+  const long long sgn = sign;
+  if ((int)blockIdx.x == nfeat) {
+    if (threadIdx.x == 0) {
+      cnt_acc[g] += sgn;
+      cnt_u32[g] = (uint32_t)cnt_acc[g];
+      if (z_slot != nullptr) *z_slot = sign > 0 ? (int32_t)g : -1;
+    }
+    __syncthreads();
+    crp_prepare_block(cnt_u32, K, kpad, alpha, crp);
+    return;
+  }
+  const FeatDesc fd = feats[blockIdx.x];
+  if (threadIdx.x == 0 && fd.col != nullptr && !load_masked(fd, row, true)) {
+    switch (fd.family) {
+      case MSC_BBNC:
+      case MSC_BB:
+        fd.acc_i64[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 0 : kpad) + g] += sgn;
+        break;
+      case MSC_GP: {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+        fd.acc_i64[g] += sgn;
+        fd.acc_i64[kpad + g] += sgn * (long long)v;
+        fd.acc_f64[g] += (double)sign * log_factorial(v);
+      } break;
+      case MSC_BNB: {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+        fd.acc_i64[g] += sgn;
+        fd.acc_i64[kpad + g] += sgn * (long long)v;
+      } break;
+      case MSC_DD: {
+        const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+        if (v >= 0 && v < (int)fd.dim) fd.acc_i64[(size_t)v * kpad + g] += sgn;
+      } break;
+      case MSC_NICH: {
+        const double x = reinterpret_cast<const float *>(fd.col)[row];
+        fd.acc_i64[g] += sgn;
+        fd.acc_f64[g] += (double)sign * x;
+        fd.acc_f64[kpad + g] += (double)sign * x * x;
+      } break;
+      default: break;
+    }
+    commit_group(fd, g, kpad);
+  }
+  __syncthreads();                                     // (the group's fields are written; every thread prepares from them)
+  prepare_group(fd, g, kpad, threadIdx.x, 256);
+}
+
+// ---------------------------------------------------------------------------
 // leave-one-out pre-pass: own[n] = (prior of z[n] with the row removed, if crp) +
 // sum over scalar features of score_value(group z[n] minus row n, row n).  One thread per row,
 // everything in double; niw features add theirs inside the niw kernel.
@@ -516,6 +576,13 @@ int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfe
 
 int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad, uint32_t value_slices) {
   hipLaunchKernelGGL(k_dm_prepare, dim3((kpad + 255) / 256, dim + 1, value_slices ? value_slices : 1), dim3(256), 0, stream, feats_dev, f, kpad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_entity_op(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row,
+                     uint32_t group, int sign, long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, int32_t *z_slot) {
+  hipLaunchKernelGGL(k_entity_op, dim3((unsigned)nfeat + 1), dim3(256), 0, stream, feats_dev, nfeat, K, kpad, row, group, sign,
+                     cnt_acc, cnt_u32, alpha, crp, z_slot);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -436,9 +436,65 @@ __global__ __launch_bounds__(256) void k_relation_blocks(RelArgs a, const uint32
   out[c] = ok ? (int32_t)block : -1;
 }
 
+// irm's slice reduction: out[e][g] = sum over the cells c of slice (dim, e) of scores[c][g * cand_stride + off[c]] --
+// "entity e joins cluster g of its domain": every cell of its slice then lies in block (g, clusters of the cell's
+// other entities), whose index is g * cand_stride + off[c]; off[c] < 0 (an entity of the cell is unassigned) skips the
+// cell, a masked cell scored 0 already.  One workgroup per entity; the four waves split the slice's cells, lane <->
+// candidate (64 at a time), sums in double in a fixed order (bit-reproducible), one LDS pass to combine the waves.
+// Dense relations enumerate the slice analytically (relation/dataview.hpp:265-407: the other dimensions in row-major
+// order); a sparse one passes its rows as CSR (seg, ids).
+struct SliceArgs {
+  uint64_t slice_cells, inner, extent;     // dense: cells per slice, product of the dimensions after `dim`, shape[dim]
+  const uint32_t *seg, *ids;               // sparse: cells of entity e are ids[seg[e] .. seg[e + 1])
+};
+__global__ __launch_bounds__(256) void k_relation_slice_scores(const float *__restrict__ scores, uint64_t ld, SliceArgs a,
+                                                                const int32_t *__restrict__ off, uint32_t ncand,
+                                                                uint32_t cand_stride, float *__restrict__ out, uint64_t ld_out) {
+  __shared__ double part[4][64];
+  const uint64_t e = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t beg = a.seg != nullptr ? a.seg[e] : 0, n = a.seg != nullptr ? a.seg[e + 1] - beg : a.slice_cells;
+  for (uint32_t g0 = 0; g0 < ncand; g0 += 64) {
+    const uint32_t g = g0 + lane;
+    double acc = 0.0;
+    for (uint64_t m = wave; m < n; m += 4) {
+      uint64_t c;
+      if (a.ids != nullptr) c = a.ids[beg + m];
+      else c = ((m / a.inner) * a.extent + e) * a.inner + m % a.inner;
+      const int o = off[c];                                  // (wave-uniform)
+      if (o < 0) continue;
+      if (g < ncand) acc += (double)scores[c * ld + (uint64_t)g * cand_stride + (uint32_t)o];
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && g < ncand) out[e * ld_out + g] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int launch_relation_slice_scores(hipStream_t stream, const float *scores, uint64_t ld, uint32_t ndim, const uint64_t *shape,
+                                 uint32_t dim, const uint32_t *seg_dev, const uint32_t *ids_dev, const int32_t *off_dev,
+                                 uint32_t ncand, uint32_t cand_stride, uint64_t nent, float *out_dev, uint64_t ld_out) {
+  if (nent == 0 || ncand == 0) return 0;
+  SliceArgs a;
+  a.seg = seg_dev;
+  a.ids = ids_dev;
+  a.inner = 1;
+  a.extent = shape[dim];
+  uint64_t total = 1;
+  for (uint32_t d = 0; d < ndim; d++) {
+    total *= shape[d];
+    if (d > dim) a.inner *= shape[d];
+  }
+  a.slice_cells = total / shape[dim];
+  hipLaunchKernelGGL(k_relation_slice_scores, dim3((unsigned)nent), dim3(256), 0, stream, scores, ld, a, off_dev, ncand, cand_stride,
+                     out_dev, ld_out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_relation_blocks(hipStream_t stream, uint32_t ndim, const uint64_t *shape, const int32_t *const *z_dev,
                            const uint32_t *ngroups, const uint32_t *positions_dev, uint64_t ncells, int32_t *out_dev) {
   if (ncells == 0) return 0;
@@ -557,6 +613,12 @@ int launch_stream_fill(hipStream_t stream, int num_cus, void *buf, size_t nbytes
   if (nrows == 0) return 0;
   const size_t nslots = (nrows / 4 + 1) / 2 ? (nrows / 4 + 1) / 2 : 1;
   hipLaunchKernelGGL(k_stream_fill, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, stream, static_cast<float4 *>(buf), nrows, nslots);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+__global__ void k_set_i32(int32_t *dst, int32_t value) { *dst = value; }
+int launch_set_i32(hipStream_t stream, int32_t *dst, int32_t value) {
+  hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, stream, dst, value);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

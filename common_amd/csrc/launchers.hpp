@@ -38,6 +38,9 @@ int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat
 int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad, uint32_t value_slices);
 int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint32_t kpad, float alpha,
                        float *crp);
+int launch_entity_op(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row,
+                     uint32_t group, int sign, long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, int32_t *z_slot);
+int launch_set_i32(hipStream_t stream, int32_t *dst, int32_t value);
 int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
 int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
@@ -111,6 +114,9 @@ int launch_score_data(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, 
                       uint32_t kpad, float *out);
 int launch_relation_blocks(hipStream_t stream, uint32_t ndim, const uint64_t *shape, const int32_t *const *z_dev,
                            const uint32_t *ngroups, const uint32_t *positions_dev, uint64_t ncells, int32_t *out_dev);
+int launch_relation_slice_scores(hipStream_t stream, const float *scores, uint64_t ld, uint32_t ndim, const uint64_t *shape,
+                                 uint32_t dim, const uint32_t *seg_dev, const uint32_t *ids_dev, const int32_t *off_dev,
+                                 uint32_t ncand, uint32_t cand_stride, uint64_t nent, float *out_dev, uint64_t ld_out);
 int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint32_t *colmax_dev,
                     uint32_t *rowtot_dev);
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);

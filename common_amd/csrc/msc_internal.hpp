@@ -328,6 +328,7 @@ struct msc_state {
   } step_graph;
   double *niw_qown = nullptr;        // q of every row's own group (niw leave-one-out), [niw_qown_cap]
   size_t niw_qown_cap = 0;
+  int32_t *one_z = nullptr;          // a one-entry assignment vector (msc_entity_op's general path)
   uint32_t *niw_scratch = nullptr;   // row bucketing for niw accumulate: 2 K + 1 + rows uint32
   size_t niw_scratch_len = 0;
 };

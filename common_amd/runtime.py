@@ -368,6 +368,15 @@ class State(object):
         L.check(self.ctx.lib.msc_accumulate(self._h, view._h, self._cols(cols), row0, n,
                                             C.c_void_p(z.data_ptr()), flags))
 
+    def entity_op(self, view, row, group, join=True, z=None, cols=None):
+        """one entity joins / leaves one group, the group by value (msc_entity_op): every table stays current"""
+        zp = None
+        if z is not None:
+            if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] <= row:
+                raise ValueError("z must be a contiguous int32 tensor covering the row")
+            zp = C.c_void_p(z.data_ptr())
+        L.check(self.ctx.lib.msc_entity_op(self._h, view._h, self._cols(cols), int(row), int(group), 1 if join else -1, zp))
+
     def score_data(self, out=None):
         if out is None:
             out = torch.empty((len(self.features), self.K), dtype=torch.float32, device=self.ctx.torch_device)
@@ -492,4 +501,30 @@ class RelationView(object):
         kg = (C.c_uint32 * nd)(*[int(k) for k in ngroups])
         L.check(self.ctx.lib.msc_relation_blocks(self.ctx._h, nd, shape, zp, kg, None, self.cells.nrows,
                                                  C.c_void_p(out.data_ptr())))
+        return out
+
+    def slice_offsets(self, zs, ngroups, dim):
+        """block index of every cell with dimension `dim`'s cluster taken as 0 (-1 where another entity of the cell is
+        unassigned): the `off` of slice_scores.  zs[dim] is ignored."""
+        zs = list(zs)
+        zs[dim] = torch.zeros(self.shape[dim], dtype=torch.int32, device=self.ctx.torch_device)
+        return self.blocks(zs, ngroups)
+
+    def slice_scores(self, scores, off, dim, ngroups):
+        """irm's slice reduction (msc_relation_slice_scores): out[e, g] = sum over the cells of slice (dim, e) of the
+        cell's score against block (g, the cell's other clusters).  scores: [ncells, >= prod(ngroups)] from
+        State.score_value on self.cells; off: slice_offsets(...).  -> float32 [shape[dim], ngroups[dim]]"""
+        nd = len(self.shape)
+        if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1 or scores.shape[0] != self.cells.nrows:
+            raise ValueError("scores must be a row-major float32 [ncells, nblocks] tensor")
+        if off.dtype != torch.int32 or off.numel() != self.cells.nrows or not off.is_contiguous():
+            raise ValueError("off must be a contiguous int32 tensor of ncells entries")
+        stride = 1
+        for k in ngroups[dim + 1:]:
+            stride *= int(k)
+        out = torch.empty((self.shape[dim], int(ngroups[dim])), dtype=torch.float32, device=self.ctx.torch_device)
+        shape = (C.c_uint64 * nd)(*self.shape)
+        L.check(self.ctx.lib.msc_relation_slice_scores(self.ctx._h, C.c_void_p(scores.data_ptr()), scores.stride(0), nd, shape, dim,
+                                                       None, None, C.c_void_p(off.data_ptr()), int(ngroups[dim]), stride,
+                                                       self.shape[dim], C.c_void_p(out.data_ptr()), out.stride(0)))
         return out

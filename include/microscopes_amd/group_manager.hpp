@@ -247,5 +247,47 @@ protected:
   std::map<std::size_t, gd<T>> groups_;
 };
 
+// Manages groups and nothing else (group_manager.hpp:320-386): ids are handed out in increasing order and never
+// reused, O(log N) create / delete / lookup, iteration in id order.
+template <typename T>
+class simple_group_manager {
+public:
+  typedef typename std::map<std::size_t, T>::const_iterator const_iterator;
+
+  simple_group_manager() = default;
+  std::size_t ngroups() const { return groups_.size(); }
+  std::vector<std::size_t> groups() const {
+    std::vector<std::size_t> ret;
+    ret.reserve(groups_.size());
+    for (const auto &g : groups_) ret.push_back(g.first);
+    return ret;
+  }
+  std::pair<std::size_t, T &> create_group() {
+    const std::size_t gid = gcount_++;
+    return std::pair<std::size_t, T &>(gid, groups_[gid]);
+  }
+  void delete_group(std::size_t gid) {
+    const auto it = groups_.find(gid);
+    if (it == groups_.end()) throw std::runtime_error("invalid gid");
+    groups_.erase(it);
+  }
+  const T &group(std::size_t gid) const {
+    const auto it = groups_.find(gid);
+    if (it == groups_.end()) throw std::runtime_error("invalid gid");
+    return it->second;
+  }
+  T &group(std::size_t gid) {
+    const auto it = groups_.find(gid);
+    if (it == groups_.end()) throw std::runtime_error("invalid gid");
+    return it->second;
+  }
+  const_iterator begin() const { return groups_.begin(); }
+  const_iterator end() const { return groups_.end(); }
+
+private:
+  std::size_t gcount_ = 0;
+  std::map<std::size_t, T> groups_;
+};
+
 }  // namespace common
 }  // namespace microscopes

@@ -118,15 +118,15 @@ public:
     const size_t slot = gm_.add_value(gid, eid);
     push_params();
     z_host_[eid] = int32_t(slot);
-    check(msc_device_upload(ctx_, z_dev_ + eid, &z_host_[eid], 4));
-    check(msc_accumulate(st_, view_, nullptr, eid, 1, z_dev_ + eid, 0));
+    // the group goes by value: one launch updates the sums, the group's fields and score constants, the counts and
+    // the device's copy of the assignment -- nothing to upload, nothing to wait for
+    check(msc_entity_op(st_, view_, nullptr, eid, uint32_t(slot), +1, z_dev_));
   }
   size_t remove_value(size_t eid, common::rng_t &) override {
     sync();
-    const auto r = gm_.remove_value(eid);                 // (throws if the entity is not assigned)
-    check(msc_accumulate(st_, view_, nullptr, eid, 1, z_dev_ + eid, MSC_ACC_SUBTRACT));
+    const auto r = gm_.remove_value(eid);                 // (throws if the entity is not assigned); r = (gid, its slot)
+    check(msc_entity_op(st_, view_, nullptr, eid, uint32_t(r.second), -1, z_dev_));
     z_host_[eid] = -1;
-    check(msc_device_upload(ctx_, z_dev_ + eid, &z_host_[eid], 4));
     return r.first;
   }
 

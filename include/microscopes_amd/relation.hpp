@@ -273,6 +273,21 @@ inline void cell_blocks(msc_context *ctx, const std::vector<size_t> &shape, cons
     throw std::runtime_error(msc_last_error());
 }
 
+// irm's slice reduction on the device (msc_relation_slice_scores): out[e][g] = sum over the cells of slice (dim, e) of
+// the cell's score against block (g, the cell's other clusters).  scores_dev = what msc_score_value wrote for the
+// relation's cells; off_dev = cell_blocks() with an all-zero assignment vector for `dim`; seg / ids non-null for a
+// compressed relation (the rows of its CSR, or of its transpose for dim 1).
+inline void slice_scores(msc_context *ctx, const float *scores_dev, uint64_t ld, const std::vector<size_t> &shape, size_t dim,
+                         const uint32_t *seg_dev, const uint32_t *ids_dev, const int32_t *off_dev, const std::vector<uint32_t> &ngroups,
+                         uint64_t nent, float *out_dev, uint64_t ld_out) {
+  std::vector<uint64_t> sh(shape.begin(), shape.end());
+  uint32_t stride = 1;
+  for (size_t d = dim + 1; d < ngroups.size(); d++) stride *= ngroups[d];
+  if (msc_relation_slice_scores(ctx, scores_dev, ld, uint32_t(shape.size()), sh.data(), uint32_t(dim), seg_dev, ids_dev, off_dev,
+                                ngroups.at(dim), stride, nent, out_dev, ld_out) != MSC_OK)
+    throw std::runtime_error(msc_last_error());
+}
+
 }  // namespace relation
 }  // namespace common
 }  // namespace microscopes

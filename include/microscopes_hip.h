@@ -232,6 +232,18 @@ int msc_score_tune(msc_state *st, const msc_dataview *view, const uint32_t *cols
 int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
                    uint64_t nrows, const int32_t *z_dev, uint32_t flags);
 
+/*
+ * ONE entity joins (sign > 0) or leaves (sign < 0) ONE group, the group passed by value: group_manager::add_value /
+ * remove_value together with every component model's add_value / remove_value for that row (the per-entity calls of
+ * entity_based_state_object, entity_state.hpp:57-68).  For states of scalar families this is a single launch that
+ * leaves every table current (sums, the reference's fields, score constants and CRP terms of the one group that
+ * changed), so a Gibbs move -- leave, msc_score_value of the row, join -- is three launches and one copy back;
+ * niw / dm features take the general accumulate path.  z_dev (nullable): the caller's device assignment vector, of
+ * which entry `row` is set to the group (join) or -1 (leave).  Asynchronous.
+ */
+int msc_entity_op(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row, uint32_t group,
+                  int sign, int32_t *z_dev);
+
 /* score_data (base.hpp:28) for every (feature, group): out_dev[f * ngroups + k] */
 int msc_score_data(msc_state *st, float *out_dev);
 
@@ -310,6 +322,24 @@ int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, int op, cons
 int msc_relation_blocks(msc_context *ctx, uint32_t ndim, const uint64_t *shape,
                         const int32_t *const *z_dev, const uint32_t *ngroups,
                         const uint32_t *positions_dev, uint64_t ncells, int32_t *z_cell_dev);
+
+/*
+ * irm's slice reduction (what its assignment kernel does with relation::dataview::slice, dataview.hpp:265-578): entity e
+ * of the domain on dimension `dim` is scored against every candidate cluster g of that domain by summing, over the
+ * cells c of slice (dim, e), the cell's score against the block it would then lie in:
+ *   out[e * ld_out + g] = sum_c scores[c * ld + g * cand_stride + off[c]]
+ * scores_dev: the per-cell matrix msc_score_value wrote for the relation's cells ([ncells][ld], one column per block);
+ * off_dev[c]: the block index of cell c with the candidate dimension's cluster set to 0 (msc_relation_blocks with an
+ * all-zero assignment vector for `dim`; -1 = an entity of the cell is unassigned: the cell is skipped);
+ * cand_stride: what one step of the candidate cluster adds to the block index (product of the cluster counts of the
+ * later dimensions).  Dense relation: seg_dev = ids_dev = NULL and the slices are enumerated from shape; sparse: the
+ * cells of entity e are ids_dev[seg_dev[e] .. seg_dev[e + 1]).  nent = entities scored (= shape[dim] for a dense one).
+ * Sums are taken in double in a fixed order.  Asynchronous on the context's stream.
+ */
+int msc_relation_slice_scores(msc_context *ctx, const float *scores_dev, uint64_t ld, uint32_t ndim,
+                              const uint64_t *shape, uint32_t dim, const uint32_t *seg_dev, const uint32_t *ids_dev,
+                              const int32_t *off_dev, uint32_t ncand, uint32_t cand_stride, uint64_t nent,
+                              float *out_dev, uint64_t ld_out);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,35 @@ static void test_row_accessor_over_reference_rows() {
   CHECK(f0 == 1.f && d1 == 943.);
 }
 
+// group_manager.hpp:320-386: ids in creation order, never reused; lookups of a deleted id fail
+static void test_simple_group_manager() {
+  simple_group_manager<std::string> g;
+  CHECK(g.ngroups() == 0 && g.groups().empty() && g.begin() == g.end());
+  auto a = g.create_group();
+  a.second = "a";
+  auto b = g.create_group();
+  b.second = "b";
+  auto c = g.create_group();
+  c.second = "c";
+  CHECK(a.first == 0 && b.first == 1 && c.first == 2 && g.ngroups() == 3);
+  g.delete_group(1);
+  CHECK(g.ngroups() == 2 && g.groups() == std::vector<size_t>({0, 2}));
+  CHECK(g.create_group().first == 3);                              // 1 is not handed out again
+  CHECK(g.group(2) == "c");
+  g.group(0) += "!";
+  const simple_group_manager<std::string> &cg = g;
+  CHECK(cg.group(0) == "a!");
+  bool threw = false;
+  try { g.group(1); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { g.delete_group(7); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);
+  size_t n = 0;
+  for (auto it = g.begin(); it != g.end(); ++it) n += it->first;
+  CHECK(n == 0 + 2 + 3);
+}
+
 static void test_group_manager_bookkeeping_and_serialization() {
   typedef group_manager<size_t> gm;
   gm g(10);
@@ -270,6 +299,7 @@ int main() {
   test_types_and_offsets();
   test_row_accessor_over_reference_rows();
   test_group_manager_bookkeeping_and_serialization();
+  test_simple_group_manager();
   test_sampling_helpers();
   test_noop_model_and_wire();
   std::puts("test_host_api ok");

@@ -146,6 +146,21 @@ int main() {
     std::printf("per-entity gibbs move incl. 8 per-value twin calls: %.0f us\n",
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 60.0);
   }
+  {  // the move alone (no twin): leave, score against every group, join -- msc_entity_op, msc_score_value + one copy
+     // back, msc_entity_op.  Entities put back where they were, so the twin stays in step.
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t n_moves = 0;
+    for (int rep = 0; rep < 4; rep++)
+      for (size_t e = 200; e < 260; e++) {
+        const size_t old = iface.remove_value(e, rng);
+        auto sc = iface.score_value(e, rng);
+        (void)sc;
+        iface.add_value(old, e, rng);
+        n_moves++;
+      }
+    std::printf("per-entity gibbs move alone (remove + score + add, 4 components): %.1f us\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / double(n_moves));
+  }
   // likelihoods and bags against the twin
   for (size_t gid : iface.groups())
     for (size_t f = 0; f < 4; f++) {

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -90,6 +92,57 @@ int main() {
     std::vector<uint32_t> rec(2 * K0 * K1);
     hip::check(msc_state_get_ss(st, 0, 0, K0 * K1, rec.data(), rec.size() * 4));
     for (uint32_t b = 0; b < K0 * K1; b++) CHECK(rec[2 * b] == heads[b] && rec[2 * b + 1] == tails[b]);
+    // irm's slice reduction over the compressed relation, both dimensions: the device sums the per-cell scores of each
+    // slice per candidate cluster; the host does the same walk through compressed_2darray::slice
+    // (test/cxx/test_relation.cpp:281-323 is how the reference exercises those iterators)
+    {
+      const uint64_t nnz = sparse.nnz(), nblk = K0 * K1;
+      float *sc = nullptr;
+      CHECK(hipMalloc(reinterpret_cast<void **>(&sc), 4 * nnz * nblk) == hipSuccess);
+      hip::check(msc_score_value(st, cells, nullptr, 0, nnz, nullptr, 0, sc, nblk));
+      std::vector<float> sch(nnz * nblk);
+      hip::check(msc_device_download(ctx, sch.data(), sc, 4 * nnz * nblk));
+      // the stored entries are the cells in CSR order: cell id of (i, j) = position in csr_i
+      std::vector<int32_t> zeros0(n, 0), zeros1(m, 0);
+      int32_t *zero0d = to_dev(zeros0), *zero1d = to_dev(zeros1), *off = nullptr;
+      CHECK(hipMalloc(reinterpret_cast<void **>(&off), 4 * (nnz + 1)) == hipSuccess);
+      for (size_t dim = 0; dim < 2; dim++) {
+        cell_blocks(ctx, sparse.shape(), {dim == 0 ? zero0d : z0d, dim == 1 ? zero1d : z1d}, {K0, K1}, posd, nnz, off);
+        // rows of the CSR (dim 0) or of its transpose (dim 1), as cell ids
+        std::vector<uint32_t> seg(1, 0), ids;
+        const size_t nent = dim == 0 ? n : m;
+        for (size_t e = 0; e < nent; e++) {
+          if (dim == 0) for (uint32_t p = csr_p[e]; p < csr_p[e + 1]; p++) ids.push_back(p);
+          else for (size_t i = 0; i < n; i++)
+            for (uint32_t p = csr_p[i]; p < csr_p[i + 1]; p++) if (csr_i[p] == e) ids.push_back(p);
+          seg.push_back(uint32_t(ids.size()));
+        }
+        uint32_t *segd = to_dev(seg), *idsd = to_dev(ids);
+        const uint32_t ncand = dim == 0 ? K0 : K1;
+        float *outd = nullptr;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&outd), 4 * nent * ncand) == hipSuccess);
+        slice_scores(ctx, sc, nblk, sparse.shape(), dim, segd, idsd, off, {K0, K1}, nent, outd, ncand);
+        std::vector<float> got(nent * ncand);
+        hip::check(msc_device_download(ctx, got.data(), outd, 4 * nent * ncand));
+        for (size_t e = 0; e < nent; e++)
+          for (uint32_t g = 0; g < ncand; g++) {
+            double want = 0.0;
+            size_t cells_seen = 0;
+            for (const auto &pv : sparse.slice(dim, e)) {
+              const size_t i = pv.first[0], j = pv.first[1];
+              uint32_t p = csr_p[i];
+              while (csr_i[p] != j) p++;                              // the cell id of (i, j)
+              const uint32_t b = dim == 0 ? g * K1 + uint32_t(z1[j]) : uint32_t(z0[i]) * K1 + g;
+              want += double(sch[size_t(p) * nblk + b]);
+              cells_seen++;
+            }
+            CHECK(cells_seen == seg[e + 1] - seg[e]);
+            CHECK(std::fabs(double(got[e * ncand + g]) - want) <= 1e-5 * std::max(1.0, std::fabs(want)));
+          }
+        (void)hipFree(segd); (void)hipFree(idsd); (void)hipFree(outd);
+      }
+      (void)hipFree(sc); (void)hipFree(off); (void)hipFree(zero0d); (void)hipFree(zero1d);
+    }
     msc_state_destroy(st);
     msc_dataview_destroy(cells);
     (void)hipFree(zc);

@@ -72,3 +72,86 @@ def test_three_dimensional_relation_and_bad_arguments(gpu_ctx):
         view.blocks([torch.from_numpy(zs[0]).to(dev)], [2])      # one vector per dimension
     with pytest.raises(MicroscopesHipError):
         view.blocks([torch.from_numpy(z).to(dev) for z in zs], [2, 3, 0])   # a dimension without groups
+
+
+def _oracle_entity_scores(F, hp_ss_of_block, rel, zs, Ks, dim, e):
+    """what irm computes for entity e of dimension dim: remove its slice's cells from their blocks, then for every
+    candidate cluster g sum score_value of the slice's cells against the blocks they would lie in (host loop over the
+    slice, as relation/dataview.hpp's slice iterators feed it)"""
+    data, mask = np.ma.getdata(rel), np.ma.getmaskarray(rel)
+    nd = rel.ndim
+    strides = [int(np.prod(Ks[d + 1:])) for d in range(nd)]
+    ss = hp_ss_of_block.copy()
+    cells = [idx for idx in np.ndindex(*rel.shape) if idx[dim] == e and not mask[idx] and all(zs[d][idx[d]] >= 0 for d in range(nd) if d != dim)]
+    if zs[dim][e] >= 0:
+        for idx in cells:                                       # the entity leaves: its cells leave their blocks
+            b = sum(int(zs[d][idx[d]]) * strides[d] for d in range(nd))
+            F.remove_value(ss, b, data[idx])
+    out = np.zeros(Ks[dim])
+    for g in range(Ks[dim]):
+        for idx in cells:
+            b = g * strides[dim] + sum(int(zs[d][idx[d]]) * strides[d] for d in range(nd) if d != dim)
+            out[g] += F.score_value(ss, b, data[idx])
+    return out
+
+
+@pytest.mark.parametrize("family,shape,Ks", [(orc.BB, (23, 31), (4, 5)), (orc.NICH, (9, 7, 6), (3, 2, 4)), (orc.GP, (20, 17), (3, 70))])
+def test_slice_scores_are_irms_per_entity_candidate_scores(gpu_ctx, family, shape, Ks):
+    """msc_relation_slice_scores against the per-entity loop irm runs over relation slices: for a handful of entities of
+    every dimension, remove the entity's cells (msc_accumulate SUBTRACT), score the cells against every block, reduce the
+    slice per candidate cluster, put the cells back"""
+    import common_amd
+    rng = np.random.default_rng(sum(shape))
+    if family == orc.BB:
+        data = rng.random(shape) < 0.4
+        hp = dict(alpha=1.0, beta=1.0)
+    elif family == orc.GP:
+        data = rng.poisson(3.0, shape).astype(np.uint32)
+        hp = dict(alpha=1.0, inv_beta=1.0)
+    else:
+        data = rng.normal(0, 2, shape).astype(np.float32)
+        hp = dict(mu=0., kappa=1., sigmasq=1., nu=1.)
+    rel = np.ma.masked_array(data, mask=rng.random(shape) < 0.25)
+    view = common_amd.RelationView(gpu_ctx, rel)
+    dev = gpu_ctx.torch_device
+    nd, nblocks = len(shape), int(np.prod(Ks))
+    zs = [rng.integers(0, k, n).astype(np.int32) for n, k in zip(shape, Ks)]
+    zs[-1][0] = -1                                              # an unassigned entity on the last dimension
+    zt = [torch.from_numpy(z).to(dev) for z in zs]
+    zc = view.blocks(zt, Ks)
+    st = common_amd.State(gpu_ctx, [(family, 0)], nblocks)
+    st.accumulate(view.cells, zc)
+    F = orc.Family(family, hp, 0, "f64")
+    base = orc.widen_ss(family, st.get_ss(0).astype(orc.ss_dtype(family, 0, "f32")))
+    zch = zc.cpu().numpy()
+    ncells = view.cells.nrows
+    cell_index = np.arange(ncells).reshape(shape)
+    for dim in range(nd):
+        off = view.slice_offsets(zt, Ks, dim)
+        ents = [0, shape[dim] - 1, int(rng.integers(1, shape[dim] - 1))]
+        for e in ents:
+            in_slice = np.zeros(ncells, dtype=bool)
+            in_slice[np.take(cell_index, e, axis=dim).reshape(-1)] = True
+            z_rm = torch.from_numpy(np.where(in_slice, zch, -1).astype(np.int32)).to(dev)
+            st.accumulate(view.cells, z_rm, reset=False, subtract=True)          # the entity's cells leave their blocks
+            scores = st.score_value(view.cells)                                   # [ncells, nblocks]
+            got = view.slice_scores(scores, off, dim, Ks)[e].cpu().numpy()
+            st.accumulate(view.cells, z_rm, reset=False)                          # ... and come back
+            want = _oracle_entity_scores(F, base, rel, zs, Ks, dim, e)
+            assert rel_err(got, want).max() <= 4 * TOL, (family, dim, e)          # a sum of up to ~60 float cell scores
+    # all entities of a dimension in one call: every row equals the reduction done on the host from the same score matrix
+    scores = st.score_value(view.cells)
+    sh = scores.cpu().numpy().astype(np.float64)
+    for dim in range(nd):
+        off = view.slice_offsets(zt, Ks, dim)
+        got = view.slice_scores(scores, off, dim, Ks).cpu().numpy()
+        offh = off.cpu().numpy()
+        stride = int(np.prod(Ks[dim + 1:]))
+        want = np.zeros((shape[dim], Ks[dim]))
+        for e in range(shape[dim]):
+            for c in np.take(cell_index, e, axis=dim).reshape(-1):
+                if offh[c] >= 0:
+                    want[e] += sh[c, offh[c] + stride * np.arange(Ks[dim])]
+        assert rel_err(got, want).max() <= 1e-6
+    with pytest.raises(common_amd.MicroscopesHipError):
+        view.slice_scores(scores[:, :2].contiguous(), view.slice_offsets(zt, Ks, 0), 0, Ks)   # score rows shorter than the blocks

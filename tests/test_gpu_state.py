@@ -217,3 +217,52 @@ def test_accumulate_with_more_groups_than_lds_histograms_hold(gpu_ctx):
     zn = z2.cpu().numpy()
     assert ((zn >= 0) & (zn < K)).all() and (zn != np.where(z < 0, 0, z)).any()
     assert np.array_equal(st.get_group_counts(), np.bincount(zn, minlength=K))
+
+
+def test_entity_op_keeps_every_table_current(gpu_ctx):
+    """msc_entity_op: one entity joins / leaves one group, the group by value, in one launch -- after a run of such moves
+    the suff-stats, the group sizes and the scores are those of a state built from the final assignment in one pass"""
+    import common_amd
+    rng = np.random.default_rng(12)
+    N, K = 400, 9
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 5), (orc.NICH, 0), (orc.BNB, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    rec = recarray_of(feats)
+    mask = np.zeros(N, dtype=[(n, np.bool_) for n in rec.dtype.names])
+    mask["f3"][::7] = True                                        # masked values take no part
+    view = common_amd.DataView.from_recarray(gpu_ctx, np.ma.masked_array(rec, mask=mask))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, f in enumerate(feats):
+        st.set_hp(i, f["hp"])
+    st.set_alpha(0.7)
+    z = np.full(N, -1, dtype=np.int32)
+    zt = torch.from_numpy(z.copy()).to(gpu_ctx.torch_device)
+    for n in range(N):                                            # everybody joins a group, one by one
+        z[n] = int(rng.integers(0, K - 1))                        # (group K - 1 stays empty)
+        st.entity_op(view, n, z[n], join=True, z=zt)
+    for _ in range(300):                                          # Gibbs-style moves: leave, (score), join
+        n = int(rng.integers(0, N))
+        st.entity_op(view, n, z[n], join=False, z=zt)
+        row = st.score_value(view, row0=n, nrows=1, crp_prior=True)           # tables are current: no prepare pass runs
+        assert bool(torch.isfinite(row).all())
+        z[n] = int(rng.integers(0, K - 1))
+        st.entity_op(view, n, z[n], join=True, z=zt)
+    assert np.array_equal(zt.cpu().numpy(), z)
+    ref = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, f in enumerate(feats):
+        ref.set_hp(i, f["hp"])
+    ref.set_alpha(0.7)
+    ref.accumulate(view, torch.from_numpy(z).to(gpu_ctx.torch_device))
+    assert np.array_equal(st.get_group_counts(), ref.get_group_counts())
+    for i in range(len(feats)):
+        a, b = st.get_ss(i), ref.get_ss(i)
+        for name in a.dtype.names:
+            if np.issubdtype(a.dtype[name].base, np.integer):
+                assert np.array_equal(a[name], b[name]), (i, name)
+            else:
+                assert rel_err(a[name], b[name]).max() <= TOL, (i, name)
+    got = st.score_value(view, crp_prior=True).cpu().numpy()
+    want = ref.score_value(view, crp_prior=True).cpu().numpy()
+    assert rel_err(got, want).max() <= 2 * TOL
+    with pytest.raises(common_amd.MicroscopesHipError):
+        st.entity_op(view, 0, K, join=True)                       # no such group
