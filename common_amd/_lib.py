@@ -48,6 +48,8 @@ _SIGS = {
     "msc_device_alloc_probed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "msc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "msc_pinned_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "msc_pinned_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "msc_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "msc_dataview_from_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -91,6 +93,16 @@ _SIGS = {
     "msc_state_reduce_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "msc_state_commit_reduce": (C.c_int, [C.c_void_p]),
+    "msc_comm_unique_id_bytes": (C.c_size_t, []),
+    "msc_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "msc_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "msc_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "msc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "msc_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "msc_state_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "msc_sweep_step_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                         C.c_uint64, C.c_uint64, C.c_void_p]),
+    "msc_accumulate_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "msc_value_op_single": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "msc_relation_slice_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

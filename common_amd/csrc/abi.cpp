@@ -187,6 +187,30 @@ extern "C" int msc_device_free(msc_context *ctx, void *dev) {
   MSC_HIP(hipFree(dev));
   return MSC_OK;
 }
+extern "C" int msc_pinned_alloc(msc_context *ctx, size_t nbytes, void **host, void **dev) {
+  MSC_REQUIRE(ctx && host && dev, "null argument");
+  *host = *dev = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  void *h = nullptr, *d = nullptr;
+  MSC_HIP(hipHostMalloc(&h, nbytes ? nbytes : 1, hipHostMallocMapped));
+  const hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) {
+    (void)hipHostFree(h);
+    return fail(MSC_EHIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+  }
+  std::memset(h, 0, nbytes ? nbytes : 1);
+  *host = h;
+  *dev = d;
+  return MSC_OK;
+}
+extern "C" int msc_pinned_free(msc_context *ctx, void *host) {
+  MSC_REQUIRE(ctx, "null context");
+  if (!host) return MSC_OK;
+  MSC_HIP(hipSetDevice(ctx->device));
+  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  MSC_HIP(hipHostFree(host));
+  return MSC_OK;
+}
 // both copies are ordered on the context's stream and have completed when the call returns
 extern "C" int msc_device_upload(msc_context *ctx, void *dst_dev, const void *src_host, size_t nbytes) {
   MSC_REQUIRE(ctx && (nbytes == 0 || (dst_dev && src_host)), "null argument");

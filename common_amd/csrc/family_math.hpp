@@ -308,6 +308,16 @@ MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1l
   log1p_parts(a * a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
 }
+// The sweep kernels' form, in log2 units: c0' - c1 log2(1 + t), with log2(1 + t) = log2(u) + log2e (t - (u - 1)) / u
+// assembled first -- the same accuracy (the product with c1 rounds at the term's own size either way) with one
+// per-group constant fewer to keep in registers than nich_eval's two factors.
+MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, float c1, float s) {
+#pragma clang fp contract(off)
+  const float a = fmaf(x, s, -smu_hi) - smu_lo;
+  float l2, r;
+  log1p_parts(a * a, l2, r);
+  return fmaf(-c1, fmaf(r, 1.44269504088896340736f, l2), c0);
+}
 // Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:
 //   n = count - 1, m2 = (mean count - x) / n, v2 = ctv - (x - mean)(x - m2), then the posterior and the
 //   Student-t of the section header with (n, m2, v2).

@@ -105,10 +105,45 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
   // entries that do not; entries with k >= K have p = 0 and cannot be the first
   float c = incl - sum;
   int nmiss = 0;
+  if constexpr (G <= 4) {
 #pragma unroll
-  for (int j = 0; j < G; j++) {
-    c += p[j];
-    nmiss += c < dart ? 1 : 0;
+    for (int j = 0; j < G; j++) {
+      c += p[j];
+      nmiss += c < dart ? 1 : 0;
+    }
+  } else {
+    // 8 or 16 entries per lane: descend through the block sums instead of walking the entries (3 instructions per
+    // entry otherwise): quads, then pairs, then the two entries -- every level asks "does everything before the
+    // right half still miss?".  Sums are formed left to right inside a block, so a block's partial sums are the
+    // walk's own values and the count is the walk's count.
+    float q[G / 4];
+#pragma unroll
+    for (int b = 0; b < G / 4; b++) q[b] = ((p[4 * b] + p[4 * b + 1]) + p[4 * b + 2]) + p[4 * b + 3];
+    int blk = 0;
+#pragma unroll
+    for (int b = 0; b < G / 4; b++) {                      // 2 or 4 quads: count those that miss entirely
+      const float cq = c + q[b];
+      const bool miss = (blk == b) && cq < dart;
+      c = miss ? cq : c;
+      blk += miss ? 1 : 0;
+    }
+    nmiss = 4 * blk;
+    if (blk < G / 4) {
+      float e0 = p[0], e1 = p[1], e2 = p[2];
+#pragma unroll
+      for (int b = 1; b < G / 4; b++) {
+        e0 = blk == b ? p[4 * b] : e0;
+        e1 = blk == b ? p[4 * b + 1] : e1;
+        e2 = blk == b ? p[4 * b + 2] : e2;
+      }
+      c += e0;
+      const bool m0 = c < dart;
+      c += e1;
+      const bool m1 = m0 && c < dart;
+      c += e2;
+      const bool m2 = m1 && c < dart;
+      nmiss += (m0 ? 1 : 0) + (m1 ? 1 : 0) + (m2 ? 1 : 0);   // (the block reaches the dart, so its fourth entry does if these miss)
+    }
   }
   const unsigned long long hit = __builtin_amdgcn_ballot_w64(nmiss < G);
   if (hit == 0ull) return (int)K - 1;
@@ -129,8 +164,10 @@ MSC_DEV void zero_spans(const ZeroSpans &zs) {
 }
 
 // ---------------------------------------------------------------------------
+// (G = 16 asks for three waves per SIMD: at two the dependent transcendental chains of one wave pair leave the vector
+//  pipe idle; the register allocator then works within 168 VGPRs)
 template <int G>
-__global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict__ feats, uint32_t K,
+__global__ __launch_bounds__(256, G == 16 ? 3 : 1) void k_sweep_nich1(const FeatDesc *__restrict__ feats, uint32_t K,
                                                       uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                       uint64_t row_id0, int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
@@ -142,61 +179,40 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
   const FeatDesc fd = feats[0];
   const int lane = threadIdx.x & 63;
   const uint32_t kb = (uint32_t)(G * lane);
-  float mh[G], ml[G], c0[G], c1l[G], c1[G], c2[G], lc[G];
-  if constexpr (G < 4) {                 // few groups (K <= 64 G): one or two per lane, scalar loads
+  // per-group constants in registers for the whole kernel: s mu (hi, lo), s = sqrt(c2), c1, and c0' (below)
+  float mh[G], ml[G], c0[G], c1[G], c2[G];
+  bool empty[G];
 #pragma unroll
-    for (int j = 0; j < G; j++) {
-      const uint32_t k = kb + j;         // < 64 G <= kpad
-      mh[j] = fd.tab[(size_t)NICH_MU_HI * kpad + k];
-      ml[j] = fd.tab[(size_t)NICH_MU_LO * kpad + k];
-      c0[j] = fd.tab[(size_t)NICH_C0 * kpad + k];
-      c1l[j] = fd.tab[(size_t)NICH_C1LN2 * kpad + k];
-      c1[j] = fd.tab[(size_t)NICH_C1 * kpad + k];
-      c2[j] = fd.tab[(size_t)NICH_C2 * kpad + k];
-      lc[j] = crp[k];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < G; j += 4) {
-      const uint32_t k = kb + j;           // kpad is a multiple of 256 >= 64*G only when K allows; guard loads
-      const bool in = k < kpad;
-      const float4 a = in ? ld4(fd.tab + (size_t)NICH_MU_HI * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 b = in ? ld4(fd.tab + (size_t)NICH_MU_LO * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 c = in ? ld4(fd.tab + (size_t)NICH_C0 * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 d = in ? ld4(fd.tab + (size_t)NICH_C1LN2 * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 e = in ? ld4(fd.tab + (size_t)NICH_C1 * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 f = in ? ld4(fd.tab + (size_t)NICH_C2 * kpad + k) : make_float4(0, 0, 0, 0);
-      const float4 g = in ? ld4(crp + k) : make_float4(0, 0, 0, 0);
-      mh[j] = a.x; mh[j + 1] = a.y; mh[j + 2] = a.z; mh[j + 3] = a.w;
-      ml[j] = b.x; ml[j + 1] = b.y; ml[j + 2] = b.z; ml[j + 3] = b.w;
-      c0[j] = c.x; c0[j + 1] = c.y; c0[j + 2] = c.z; c0[j + 3] = c.w;
-      c1l[j] = d.x; c1l[j + 1] = d.y; c1l[j + 2] = d.z; c1l[j + 3] = d.w;
-      c1[j] = e.x; c1[j + 1] = e.y; c1[j + 2] = e.z; c1[j + 3] = e.w;
-      c2[j] = f.x; c2[j + 1] = f.y; c2[j + 2] = f.z; c2[j + 3] = f.w;
-      lc[j] = g.x; lc[j + 1] = g.y; lc[j + 2] = g.z; lc[j + 3] = g.w;
-    }
+  for (int j = 0; j < G; j++) {
+    const uint32_t k = kb + j;
+    const size_t kc = k < kpad ? k : 0;                  // (kpad >= 64 G only when K needs it)
+    mh[j] = fd.tab[(size_t)NICH_MU_HI * kpad + kc];
+    ml[j] = fd.tab[(size_t)NICH_MU_LO * kpad + kc];
+    c0[j] = fd.tab[(size_t)NICH_C0 * kpad + kc];
+    c1[j] = fd.tab[(size_t)NICH_C1 * kpad + kc];
+    c2[j] = fd.tab[(size_t)NICH_C2 * kpad + kc];
+    const float lcj = crp[kc];
+    empty[j] = __builtin_isinf(lcj);
+    c0[j] += empty[j] ? 0.f : lcj;                        // + log count (an empty group's prior is added below)
   }
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
-  // Sampling only needs the scores up to what exp2 sees, so everything is moved to log2 units once
-  // per lane: c0' = (c0 + log count) log2e (or -inf beyond K), c1 ln2 log2e = c1, c1' = c1 log2e, and
-  // the prior of an empty group enters as emp * e with emp = log2e there and 0 elsewhere.
-  constexpr float kLog2e = 1.44269504088896340736f;
-  // ... and so is everything else that does not depend on the row: an empty group's prior log(alpha / n_empty) (when
-  // that is -inf no group is empty and the value is never used), and minus the wave-uniform bound that stands in for
-  // the row maximum in the draw, so that a row's unnormalised probability is exp2(score) with nothing in between.
-  // A row that is its group's only member leaves one more empty group behind: every empty group's prior moves by
+  // Sampling only needs the scores up to what exp2 sees, so everything is moved to log2 units once per lane:
+  // score = c0' - c1 w with w = log2(1 + t) (the hardware logarithm plus the log1p remainder scaled by log2 e) and
+  // c0' = (c0 + prior) log2e - bound.  The prior of an empty group, log(alpha / n_empty), is folded in (when that is
+  // -inf no group is empty and the value is never used), and so is minus the wave-uniform bound that stands in for the
+  // row maximum in the draw: a row's unnormalised probability is exp2(score) with nothing in between.  A row that is
+  // its group's only member leaves one more empty group behind: every empty group's prior moves by
   // dle = log2(n_empty / (n_empty + 1)) for that row (wave-uniform side path, rare).
+  constexpr float kLog2e = 1.44269504088896340736f;
   const bool any_empty = !__builtin_isinf(le0);
   const float dle = any_empty ? (le1 - le0) * kLog2e : 0.f;
-  float c0s[G], c1s[G];
+  float c0s[G];
   unsigned emask = 0u;                                  // bit j: group kb + j is empty
   float bound = -INFINITY;
 #pragma unroll
   for (int j = 0; j < G; j++) {
-    const bool empty = __builtin_isinf(lc[j]);
-    if (empty && kb + j < K) emask |= 1u << j;
-    c0s[j] = (kb + j >= K) ? -INFINITY : (c0[j] + (empty ? le0 : lc[j])) * kLog2e;
-    c1s[j] = c1[j] * kLog2e;
+    if (empty[j] && kb + j < K) emask |= 1u << j;
+    c0s[j] = (kb + j >= K) ? -INFINITY : (c0[j] + (empty[j] ? le0 : 0.f)) * kLog2e;
     if (kb + j < K) bound = fmaxf(bound, c0s[j]);
   }
   // no score exceeds its c0' (log1p >= 0); the own group's leave-one-out value, a masked row's prior-only scores and a
@@ -240,13 +256,15 @@ __global__ __launch_bounds__(256) void k_sweep_nich1(const FeatDesc *__restrict_
       const int g = lane_bcast(gz, r);
       float s[G];
 #pragma unroll
-      for (int j = 0; j < G; j++) s[j] = nich_eval(x, mh[j], ml[j], c0s[j], c1[j], c1s[j], c2[j]);
+      for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, mh[j], ml[j], c0s[j], c1[j], c2[j]);
       if ((odd >> r) & 1ull) {                            // (wave-uniform, rare)
         if ((mbits >> r) & 1ull) {                        // masked value: only the prior speaks
           const float e_raw = ((singles >> r) & 1ull) ? le1 : le0;
 #pragma unroll
-          for (int j = 0; j < G; j++)
-            s[j] = (kb + j >= K) ? -INFINITY : (__builtin_isinf(lc[j]) ? e_raw : lc[j]) * kLog2e - bound;
+          for (int j = 0; j < G; j++) {
+            const float lcj = crp[kb + j < kpad ? kb + j : 0];
+            s[j] = (kb + j >= K) ? -INFINITY : (__builtin_isinf(lcj) ? e_raw : lcj) * kLog2e - bound;
+          }
         } else {                                          // one more empty group shares alpha for this row
 #pragma unroll
           for (int j = 0; j < G; j++) s[j] += ((emask >> j) & 1u) ? dle : 0.f;

@@ -58,7 +58,7 @@ public:
     view_ = data.to_device(ctx_, &col_types);
     check(msc_state_create(ctx_, specs.data(), uint32_t(specs.size()), uint32_t(kmax_), &st_));
     check(msc_device_alloc(ctx_, 4 * (n_ ? n_ : 1), reinterpret_cast<void **>(&z_dev_)));
-    check(msc_device_alloc(ctx_, 4 * kmax_, reinterpret_cast<void **>(&row_dev_)));
+    check(msc_pinned_alloc(ctx_, 4 * kmax_, reinterpret_cast<void **>(&row_host_), reinterpret_cast<void **>(&row_dev_)));   // the score row lands in host memory
     check(msc_device_alloc(ctx_, 4 * kmax_ * hypers_.size(), reinterpret_cast<void **>(&sd_dev_)));
     z_host_.assign(n_, -1);
     check(msc_device_upload(ctx_, z_dev_, z_host_.data(), 4 * n_));
@@ -68,7 +68,7 @@ public:
     if (st_) msc_state_destroy(st_);
     if (view_) msc_dataview_destroy(view_);
     msc_device_free(ctx_, z_dev_);
-    msc_device_free(ctx_, row_dev_);
+    msc_pinned_free(ctx_, row_host_);
     msc_device_free(ctx_, sd_dev_);
   }
   mixture_state(const mixture_state &) = delete;
@@ -139,8 +139,8 @@ public:
     mixture_state *self = const_cast<mixture_state *>(this);
     self->push_params(true);
     check(msc_score_value(st_, view_, nullptr, eid, 1, nullptr, 0, row_dev_, kmax_));
-    std::vector<float> row(kmax_);
-    check(msc_device_download(ctx_, row.data(), row_dev_, 4 * kmax_));
+    check(msc_context_synchronize(ctx_));                 // the only wait of a move; the row was written into pinned host memory
+    const float *row = row_host_;
     scores.first.clear();
     scores.second.clear();
     for (auto it = gm_.begin(); it != gm_.end(); ++it) {
@@ -360,7 +360,7 @@ private:
   msc_dataview *view_ = nullptr;
   msc_state *st_ = nullptr;
   int32_t *z_dev_ = nullptr;
-  float *row_dev_ = nullptr, *sd_dev_ = nullptr;
+  float *row_dev_ = nullptr, *row_host_ = nullptr, *sd_dev_ = nullptr;
 };
 
 }  // namespace hip

@@ -105,6 +105,13 @@ int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out_dev);
 int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out_dev,
                             float *rates_gbps, uint32_t *chosen);
 int msc_device_free(msc_context *ctx, void *dev);
+/*
+ * Pinned host memory the device writes straight into (zero-copy): a row of scores the host reads after
+ * msc_context_synchronize, with no copy in between -- what a per-entity caller wants for its one row of K floats.
+ * *host is the CPU address, *dev the address to hand to the kernels (msc_score_value's out_dev).
+ */
+int msc_pinned_alloc(msc_context *ctx, size_t nbytes, void **host, void **dev);
+int msc_pinned_free(msc_context *ctx, void *host);
 int msc_device_upload(msc_context *ctx, void *dst_dev, const void *src_host, size_t nbytes);
 int msc_device_download(msc_context *ctx, void *dst_host, const void *src_dev, size_t nbytes);
 
@@ -295,6 +302,30 @@ int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *g
 int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n_i64, void **dev_f64,
                              size_t *n_f64);
 int msc_state_commit_reduce(msc_state *st);
+
+/*
+ * The same exchange for hosts that are not Python: a communicator over RCCL (xGMI inside a node), one rank per
+ * process and GPU.  The 128-byte id is created on one rank (msc_comm_unique_id) and carried to the others by the
+ * caller's own means (MPI, a file, a socket), exactly as ncclGetUniqueId / ncclCommInitRank want it;
+ * msc_comm_adopt wraps an ncclComm_t the caller already has.  librccl is resolved at the first of these calls.
+ *   msc_state_allreduce      sums both additive tables in place across the ranks (one RCCL group, context's stream)
+ *   msc_sweep_step_sharded   msc_sweep_step_begin + that + msc_state_commit_reduce: a whole sharded sweep step
+ *   msc_accumulate_sharded   suff-stats of the GLOBAL assignment: local accumulate, exchange, commit
+ * With one rank these are msc_sweep_step / msc_accumulate.  Asynchronous (msc_comm_create / destroy are not).
+ */
+typedef struct msc_comm msc_comm;
+size_t msc_comm_unique_id_bytes(void);
+int msc_comm_unique_id(void *id_out, size_t nbytes);
+int msc_comm_create(msc_context *ctx, const void *unique_id, size_t nbytes, int nranks, int rank, msc_comm **out);
+int msc_comm_adopt(msc_context *ctx, void *nccl_comm, int nranks, int rank, msc_comm **out);
+int msc_comm_destroy(msc_comm *comm);
+int msc_comm_size(const msc_comm *comm, int *nranks, int *rank);
+int msc_state_allreduce(msc_state *st, msc_comm *comm);
+int msc_sweep_step_sharded(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                           uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep,
+                           msc_comm *comm);
+int msc_accumulate_sharded(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
+                           uint64_t nrows, const int32_t *z_dev, msc_comm *comm);
 
 /* ---- per-value entry (the virtual group API, base.hpp:25-28) ----------- */
 typedef enum msc_value_op {

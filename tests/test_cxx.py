@@ -105,6 +105,15 @@ def test_relation_dataviews_on_device():
 
 
 @pytest.mark.gpu
+def test_c_level_collective_over_rccl():
+    """msc_comm_* / msc_state_allreduce / msc_sweep_step_sharded from a plain C++ host: RCCL on the box's GPU"""
+    exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_comm_gpu.cpp"), "test_comm_gpu",
+               ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"] + LINK)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    assert "test_comm_gpu ok" in subprocess.check_output([exe], env=env, timeout=300).decode()
+
+
+@pytest.mark.gpu
 def test_perf_group_harness_runs():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bin")])
     out = subprocess.check_output([os.path.join(ROOT, "bin", "perf_group_hip"), "64", "2"]).decode()
