@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 MFMA_F64_PEAK_TF = 78.6      # dense f64 matrix peak (MI355X spec; the table's dense figures, no sparsity)
 # vector-pipe issue roof for the kernels that are bound by it (C3 and the fused sweep): one wave
 # instruction per SIMD every 4 cycles (v_fma_f32 "one wave alone: 4", MI355X_MICROARCH.md per-instruction table),
-# 256 CUs x 4 SIMDs at the 2.4 GHz the guide's constants are quoted at = 2.46e11 wave-instructions/s
+# 256 CUs x 4 SIMDs at the 2.4 GHz the guide's constants are quoted at = 6.14e11 wave-instructions/s
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
 C5_ROWS_PER_RANK = 12_500_000
 C5_GROUPS = 1024
@@ -182,12 +182,14 @@ def sweep_roofline(nrows, K, kern_ms, kernel):
     evals = float(nrows) * K
     alg_bytes = 12.0 * nrows                                  # x, z in, z out
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    insts, src = pmc_entry(kernel, "SQ_INSTS_VALU")
+    # (the committed counters are per launch of this very shape: <16> = K 1024 on the 12.5 M-row shard, <4> = C2)
+    insts, src = pmc_entry(kernel + ("<16>" if K == C5_GROUPS else "<4>"), "SQ_INSTS_VALU")
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": pmc_entry(kernel, "hbm_bytes_per_launch")[0] if nrows == C5_ROWS_PER_RANK else None,
+         "traffic": pmc_entry(kernel + "<16>", "hbm_bytes_per_launch")[0] if (nrows, K) == (C5_ROWS_PER_RANK, C5_GROUPS) else None,
          "kernel": kernel, "kernel_avg_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
          "note": "the fused sweep materialises nothing: 12 B per row of HBM traffic, so HBM is not what binds it "
-                 "(SURVEY 8d: transcendental / vector issue rate); see valu_issue",
+                 "(SURVEY 8d: transcendental / vector issue rate); valu_issue = SQ_INSTS_VALU of the committed PMC pass "
+                 "over this run's kernel time, against one wave instruction per SIMD per 4 cycles",
          "evals_per_s": evals / (kern_ms * 1e-3)}
     if insts is not None and nrows == C5_ROWS_PER_RANK:
         # SQ_INSTS_VALU counts wave instructions; the roof is one per SIMD every 4 cycles
