@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c4 / c5_shard objects at N = 1")
     ap.add_argument("--tune", action="store_true", help="msc_score_tune before the C2 pass (off: the default launch shape)")
-    ap.add_argument("--probe-alloc", type=int, default=12, help="candidates of msc_device_alloc_probed for the C2 score matrix")
+    ap.add_argument("--probe-alloc", type=int, default=24, help="candidates of msc_device_alloc_probed for the C2 score matrix")
     ap.add_argument("--no-probe-alloc", action="store_true", help="plain torch allocation for the score matrix")
     return ap.parse_args()
 
@@ -191,7 +191,7 @@ def sweep_roofline(nrows, K, kern_ms, kernel):
                  "(SURVEY 8d: transcendental / vector issue rate); valu_issue = SQ_INSTS_VALU of the committed PMC pass "
                  "over this run's kernel time, against one wave instruction per SIMD per 4 cycles",
          "evals_per_s": evals / (kern_ms * 1e-3)}
-    if insts is not None and nrows == C5_ROWS_PER_RANK:
+    if insts is not None and (nrows, K) in ((C5_ROWS_PER_RANK, C5_GROUPS), (1_000_000, 256)):
         # SQ_INSTS_VALU counts wave instructions; the roof is one per SIMD every 4 cycles
         r["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "achieved": insts / (kern_ms * 1e-3),
                            "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
@@ -253,7 +253,8 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)   # default hp mu=0,kappa=1,sigmasq=1,nu=1
     st.accumulate(view, z)                                   # suff-stats from the true components
     # the [N, K] matrix is caller-owned; where the driver places it decides between ~5.6 and ~7.0 TB/s for the same
-    # kernel (profiles/r02_placement_study.txt), so the library offers a probed allocation: the best of a dozen
+    # kernel (profiles/r02_placement_study.txt), so the library offers a probed allocation: the best of two dozen
+    # candidates held side by side (24 GB for a moment, ~60 ms, before anything is timed)
     placement = {"allocator": "torch.empty"}
     if a.no_probe_alloc or a.probe_alloc <= 1:
         out = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -334,6 +335,7 @@ def c2_sweep(a, torch, common_amd, ctx, st, view, z):
     kern_ms, _ = sweep_kernel_ms(torch, st, view, zs)
     return {"metric": "Gibbs-sweep rows/sec", "value": N / (wall_ms * 1e-3), "unit": "rows/s",
             "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1", "kernel_avg_ms": kern_ms,
+            "roofline": sweep_roofline(N, st.K, kern_ms, "k_sweep_nich1"),
             "includes": "leave-one-out score + CRP prior + sample (fused, nothing materialised), accumulate, "
                         "commit + prepare; one rank: no exchange (msc_sweep_step)"}
 

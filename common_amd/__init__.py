@@ -8,9 +8,9 @@ loudly when the HIP library or a gfx950 device is missing (there is no CPU path)
 """
 from ._lib import (ACC_NO_COMMIT, ACC_RESET, ACC_SUBTRACT, BB, BBNC, BNB, DD, DM, GP, NICH, NIW, NOOP,
                    SCORE_CRP_PRIOR, MicroscopesHipError, EXPORTS, LIB_PATH, load)
-from .runtime import Context, DataView, RelationView, State, pack_hp, runtime_types_of, ss_dtype, type_of_numpy
+from .runtime import Context, DataView, RelationView, SparseRelationView, State, pack_hp, runtime_types_of, ss_dtype, type_of_numpy
 from . import dist, models
 
-__all__ = ["Context", "DataView", "RelationView", "State", "BNB", "DM", "models", "dist", "load", "MicroscopesHipError", "BB", "BBNC", "GP", "DD",
+__all__ = ["Context", "DataView", "RelationView", "SparseRelationView", "State", "BNB", "DM", "models", "dist", "load", "MicroscopesHipError", "BB", "BBNC", "GP", "DD",
            "NICH", "NIW", "NOOP", "pack_hp", "ss_dtype", "runtime_types_of", "type_of_numpy",
            "EXPORTS", "LIB_PATH", "SCORE_CRP_PRIOR", "ACC_RESET", "ACC_SUBTRACT", "ACC_NO_COMMIT"]

@@ -476,6 +476,8 @@ class RelationView(object):
     def __init__(self, ctx, array):
         if array is None or array.ndim < 1:
             raise ValueError("need an N-d array")
+        if any(int(d) == 0 for d in array.shape):
+            raise ValueError("empty dims not allowed")              # relation/_dataview.pyx:33-34
         self.ctx = ctx
         self.shape = tuple(int(s) for s in array.shape)
         data = np.ascontiguousarray(np.ma.getdata(array)).reshape(-1)
@@ -527,4 +529,74 @@ class RelationView(object):
         L.check(self.ctx.lib.msc_relation_slice_scores(self.ctx._h, C.c_void_p(scores.data_ptr()), scores.stride(0), nd, shape, dim,
                                                        None, None, C.c_void_p(off.data_ptr()), int(ngroups[dim]), stride,
                                                        self.shape[dim], C.c_void_p(out.data_ptr()), out.stride(0)))
+        return out
+
+
+class SparseRelationView(object):
+    """A sparse 2-D relation (scipy.sparse matrix) on the device -- microscopes/common/relation/dataview.pyx
+    sparse_2d_dataview over compressed_2darray (relation/dataview.hpp:420-578): only the stored entries are cells, in CSR
+    order; their (row, column) positions travel with them.  Same operations as RelationView."""
+
+    def __init__(self, ctx, rep):
+        rows, cols = rep.shape
+        if rows <= 0 or cols <= 0:
+            raise ValueError("both dimensions must be positive")
+        csr = rep.tocsr()
+        csr.sort_indices()
+        self.ctx = ctx
+        self.shape = (int(rows), int(cols))
+        self._csr = csr
+        nnz = int(csr.nnz)
+        rec = np.zeros(nnz, dtype=[("f0", csr.data.dtype)])
+        rec["f0"] = csr.data
+        self.cells = DataView.from_recarray(ctx, rec) if nnz else None
+        row_of = np.repeat(np.arange(rows, dtype=np.uint32), np.diff(csr.indptr))
+        pos = np.stack([row_of, csr.indices.astype(np.uint32)], axis=1)
+        dev = ctx.torch_device
+        self._pos = torch.from_numpy(np.ascontiguousarray(pos).view(np.int32).reshape(-1).copy()).to(dev)   # uint32 pairs
+        # slices: rows of the CSR (dimension 0) and of its transpose (dimension 1), as cell ids
+        order = np.argsort(csr.indices, kind="stable").astype(np.int32)
+        colptr = np.concatenate([[0], np.cumsum(np.bincount(csr.indices, minlength=cols))]).astype(np.int32)
+        self._seg = [torch.from_numpy(csr.indptr.astype(np.int32).copy()).to(dev), torch.from_numpy(colptr).to(dev)]
+        self._ids = [torch.arange(nnz, dtype=torch.int32, device=dev), torch.from_numpy(order).to(dev)]
+
+    def tocsr(self):
+        return self._csr
+
+    def nnz(self):
+        return int(self._csr.nnz)
+
+    def blocks(self, zs, ngroups):
+        if len(zs) != 2 or len(ngroups) != 2:
+            raise ValueError("one assignment vector and one cluster count per dimension")
+        for z, n in zip(zs, self.shape):
+            if z.dtype != torch.int32 or z.numel() != n or not z.is_contiguous():
+                raise ValueError("assignments must be contiguous int32 tensors of the dimension's length")
+        out = torch.empty(max(self.nnz(), 1), dtype=torch.int32, device=self.ctx.torch_device)
+        shape = (C.c_uint64 * 2)(*self.shape)
+        zp = (C.c_void_p * 2)(*[z.data_ptr() for z in zs])
+        kg = (C.c_uint32 * 2)(*[int(k) for k in ngroups])
+        L.check(self.ctx.lib.msc_relation_blocks(self.ctx._h, 2, shape, zp, kg, C.c_void_p(self._pos.data_ptr()), self.nnz(),
+                                                 C.c_void_p(out.data_ptr())))
+        return out[:self.nnz()]
+
+    def slice_offsets(self, zs, ngroups, dim):
+        zs = list(zs)
+        zs[dim] = torch.zeros(self.shape[dim], dtype=torch.int32, device=self.ctx.torch_device)
+        return self.blocks(zs, ngroups)
+
+    def slice_scores(self, scores, off, dim, ngroups):
+        """out[e, g] = sum over the stored cells of row / column e of the cell's score against block (g, the other
+        entity's cluster) -- msc_relation_slice_scores with the CSR rows (dim 0) or the transpose's (dim 1)"""
+        if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1 or scores.shape[0] != self.nnz():
+            raise ValueError("scores must be a row-major float32 [nnz, nblocks] tensor")
+        if off.dtype != torch.int32 or off.numel() != self.nnz() or not off.is_contiguous():
+            raise ValueError("off must be a contiguous int32 tensor of nnz entries")
+        stride = int(ngroups[1]) if dim == 0 else 1
+        out = torch.empty((self.shape[dim], int(ngroups[dim])), dtype=torch.float32, device=self.ctx.torch_device)
+        shape = (C.c_uint64 * 2)(*self.shape)
+        L.check(self.ctx.lib.msc_relation_slice_scores(
+            self.ctx._h, C.c_void_p(scores.data_ptr()), scores.stride(0), 2, shape, dim, C.c_void_p(self._seg[dim].data_ptr()),
+            C.c_void_p(self._ids[dim].data_ptr()), C.c_void_p(off.data_ptr()), int(ngroups[dim]), stride, self.shape[dim],
+            C.c_void_p(out.data_ptr()), out.stride(0)))
         return out

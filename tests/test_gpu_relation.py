@@ -155,3 +155,45 @@ def test_slice_scores_are_irms_per_entity_candidate_scores(gpu_ctx, family, shap
         assert rel_err(got, want).max() <= 1e-6
     with pytest.raises(common_amd.MicroscopesHipError):
         view.slice_scores(scores[:, :2].contiguous(), view.slice_offsets(zt, Ks, 0), 0, Ks)   # score rows shorter than the blocks
+
+
+def test_sparse_2d_relation_equals_the_dense_masked_one(gpu_ctx):
+    """sparse_2d_dataview (relation/dataview.pyx; compressed_2darray): the stored entries of a scipy.sparse matrix as
+    cells -- block suff-stats, per-cell scores and both dimensions' slice reductions equal those of the dense relation
+    with the absent entries masked"""
+    import scipy.sparse as sp
+    import common_amd
+    rng = np.random.default_rng(21)
+    n0, n1, K0, K1 = 41, 29, 5, 3
+    present = rng.random((n0, n1)) < 0.35
+    present[7, :] = False                                       # an empty row and an empty column
+    present[:, 4] = False
+    vals = rng.poisson(2.5, (n0, n1)).astype(np.uint32) + 1     # (stored zeros would be dropped by scipy)
+    m = sp.csr_matrix(np.where(present, vals, 0).astype(np.uint32))
+    sview = common_amd.SparseRelationView(gpu_ctx, m)
+    dview = common_amd.RelationView(gpu_ctx, np.ma.masked_array(vals, mask=~present))
+    assert sview.nnz() == int(present.sum()) and sview.shape == (n0, n1)
+    dev = gpu_ctx.torch_device
+    zs = [rng.integers(0, K0, n0).astype(np.int32), rng.integers(0, K1, n1).astype(np.int32)]
+    zs[1][3] = -1
+    zt = [torch.from_numpy(z).to(dev) for z in zs]
+    Ks = [K0, K1]
+    zc_s, zc_d = sview.blocks(zt, Ks), dview.blocks(zt, Ks)
+    cell_of = np.flatnonzero(present.reshape(-1))               # CSR order = row-major order of the present cells
+    assert np.array_equal(zc_s.cpu().numpy(), zc_d.cpu().numpy()[cell_of])
+    st_s = common_amd.State(gpu_ctx, [(orc.GP, 0)], K0 * K1)
+    st_d = common_amd.State(gpu_ctx, [(orc.GP, 0)], K0 * K1)
+    st_s.accumulate(sview.cells, zc_s)
+    st_d.accumulate(dview.cells, zc_d)
+    a, b = st_s.get_ss(0), st_d.get_ss(0)
+    assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["sum"], b["sum"])
+    sc_s, sc_d = st_s.score_value(sview.cells), st_d.score_value(dview.cells)
+    assert rel_err(sc_s.cpu().numpy(), sc_d.cpu().numpy()[cell_of]).max() <= TOL
+    for dim in (0, 1):
+        got = sview.slice_scores(sc_s, sview.slice_offsets(zt, Ks, dim), dim, Ks).cpu().numpy()
+        want = dview.slice_scores(sc_d, dview.slice_offsets(zt, Ks, dim), dim, Ks).cpu().numpy()
+        assert got.shape == (m.shape[dim], Ks[dim])
+        assert rel_err(got, want).max() <= 2e-6
+    assert np.all(sview.slice_scores(sc_s, sview.slice_offsets(zt, Ks, 0), 0, Ks).cpu().numpy()[7] == 0.0)   # the empty row
+    with pytest.raises(ValueError):
+        common_amd.RelationView(gpu_ctx, np.zeros((3, 0)))      # empty dims not allowed (relation/_dataview.pyx:33-34)
