@@ -90,9 +90,13 @@ extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
   return MSC_OK;
 }
 
+static void vmm_free(msc_context::VmmAlloc &a);
+
 extern "C" int msc_context_destroy(msc_context *ctx) {
   if (!ctx) return MSC_OK;
   (void)hipSetDevice(ctx->device);
+  for (auto &a : ctx->vmm) vmm_free(a);
+  ctx->vmm.clear();
   if (ctx->mailbox_host) (void)hipHostFree(ctx->mailbox_host);
   if (ctx->record_stream) (void)hipStreamDestroy(ctx->record_stream);
   delete ctx;
@@ -125,6 +129,63 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
   *out = p;
   return MSC_OK;
 }
+// One candidate of msc_device_alloc_probed: nbytes of device memory mapped from 32 MiB physical chunks that are created
+// one by one (hipMemCreate) and mapped side by side into one reserved VA range.  Measured
+// (tools/microbench/placement_stitch.hip, four rounds): such buffers take the C2 store stream at 6.2-7.0 TB/s where
+// hipMalloc'ed ones of the same process take it at 5.3-6.2 -- whatever the chunk size (2 / 32 / 256 MiB) and mapping
+// order.  Returns false (nothing allocated) when the virtual-memory API is not usable.
+static bool vmm_alloc(int device, size_t nbytes, msc_context::VmmAlloc *out) {
+  const size_t chunk = 32u << 20;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0 || chunk % gran != 0) {
+    (void)hipGetLastError();
+    return false;
+  }
+  msc_context::VmmAlloc a;
+  const size_t n = (std::max<size_t>(nbytes, 1) + chunk - 1) / chunk;
+  a.size = n * chunk;
+  a.va = nullptr;
+  if (hipMemAddressReserve(&a.va, a.size, 2u << 20, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  bool ok = true;
+  size_t mapped = 0;
+  for (size_t i = 0; i < n && ok; i++) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+    a.handles.push_back(h);
+    if (hipMemMap(static_cast<char *>(a.va) + i * chunk, chunk, 0, h, 0) != hipSuccess) { ok = false; break; }
+    mapped = i + 1;
+  }
+  if (ok) {
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = hipMemSetAccess(a.va, a.size, &acc, 1) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    if (mapped) (void)hipMemUnmap(a.va, mapped * chunk);
+    for (auto h : a.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(a.va, a.size);
+    return false;
+  }
+  *out = a;
+  return true;
+}
+static void vmm_free(msc_context::VmmAlloc &a) {
+  (void)hipMemUnmap(a.va, a.size);
+  for (auto h : a.handles) (void)hipMemRelease(h);
+  (void)hipMemAddressFree(a.va, a.size);
+  a.handles.clear();
+  a.va = nullptr;
+}
+
 extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out,
                                        float *rates_gbps, uint32_t *chosen) {
   MSC_REQUIRE(ctx && out, "null argument");
@@ -134,23 +195,33 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
     return fail(MSC_EINVAL, "msc_device_alloc_probed waits for the device: not on a capturing stream");
-  std::vector<void *> bufs;
+  static const bool no_vmm = std::getenv("MSC_ALLOC_NO_VMM") != nullptr;       // (A/B knob: plain hipMalloc candidates)
+  struct Cand { void *p; bool vmm; msc_context::VmmAlloc v; };
+  std::vector<Cand> bufs;
   std::vector<float> rate;
   auto release = [&](int keep) {
-    for (size_t i = 0; i < bufs.size(); i++)
-      if ((int)i != keep) (void)hipFree(bufs[i]);
+    for (size_t i = 0; i < bufs.size(); i++) {
+      if ((int)i == keep) continue;
+      if (bufs[i].vmm) vmm_free(bufs[i].v);
+      else (void)hipFree(bufs[i].p);
+    }
   };
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MSC_EHIP, "hipEventCreate failed");
   int rc = MSC_OK;
   const int reps = nbytes >= (256u << 20) ? 3 : 8;
+  const bool want_vmm = !no_vmm && nbytes >= (64u << 20);                      // small buffers: not worth 32 MiB chunks
   for (uint32_t i = 0; i < candidates; i++) {
-    void *p = nullptr;
-    if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) {        // out of memory: settle for what there is
+    Cand c{nullptr, false, {}};
+    if (want_vmm && vmm_alloc(ctx->device, nbytes, &c.v)) {
+      c.p = c.v.va;
+      c.vmm = true;
+    } else if (hipMalloc(&c.p, nbytes ? nbytes : 1) != hipSuccess) {           // out of memory: settle for what there is
       (void)hipGetLastError();
       break;
     }
-    bufs.push_back(p);
+    bufs.push_back(c);
+    void *p = c.p;
     hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);          // (zero-filled, like msc_device_alloc)
     if (e == hipSuccess && launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
     if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
@@ -166,17 +237,19 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (rc != MSC_OK || bufs.empty() || rate.size() != bufs.size()) {
+    (void)hipStreamSynchronize(ctx->stream);
     release(-1);
-    return rc != MSC_OK ? rc : fail(MSC_ENOMEM, "hipMalloc of %zu bytes failed", nbytes);
+    return rc != MSC_OK ? rc : fail(MSC_ENOMEM, "allocation of %zu bytes failed", nbytes);
   }
   int best = 0;
   for (size_t i = 1; i < rate.size(); i++)
     if (rate[i] > rate[best]) best = (int)i;
   release(best);
+  if (bufs[best].vmm) ctx->vmm.push_back(bufs[best].v);
   if (rates_gbps)
     for (uint32_t i = 0; i < candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
   if (chosen) *chosen = (uint32_t)best;
-  *out = bufs[best];
+  *out = bufs[best].p;
   return MSC_OK;
 }
 extern "C" int msc_device_free(msc_context *ctx, void *dev) {
@@ -184,6 +257,12 @@ extern "C" int msc_device_free(msc_context *ctx, void *dev) {
   if (!dev) return MSC_OK;
   MSC_HIP(hipSetDevice(ctx->device));
   MSC_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ctx->vmm.size(); i++)
+    if (ctx->vmm[i].va == dev) {                          // a probed buffer mapped from chunks
+      vmm_free(ctx->vmm[i]);
+      ctx->vmm.erase(ctx->vmm.begin() + i);
+      return MSC_OK;
+    }
   MSC_HIP(hipFree(dev));
   return MSC_OK;
 }

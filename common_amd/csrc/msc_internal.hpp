@@ -237,6 +237,10 @@ struct msc_context {
   // a stream of the library's own on which sweep steps are recorded (the caller's may be the null stream, which
   // cannot capture); nothing ever executes on it
   hipStream_t record_stream = nullptr;
+  // buffers msc_device_alloc_probed mapped from separately created physical chunks (hipMemCreate + hipMemMap); freed
+  // through msc_device_free
+  struct VmmAlloc { void *va; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
+  std::vector<VmmAlloc> vmm;
   // pinned, device-mapped mailbox for msc_value_op_single
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;

@@ -98,8 +98,9 @@ int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out_dev);
  * A large, long-lived output buffer (the [N, K] score matrix) placed where the write stream runs fastest: the same
  * 1 GB stream takes 5.6 TB/s into most allocations and 7.0 TB/s into some, decided by where the driver put the pages
  * (profiles/r02_placement_study.txt), and no allocator argument selects that.  Up to `candidates` buffers are
- * allocated side by side, each is stream-filled a few times on the context's stream, the fastest is returned and the
- * rest are freed.  SYNCHRONOUS (about 1 ms per candidate and GB).  rates_gbps (nullable, `candidates` floats) receives
+ * allocated side by side (each mapped from 32 MiB physical chunks through the virtual-memory API; hipMalloc where
+ * that is unavailable or the buffer is small -- both show both regimes), each is stream-filled a few times on the
+ * context's stream, the fastest is returned and the rest are freed.  SYNCHRONOUS (about 1 ms per candidate and GB).  rates_gbps (nullable, `candidates` floats) receives
  * every candidate's fill rate, *chosen (nullable) the index kept.  Free with msc_device_free.
  */
 int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out_dev,
