@@ -141,3 +141,26 @@ def test_probed_allocation_is_zero_filled_usable_and_outlives_its_handle(gpu_ctx
     assert torch.equal(t[5], keep)                      # the owner rides on the tensor's storage
     with pytest.raises(common_amd.MicroscopesHipError):
         gpu_ctx.alloc_probed((4,), torch.float32, candidates=0)
+
+
+def test_score_tune_is_explicit_and_changes_no_value(gpu_ctx):
+    """msc_score_tune settles the single-nich pass's launch shape for a buffer (synchronously, on request); the scores a
+    pass writes do not depend on the shape, and states that do not take that kernel report -1"""
+    import common_amd
+    N, K = 300_000, 256                                     # 300k x 256 scores: large enough for every shape to differ
+    g = torch.Generator(device=gpu_ctx.torch_device)
+    g.manual_seed(5)
+    x = torch.randn(N, generator=g, device=gpu_ctx.torch_device)
+    z = torch.randint(0, K, (N,), generator=g, device=gpu_ctx.torch_device, dtype=torch.int32)
+    view = common_amd.DataView.from_tensors(gpu_ctx, [x])
+    st = common_amd.State(gpu_ctx, [(common_amd.NICH, 0)], K)
+    st.accumulate(view, z)
+    out = torch.empty((N, K), dtype=torch.float32, device=gpu_ctx.torch_device)
+    before = st.score_value(view).clone()
+    shape, ms = st.score_tune(view, out)
+    assert 0 <= shape < 8 and ms > 0
+    assert torch.equal(st.score_value(view, out=out), before)            # the tuned buffer
+    assert torch.equal(st.score_value(view), before)                     # another buffer of the same size (fallback entry)
+    st2 = common_amd.State(gpu_ctx, [(common_amd.NICH, 0), (common_amd.BB, 0)], K)
+    view2 = common_amd.DataView.from_tensors(gpu_ctx, [x, x > 0])
+    assert st2.score_tune(view2, out)[0] == -1                           # the tile kernel has no shapes to settle
