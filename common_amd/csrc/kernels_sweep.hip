@@ -283,6 +283,250 @@ __global__ __launch_bounds__(256, G == 16 ? 3 : 1) void k_sweep_nich1(const Feat
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_nich1_t<G>: the same step with the draw TRANSPOSED.  In k_sweep_nich1 every row pays a cross-lane prefix scan
+// (six dependent DPP steps with their wait states), a ballot / first-hit / broadcast chain and the own-group patch: ~50
+// of its 94 vector instructions at K = 256.  Here a wave takes 32 rows and
+//   1. streams them past its groups exactly as before, but keeps only each lane's SUM of the row's unnormalised
+//      probabilities: one ds_write_b32 per row (row r's 64 lane sums lie side by side, rows padded to 65 words);
+//   2. then lane r finishes row r on its own: it recomputes the entries of the lane that holds the row's own group with
+//      the leave-one-out value in place (the streaming pass knows nothing of own groups), adds up the row's 64 lane sums
+//      in lane order (eight block sums kept), throws the dart and finds the block, then the lane, that reaches it;
+//   3. and recomputes that one lane's G entries to find the group.
+// Steps 2 and 3 cost a few hundred instructions per lane -- per 32 rows.  Same CDF order (lane by lane, entry by entry),
+// same uniforms, same side paths (masked rows, rows that are their group's only member); a row whose total leaves the
+// comfortable float range is redone by the wave with the exact maximum, as before.
+// ---------------------------------------------------------------------------
+constexpr int kTRows = 32;            // rows of a wave's chunk (lanes 0..31 finish them)
+constexpr int kTPad = 65;             // words per row of lane sums: lane r reading word j hits bank (r + j) % 64
+
+template <int G>
+struct NichConsts {
+  float mh[G], ml[G], c0s[G], c1[G], c2[G];
+  unsigned emask;                     // bit j: group G l + j exists and is empty
+};
+// one row against group k from memory (what the finishing lane needs of a lane that is not its own): unnormalised log2
+// probability, bound subtracted.  masked -> the prior alone; single -> an empty group's prior is le1 instead of le0
+struct NichRowCtx {
+  const float *tab, *crp;
+  uint32_t K, kpad;
+  float le0, le1, dle, bound, x;
+  bool masked, single;
+};
+MSC_DEV float nich_entry_log2(const NichRowCtx &c, uint32_t k) {
+  constexpr float kLog2e = 1.44269504088896340736f;
+  const size_t kc = k < c.kpad ? k : 0;
+  const float lc = c.crp[kc];
+  const bool empty = __builtin_isinf(lc);
+  float s;
+  if (c.masked) {
+    s = (empty ? (c.single ? c.le1 : c.le0) : lc) * kLog2e - c.bound;
+  } else {
+    const float c0s = (c.tab[(size_t)NICH_C0 * c.kpad + kc] + (empty ? c.le0 : lc)) * kLog2e - c.bound;
+    s = nich_eval_log2(c.x, c.tab[(size_t)NICH_MU_HI * c.kpad + kc], c.tab[(size_t)NICH_MU_LO * c.kpad + kc], c0s,
+                       c.tab[(size_t)NICH_C1 * c.kpad + kc], c.tab[(size_t)NICH_C2 * c.kpad + kc]);
+    s += (c.single && empty) ? c.dle : 0.f;
+  }
+  return k < c.K ? s : -INFINITY;
+}
+// the streaming lanes' version of the same for the rare rows (masked / only member of their group / redone)
+template <int G>
+MSC_DEV void nich_row_scores(float (&s)[G], const NichConsts<G> &c, float x, bool masked, bool single, float dle, int own,
+                             float sl, const float *__restrict__ crp, uint32_t K, uint32_t kpad, uint32_t l, float le0,
+                             float le1, float bound) {
+  constexpr float kLog2e = 1.44269504088896340736f;
+#pragma unroll
+  for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, c.mh[j], c.ml[j], c.c0s[j], c.c1[j], c.c2[j]);
+  if (masked) {
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      const uint32_t k = (uint32_t)G * l + j;
+      const float lc = crp[k < kpad ? k : 0];
+      s[j] = (k >= K) ? -INFINITY : (__builtin_isinf(lc) ? (single ? le1 : le0) : lc) * kLog2e - bound;
+    }
+  } else if (single) {
+#pragma unroll
+    for (int j = 0; j < G; j++) s[j] += ((c.emask >> j) & 1u) ? dle : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < G; j++)
+    if (j == own) s[j] = sl;
+}
+
+constexpr int kTCst = 5;              // words per group of the block's LDS copy of the constants (odd: random groups spread over the banks)
+enum { TC_MH = 0, TC_ML, TC_C0, TC_C1, TC_C2 };
+
+template <int G>
+__global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
+                                                        uint64_t row0, uint64_t nrows, uint64_t row_id0,
+                                                        int32_t *z, const float *__restrict__ crp,
+                                                        const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  __shared__ float lsum[4][kTRows * kTPad];
+  __shared__ float cst[64 * G * kTCst];       // every group's constants, for the finishing lanes (log2 units, prior folded)
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  const FeatDesc fd = feats[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *mysum = lsum[wave];
+  constexpr float kLog2e = 1.44269504088896340736f;
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const bool any_empty = !__builtin_isinf(le0);
+  const float dle = any_empty ? (le1 - le0) * kLog2e : 0.f;
+  for (uint32_t k = threadIdx.x; k < 64u * G; k += 256u) {
+    const uint32_t kc = k < kpad ? k : 0u;
+    const float lc = crp[kc];
+    float *c = cst + k * kTCst;
+    c[TC_MH] = fd.tab[NICH_MU_HI * kpad + kc];
+    c[TC_ML] = fd.tab[NICH_MU_LO * kpad + kc];
+    c[TC_C0] = k < K ? (fd.tab[NICH_C0 * kpad + kc] + (__builtin_isinf(lc) ? le0 : lc)) * kLog2e : -INFINITY;
+    c[TC_C1] = fd.tab[NICH_C1 * kpad + kc];
+    c[TC_C2] = fd.tab[NICH_C2 * kpad + kc];
+  }
+  __syncthreads();
+  // the wave-uniform bound that stands in for the row maximum: no score exceeds its c0' (log1p >= 0); 16 bits of
+  // headroom for what may (own-group values, masked rows, a singleton's empties), and the total is checked
+  NichConsts<G> mine;
+  mine.emask = 0u;
+  float bound = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    const uint32_t k = (uint32_t)(G * lane + j);
+    const float *c = cst + k * kTCst;
+    mine.mh[j] = c[TC_MH], mine.ml[j] = c[TC_ML], mine.c0s[j] = c[TC_C0], mine.c1[j] = c[TC_C1], mine.c2[j] = c[TC_C2];
+    if (k < K && __builtin_isinf(crp[k])) mine.emask |= 1u << j;
+    bound = fmaxf(bound, mine.c0s[j]);
+  }
+  bound = wave_max(bound) + 16.f;
+#pragma unroll
+  for (int j = 0; j < G; j++) mine.c0s[j] -= bound;
+  const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
+  // every wave takes one contiguous range of rows, the same number (+-1) for all: no wave runs a chunk longer than another
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, nwaves = (uint64_t)gridDim.x * 4;
+  const uint64_t per = nrows / nwaves, extra = nrows % nwaves;
+  const uint64_t rbeg = wave_id * per + (wave_id < extra ? wave_id : extra), rend = rbeg + per + (wave_id < extra ? 1 : 0);
+  for (uint64_t rb = rbeg; rb < rend; rb += kTRows) {
+    const int nr = (int)((rend - rb) < (uint64_t)kTRows ? (rend - rb) : (uint64_t)kTRows);
+    const bool has_row = lane < nr;
+    // ---- per-row setup, lane r <-> row r ----
+    const float xv = has_row ? xcol[rb + lane] : 0.0f;
+    const int gz = has_row ? z[rb + lane] : -1;
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    const bool my_mask = fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0;
+    const unsigned long long mbits = __builtin_amdgcn_ballot_w64(my_mask);
+    float sloo = 0.f;
+    bool single = false;
+    if (gz >= 0) {
+      // leave-one-out score + prior of the row's own group, in double (what k_loo_own does for the other kernels)
+      const float lm1 = crp[kpad + gz];
+      single = __builtin_isinf(lm1);                          // the row is its group's only member
+      double s = single ? (double)le1 + (double)crp[2 * (size_t)kpad + 3] : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + gz];
+      if (!my_mask) s += nich_loo_tab(fd.hp, fd.loo64 + gz, kpad, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
+      sloo = (float)s * kLog2e - bound;
+    }
+    const bool my_single = single && any_empty;               // (with no other empty group nothing moves)
+    const unsigned long long singles = __builtin_amdgcn_ballot_w64(my_single);
+    const unsigned long long odd = mbits | singles;
+    // ---- 1. stream the rows past the groups: lane sums only ----
+    for (int r = 0; r < nr; r++) {
+      const float x = lane_bcast(xv, r);
+      float s[G];
+      if ((odd >> r) & 1ull) {                               // (wave-uniform, rare)
+        nich_row_scores<G>(s, mine, x, ((mbits >> r) & 1ull) != 0, ((singles >> r) & 1ull) != 0, dle, -1, 0.f, crp, K, kpad,
+                           (uint32_t)lane, le0, le1, bound);
+      } else {
+#pragma unroll
+        for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, mine.mh[j], mine.ml[j], mine.c0s[j], mine.c1[j], mine.c2[j]);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < G; j++) sum += __builtin_amdgcn_exp2f(s[j]);     // exp2(-inf) = 0 beyond K
+      mysum[r * kTPad + lane] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();                          // (LDS traffic of one wave is in order; this stops the compiler)
+    // ---- 2. lane r finishes row r ----
+    int pick = gz;
+    bool redo = false;
+    if (has_row) {
+      float *row = mysum + lane * kTPad;
+      const int own_lane = gz >= 0 ? gz / G : -1;
+      const bool plain = !(my_mask || my_single);             // (the others read the prior from memory)
+      const NichRowCtx rc = {fd.tab, crp, K, kpad, le0, le1, dle, bound, xv, my_mask, my_single};
+      // group k for this row: from the block's constants; the row's own group is its leave-one-out value
+      auto entry = [&](int k) -> float {
+        const float *c = cst + k * kTCst;
+        float s = nich_eval_log2(xv, c[TC_MH], c[TC_ML], c[TC_C0] - bound, c[TC_C1], c[TC_C2]);
+        if (!plain) s = nich_entry_log2(rc, (uint32_t)k);
+        return __builtin_amdgcn_exp2f(k == gz ? sloo : s);
+      };
+      if (own_lane >= 0) {                                    // the own group's lane, with the leave-one-out value in place
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < G; j++) sum += entry(G * own_lane + j);
+        row[own_lane] = sum;
+      }
+      float blk[8], total = 0.f;                              // eight blocks of eight lanes, summed in lane order
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t += row[8 * b + i];
+        blk[b] = t;
+        total += t;
+      }
+      if (total > 0x1p-60f && total < 0x1p100f) {             // (false for NaN too)
+        const float dart = u01 * total;
+        // the running sum is monotone: the first block, lane, entry that reaches the dart is found by stepping over
+        // those that do not (util.hpp:145-156; rounding may let the dart fall off the end: the last one then)
+        float c0 = 0.f;
+        int b0 = 0;
+#pragma unroll
+        for (int b = 0; b < 7; b++) {
+          const bool miss = b0 == b && c0 + blk[b] < dart;
+          c0 = miss ? c0 + blk[b] : c0;
+          b0 += miss ? 1 : 0;
+        }
+        int hl = 8 * b0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const float v = row[8 * b0 + i];
+          const bool miss = hl == 8 * b0 + i && c0 + v < dart;
+          c0 = miss ? c0 + v : c0;
+          hl += miss ? 1 : 0;
+        }
+        // ---- 3. the entries of lane hl ----
+        int j0 = 0;
+#pragma unroll
+        for (int j = 0; j < G - 1; j++) {
+          const float v = entry(G * hl + j);
+          const bool miss = j0 == j && c0 + v < dart;
+          c0 = miss ? c0 + v : c0;
+          j0 += miss ? 1 : 0;
+        }
+        const int k = G * hl + j0;
+        pick = k < (int)K ? k : (int)K - 1;
+      } else {
+        redo = true;
+      }
+    }
+    // rows whose total left the float range (an outlier thousands of bits below the bound): the wave redoes them one
+    // by one with the exact maximum
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(redo);
+    while (todo != 0ull) {
+      const int r = (int)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const float x = lane_bcast(xv, r);
+      const int g = lane_bcast(gz, r);
+      float s[G];
+      nich_row_scores<G>(s, mine, x, ((mbits >> r) & 1ull) != 0, ((singles >> r) & 1ull) != 0, dle,
+                         (g >= 0 && lane == g / G) ? g % G : -1, lane_bcast(sloo, r), crp, K, kpad, (uint32_t)lane, le0, le1, bound);
+      const int p = sample_from_scores<G, true, false>(s, lane_bcast(u01, r), lane, K);
+      if (lane == r) pick = p;
+    }
+    if (has_row) z[rb + lane] = pick;
+    __builtin_amdgcn_wave_barrier();                          // (the next chunk overwrites the lane sums)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // One niw feature of small dimension, K <= 64 -- a Gaussian mixture on low-dimensional vectors, the textbook use of
 // the family: the whole Gibbs step fused like k_sweep_nich1.  A lane keeps one group (lower triangle of W_k, W_k mu_k
 // and the constants in registers), the rows of a chunk stream past as wave-uniform values, and q = |W_k (x - mu_k)|^2
@@ -827,6 +1071,24 @@ static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int wa
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
+  // enough rows to give every SIMD several 32-row chunks: the transposed draw (k_sweep_nich1_t)
+  static const int which = [] { const char *e = std::getenv("MSC_SWEEP_NICH1"); return e ? std::atoi(e) : 0; }();   // 1: old, 2: new, always
+  const bool transposed = which == 2 || (which != 1 && nrows >= (uint64_t)num_cus * 4 * 4 * kTRows);
+  if (transposed && K <= 1024) {
+    const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, 16);
+    const dim3 gridt((unsigned)gxt), blockt(256);
+    if (K <= 64)
+      hipLaunchKernelGGL(k_sweep_nich1_t<1>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+    else if (K <= 128)
+      hipLaunchKernelGGL(k_sweep_nich1_t<2>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+    else if (K <= 256)
+      hipLaunchKernelGGL(k_sweep_nich1_t<4>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+    else if (K <= 512)
+      hipLaunchKernelGGL(k_sweep_nich1_t<8>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+    else
+      hipLaunchKernelGGL(k_sweep_nich1_t<16>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   // 64 rows per wave visit once there are enough rows for ~8 waves per SIMD; fewer rows: halve the visit down to 4
   int chunk_rows = 64;
   while (chunk_rows > 4 && (nrows + chunk_rows - 1) / chunk_rows < (uint64_t)num_cus * 32) chunk_rows >>= 1;
