@@ -1072,7 +1072,9 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   // enough rows to give every SIMD several 32-row chunks: the transposed draw (k_sweep_nich1_t)
-  static const int which = [] { const char *e = std::getenv("MSC_SWEEP_NICH1"); return e ? std::atoi(e) : 0; }();   // 1: old, 2: new, always
+  // MSC_SWEEP_NICH1 = 1 / 2 pins the row-at-a-time / the transposed kernel whatever the size (tests, A/B timing)
+  const char *pin = std::getenv("MSC_SWEEP_NICH1");
+  const int which = pin ? std::atoi(pin) : 0;
   const bool transposed = which == 2 || (which != 1 && nrows >= (uint64_t)num_cus * 4 * 4 * kTRows);
   if (transposed && K <= 1024) {
     const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, 16);

@@ -73,7 +73,9 @@ def test_masked_values_add_nothing_to_scores(gpu_ctx, specs):
     assert rel_err(got, _oracle(feats, masks, fs, z)).max() <= TOL
 
 
-def test_fully_masked_row_scores_zero_and_samples_from_the_prior(gpu_ctx):
+@pytest.mark.parametrize("pin", ["1", "2"])
+def test_fully_masked_row_scores_zero_and_samples_from_the_prior(gpu_ctx, monkeypatch, pin):
+    monkeypatch.setenv("MSC_SWEEP_NICH1", pin)          # the row-at-a-time and the transposed single-nich kernel
     import common_amd
     N, K = 20000, 8
     x = np.ma.masked_array(np.zeros(N, dtype=[("f0", np.float32)]), mask=[(True,)] * N)

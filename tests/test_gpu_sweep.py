@@ -42,8 +42,16 @@ def _check_agreement(got, want, scores, seed, sweep_idx, min_agree):
         assert abs(cdf[lo] - u) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, (n, lo, hi, cdf[lo], u)
 
 
-@pytest.mark.parametrize("K", [7, 64, 100, 256, 300, 512, 1000])
-def test_sweep_single_nich_feature_matches_oracle(gpu_ctx, K):
+@pytest.fixture(params=["rowwise", "transposed"])
+def nich1_kernel(request, monkeypatch):
+    """the single-nich sweep has two kernels (k_sweep_nich1: a wave scans one row at a time; k_sweep_nich1_t: lane sums
+    through LDS, one lane finishes one row; the launcher picks by size): run the test through each"""
+    monkeypatch.setenv("MSC_SWEEP_NICH1", {"rowwise": "1", "transposed": "2"}[request.param])
+    return request.param
+
+
+@pytest.mark.parametrize("K", [1, 2, 7, 64, 65, 100, 256, 257, 300, 512, 1000, 1024])
+def test_sweep_single_nich_feature_matches_oracle(gpu_ctx, K, nich1_kernel):
     got, want, scores, _ = _run(gpu_ctx, [(orc.NICH, 0)], 3000, K, seed=11 + K, sweep_idx=3)
     _check_agreement(got, want, scores, 11 + K, 3, 0.998)
 
@@ -69,7 +77,69 @@ def test_sweep_with_niw_feature_takes_the_generic_path(gpu_ctx):
     _check_agreement(got, want, scores, 17, 2, 0.995)
 
 
-def test_sweep_is_a_function_of_seed_sweep_and_global_row(gpu_ctx):
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 63, 64, 65, 1000, 4097])
+def test_sweep_single_nich_row_counts_across_chunk_boundaries(gpu_ctx, N, nich1_kernel):
+    got, want, scores, _ = _run(gpu_ctx, [(orc.NICH, 0)], N, 20, seed=300 + N, sweep_idx=1)
+    _check_agreement(got, want, scores, 300 + N, 1, 0.99 if N > 100 else 1.0)
+
+
+def test_sweep_single_nich_with_singletons_and_unassigned_rows(gpu_ctx, nich1_kernel):
+    """off the main path: rows that are their group's only member (the group becomes empty: every empty group's prior
+    changes for that row) and rows not assigned to any group"""
+    import common_amd
+    N, K, seed, sweep_idx, alpha = 2500, 70, 41, 2, 1.7
+    rng = np.random.default_rng(seed)
+    f = make_feature(orc.NICH, N, K, rng)
+    z = rng.integers(0, 40, N).astype(np.int32)
+    z[rng.choice(N, 20, replace=False)] = np.arange(40, 60)          # twenty singletons; groups 60..69 stay empty
+    z[rng.choice(np.nonzero(z < 40)[0], 100, replace=False)] = -1    # not assigned
+    F = orc.Family(orc.NICH, f["hp"], 0, "f64")
+    ss64 = F.accumulate(K, f["values"], z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of([f]))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, F.hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    st.set_alpha(alpha)
+    st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
+    want, scores = orc.sweep([(F, ss64, f["values"])], K, alpha, z, seed, sweep_idx, "f64", want_scores=True)
+    _check_agreement(zt.cpu().numpy(), want, scores, seed, sweep_idx, 0.995)
+
+
+@pytest.mark.parametrize("N,K", [(3000, 70), (50_000, 256), (20_000, 1000)])
+def test_both_single_nich_kernels_draw_the_same_assignments(gpu_ctx, monkeypatch, N, K):
+    """the two kernels follow the same CDF order with the same uniforms: masked values, singletons, unassigned rows
+    and empty groups included they may differ only where a dart lands within rounding of a step"""
+    import common_amd
+    rng = np.random.default_rng(N + K)
+    f = make_feature(orc.NICH, N, K, rng)
+    used = K - 6
+    z = rng.integers(0, used - 10, N).astype(np.int32)
+    z[rng.choice(N, 10, replace=False)] = np.arange(used - 10, used)  # singletons
+    z[rng.choice(np.nonzero(z < used - 10)[0], N // 20, replace=False)] = -1
+    mask = rng.random(N) < 0.15
+    mask[np.nonzero(z >= used - 10)[0][:4]] = True                    # masked singletons too
+    rec = np.ma.masked_array(np.zeros(N, dtype=[("f0", np.float32)]), mask=[(bool(m),) for m in mask])
+    rec.data["f0"] = f["values"]
+    view = common_amd.DataView.from_recarray(gpu_ctx, rec)
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, orc.Family(orc.NICH, f["hp"], 0, "f64").hp)
+    z0 = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, z0)
+    st.set_alpha(0.9)
+    picks = {}
+    for name, pin in (("rowwise", "1"), ("transposed", "2")):
+        monkeypatch.setenv("MSC_SWEEP_NICH1", pin)
+        zt = z0.clone()
+        st.sweep_assign(view, zt, seed=5, sweep=9)
+        picks[name] = zt.cpu().numpy()
+    a, b = picks["rowwise"], picks["transposed"]
+    assert (a != z).mean() > 0.05                                     # (something was drawn)
+    assert (a == b).mean() >= 0.9995, (a == b).mean()
+    assert np.all(np.abs(a - b)[a != b] <= 1) or (a != b).sum() <= 3  # a step to the neighbouring group, if any
+
+
+def test_sweep_is_a_function_of_seed_sweep_and_global_row(gpu_ctx, nich1_kernel):
     a, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
     b, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=4)
     c, _, _, _ = _run(gpu_ctx, [(orc.NICH, 0)], 2000, 64, seed=21, sweep_idx=5)
@@ -127,7 +197,7 @@ def test_sweep_then_rebuild_tables_gives_suffstats_of_new_assignment(gpu_ctx):
                 assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(1, np.abs(b)))
 
 
-def test_sweep_draws_follow_the_softmax_of_the_scores(gpu_ctx):
+def test_sweep_draws_follow_the_softmax_of_the_scores(gpu_ctx, nich1_kernel):
     """statistical check: one row repeated, many independent uniforms -> empirical = softmax"""
     import common_amd
     rng = np.random.default_rng(3)
@@ -152,7 +222,7 @@ def test_sweep_draws_follow_the_softmax_of_the_scores(gpu_ctx):
     assert np.abs(emp - p).max() < 4 * np.sqrt(0.25 / N) + 1e-3, (emp, p)
 
 
-def test_sweep_rows_far_below_the_score_bound_take_the_exact_maximum(gpu_ctx):
+def test_sweep_rows_far_below_the_score_bound_take_the_exact_maximum(gpu_ctx, nich1_kernel):
     """k_sweep_nich1 normalises with a per-wave upper bound of the scores and falls back to the row's exact maximum
     when that underflows: rows thousands of bits below the bound (outliers), next to ordinary rows in the same wave"""
     import common_amd
