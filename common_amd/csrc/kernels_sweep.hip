@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
   const uint64_t seed = rng[0], sweep = rng[1];
   zero_spans(zero);
   const FeatDesc fd = feats[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform, and known to be)
   float *mysum = lsum[wave];
   constexpr float kLog2e = 1.44269504088896340736f;
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
@@ -403,10 +403,10 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, nwaves = (uint64_t)gridDim.x * 4;
   const uint64_t per = nrows / nwaves, extra = nrows % nwaves;
   const uint64_t rbeg = wave_id * per + (wave_id < extra ? wave_id : extra), rend = rbeg + per + (wave_id < extra ? 1 : 0);
-  for (uint64_t rb = rbeg; rb < rend; rb += kTRows) {
-    const int nr = (int)((rend - rb) < (uint64_t)kTRows ? (rend - rb) : (uint64_t)kTRows);
+  for (uint64_t rb = rbeg; rb < rend; rb += 64) {
+    const int nr = __builtin_amdgcn_readfirstlane((int)((rend - rb) < 64u ? (rend - rb) : 64u));
     const bool has_row = lane < nr;
-    // ---- per-row setup, lane r <-> row r ----
+    // ---- per-row setup, lane r <-> row r: 64 rows at a time (the uniform and the leave-one-out value are per-lane work) ----
     const float xv = has_row ? xcol[rb + lane] : 0.0f;
     const int gz = has_row ? z[rb + lane] : -1;
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
@@ -425,87 +425,95 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
     const bool my_single = single && any_empty;               // (with no other empty group nothing moves)
     const unsigned long long singles = __builtin_amdgcn_ballot_w64(my_single);
     const unsigned long long odd = mbits | singles;
-    // ---- 1. stream the rows past the groups: lane sums only ----
-    for (int r = 0; r < nr; r++) {
-      const float x = lane_bcast(xv, r);
-      float s[G];
-      if ((odd >> r) & 1ull) {                               // (wave-uniform, rare)
-        nich_row_scores<G>(s, mine, x, ((mbits >> r) & 1ull) != 0, ((singles >> r) & 1ull) != 0, dle, -1, 0.f, crp, K, kpad,
-                           (uint32_t)lane, le0, le1, bound);
-      } else {
+    // group k for this row: from the block's constants; the row's own group is its leave-one-out value
+    const bool plain = !(my_mask || my_single);               // (the others read the prior from memory)
+    const NichRowCtx rc = {fd.tab, crp, K, kpad, le0, le1, dle, bound, xv, my_mask, my_single};
+    auto entry = [&](int k) -> float {
+      const float *c = cst + k * kTCst;
+      float s = nich_eval_log2(xv, c[TC_MH], c[TC_ML], c[TC_C0] - bound, c[TC_C1], c[TC_C2]);
+      if (!plain) s = nich_entry_log2(rc, (uint32_t)k);
+      return __builtin_amdgcn_exp2f(k == gz ? sloo : s);
+    };
+    // the lane that holds the row's own group, summed with the leave-one-out value in place (the streaming pass knows
+    // nothing of own groups)
+    const int own_lane = gz >= 0 ? gz / G : -1;
+    float own_sum = 0.f;
+    if (own_lane >= 0) {
+      own_sum = entry(G * own_lane);
 #pragma unroll
-        for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, mine.mh[j], mine.ml[j], mine.c0s[j], mine.c1[j], mine.c2[j]);
-      }
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < G; j++) sum += __builtin_amdgcn_exp2f(s[j]);     // exp2(-inf) = 0 beyond K
-      mysum[r * kTPad + lane] = sum;
+      for (int j = 1; j < G; j++) own_sum += entry(G * own_lane + j);
     }
-    __builtin_amdgcn_wave_barrier();                          // (LDS traffic of one wave is in order; this stops the compiler)
-    // ---- 2. lane r finishes row r ----
     int pick = gz;
     bool redo = false;
-    if (has_row) {
-      float *row = mysum + lane * kTPad;
-      const int own_lane = gz >= 0 ? gz / G : -1;
-      const bool plain = !(my_mask || my_single);             // (the others read the prior from memory)
-      const NichRowCtx rc = {fd.tab, crp, K, kpad, le0, le1, dle, bound, xv, my_mask, my_single};
-      // group k for this row: from the block's constants; the row's own group is its leave-one-out value
-      auto entry = [&](int k) -> float {
-        const float *c = cst + k * kTCst;
-        float s = nich_eval_log2(xv, c[TC_MH], c[TC_ML], c[TC_C0] - bound, c[TC_C1], c[TC_C2]);
-        if (!plain) s = nich_entry_log2(rc, (uint32_t)k);
-        return __builtin_amdgcn_exp2f(k == gz ? sloo : s);
-      };
-      if (own_lane >= 0) {                                    // the own group's lane, with the leave-one-out value in place
-        float sum = 0.f;
+    // the lane sums of 32 rows fit the wave's LDS: the chunk goes through steps 1-3 in two halves
+    for (int h0 = 0; h0 < nr; h0 += kTRows) {
+      const int h1 = h0 + kTRows < nr ? h0 + kTRows : nr;
+      // ---- 1. stream the rows past the groups: lane sums only ----
+      for (int r = h0; r < h1; r++) {
+        const float x = lane_bcast(xv, r);
+        float s[G];
+        if ((odd >> r) & 1ull) {                             // (wave-uniform, rare)
+          nich_row_scores<G>(s, mine, x, ((mbits >> r) & 1ull) != 0, ((singles >> r) & 1ull) != 0, dle, -1, 0.f, crp, K, kpad,
+                             (uint32_t)lane, le0, le1, bound);
+        } else {
 #pragma unroll
-        for (int j = 0; j < G; j++) sum += entry(G * own_lane + j);
-        row[own_lane] = sum;
-      }
-      float blk[8], total = 0.f;                              // eight blocks of eight lanes, summed in lane order
-#pragma unroll
-      for (int b = 0; b < 8; b++) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) t += row[8 * b + i];
-        blk[b] = t;
-        total += t;
-      }
-      if (total > 0x1p-60f && total < 0x1p100f) {             // (false for NaN too)
-        const float dart = u01 * total;
-        // the running sum is monotone: the first block, lane, entry that reaches the dart is found by stepping over
-        // those that do not (util.hpp:145-156; rounding may let the dart fall off the end: the last one then)
-        float c0 = 0.f;
-        int b0 = 0;
-#pragma unroll
-        for (int b = 0; b < 7; b++) {
-          const bool miss = b0 == b && c0 + blk[b] < dart;
-          c0 = miss ? c0 + blk[b] : c0;
-          b0 += miss ? 1 : 0;
+          for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, mine.mh[j], mine.ml[j], mine.c0s[j], mine.c1[j], mine.c2[j]);
         }
-        int hl = 8 * b0;
+        float sum = __builtin_amdgcn_exp2f(s[0]);            // exp2(-inf) = 0 beyond K
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-          const float v = row[8 * b0 + i];
-          const bool miss = hl == 8 * b0 + i && c0 + v < dart;
-          c0 = miss ? c0 + v : c0;
-          hl += miss ? 1 : 0;
-        }
-        // ---- 3. the entries of lane hl ----
-        int j0 = 0;
-#pragma unroll
-        for (int j = 0; j < G - 1; j++) {
-          const float v = entry(G * hl + j);
-          const bool miss = j0 == j && c0 + v < dart;
-          c0 = miss ? c0 + v : c0;
-          j0 += miss ? 1 : 0;
-        }
-        const int k = G * hl + j0;
-        pick = k < (int)K ? k : (int)K - 1;
-      } else {
-        redo = true;
+        for (int j = 1; j < G; j++) sum += __builtin_amdgcn_exp2f(s[j]);
+        mysum[(r - h0) * kTPad + lane] = sum;
       }
+      __builtin_amdgcn_wave_barrier();                        // (LDS traffic of one wave is in order; this stops the compiler)
+      // ---- 2. lane r finishes row r ----
+      if (lane >= h0 && lane < h1) {
+        float *row = mysum + (lane - h0) * kTPad;
+        if (own_lane >= 0) row[own_lane] = own_sum;
+        float blk[8], total = 0.f;                            // eight blocks of eight lanes, summed in lane order
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          float t = row[8 * b];
+#pragma unroll
+          for (int i = 1; i < 8; i++) t += row[8 * b + i];
+          blk[b] = t;
+          total = b == 0 ? t : total + t;
+        }
+        if (total > 0x1p-60f && total < 0x1p100f) {           // (false for NaN too)
+          const float dart = u01 * total;
+          // the running sum is monotone: the first block, lane, entry that reaches the dart is found by stepping over
+          // those that do not (util.hpp:145-156; rounding may let the dart fall off the end: the last one then)
+          float c0 = 0.f;
+          int b0 = 0;
+#pragma unroll
+          for (int b = 0; b < 7; b++) {
+            const bool miss = b0 == b && c0 + blk[b] < dart;
+            c0 = miss ? c0 + blk[b] : c0;
+            b0 += miss ? 1 : 0;
+          }
+          int hl = 8 * b0;
+#pragma unroll
+          for (int i = 0; i < 7; i++) {
+            const float v = row[8 * b0 + i];
+            const bool miss = hl == 8 * b0 + i && c0 + v < dart;
+            c0 = miss ? c0 + v : c0;
+            hl += miss ? 1 : 0;
+          }
+          // ---- 3. the entries of lane hl ----
+          int j0 = 0;
+#pragma unroll
+          for (int j = 0; j < G - 1; j++) {
+            const float v = entry(G * hl + j);
+            const bool miss = j0 == j && c0 + v < dart;
+            c0 = miss ? c0 + v : c0;
+            j0 += miss ? 1 : 0;
+          }
+          const int k = G * hl + j0;
+          pick = k < (int)K ? k : (int)K - 1;
+        } else {
+          redo = true;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                        // (the next half overwrites the lane sums)
     }
     // rows whose total left the float range (an outlier thousands of bits below the bound): the wave redoes them one
     // by one with the exact maximum
@@ -522,7 +530,6 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
       if (lane == r) pick = p;
     }
     if (has_row) z[rb + lane] = pick;
-    __builtin_amdgcn_wave_barrier();                          // (the next chunk overwrites the lane sums)
   }
 }
 
@@ -1077,7 +1084,8 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   const int which = pin ? std::atoi(pin) : 0;
   const bool transposed = which == 2 || (which != 1 && nrows >= (uint64_t)num_cus * 4 * 4 * kTRows);
   if (transposed && K <= 1024) {
-    const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, 16);
+    // one wave per slot the registers leave (4 / 3 / 2 a SIMD for G <= 4 / 8 / 16): the waves split the rows evenly
+    const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, K <= 256 ? 16 : K <= 512 ? 12 : 8);
     const dim3 gridt((unsigned)gxt), blockt(256);
     if (K <= 64)
       hipLaunchKernelGGL(k_sweep_nich1_t<1>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
