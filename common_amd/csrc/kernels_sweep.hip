@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
     const NichRowCtx rc = {fd.tab, crp, K, kpad, le0, le1, dle, bound, xv, my_mask, my_single};
     auto entry = [&](int k) -> float {
       const float *c = cst + k * kTCst;
-      float s = nich_eval_log2(xv, c[TC_MH], c[TC_ML], c[TC_C0] - bound, c[TC_C1], c[TC_C2]);
+      float s = nich_eval_log2_est(xv, c[TC_MH], c[TC_ML], c[TC_C0] - bound, c[TC_C1], c[TC_C2]);
       if (!plain) s = nich_entry_log2(rc, (uint32_t)k);
       return __builtin_amdgcn_exp2f(k == gz ? sloo : s);
     };
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
                              (uint32_t)lane, le0, le1, bound);
         } else {
 #pragma unroll
-          for (int j = 0; j < G; j++) s[j] = nich_eval_log2(x, mine.mh[j], mine.ml[j], mine.c0s[j], mine.c1[j], mine.c2[j]);
+          for (int j = 0; j < G; j++) s[j] = nich_eval_log2_est(x, mine.mh[j], mine.ml[j], mine.c0s[j], mine.c1[j], mine.c2[j]);
         }
         float sum = __builtin_amdgcn_exp2f(s[0]);            // exp2(-inf) = 0 beyond K
 #pragma unroll
