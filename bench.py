@@ -171,7 +171,7 @@ def c5_setup(a, torch, common_amd, ctx, world, rank, nrows):
 
 
 def sweep_kernel_ms(torch, st, view, z, steps=5):
-    """average duration of the fused sweep kernel alone (k_sweep_nich1), HIP events around msc_sweep_assign on a copy
+    """average duration of the fused sweep kernel alone (k_sweep_nich1_t), HIP events around msc_sweep_assign on a copy
     of z -- outside the timed region; the rocprof summary in profiles/ must agree"""
     zc = z.clone()
     _, avg, mn = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), steps, 2)
@@ -196,6 +196,12 @@ def sweep_roofline(nrows, K, kern_ms, kernel):
         r["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "achieved": insts / (kern_ms * 1e-3),
                            "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
                            "frac": insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK}
+        # SQ_ACTIVE_INST_VALU counts the 4-cycle slots the vector ALUs were held (a transcendental holds two): the same
+        # roof with every instruction at its own issue cost
+        busy, _ = pmc_entry(kernel + ("<16>" if K == C5_GROUPS else "<4>"), "SQ_ACTIVE_INST_VALU")
+        if busy is not None:
+            r["valu_issue"]["busy_slots_per_launch"] = busy
+            r["valu_issue"]["busy_frac"] = busy / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
     return r
 
 
@@ -238,7 +244,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
                    "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
                    "backend": backend},
         "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
-        "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1"),
+        "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t"),
     }
 
 
@@ -334,8 +340,8 @@ def c2_sweep(a, torch, common_amd, ctx, st, view, z):
     wall_ms, avg, mn = timed(torch, one, steps, 2)
     kern_ms, _ = sweep_kernel_ms(torch, st, view, zs)
     return {"metric": "Gibbs-sweep rows/sec", "value": N / (wall_ms * 1e-3), "unit": "rows/s",
-            "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1", "kernel_avg_ms": kern_ms,
-            "roofline": sweep_roofline(N, st.K, kern_ms, "k_sweep_nich1"),
+            "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1_t", "kernel_avg_ms": kern_ms,
+            "roofline": sweep_roofline(N, st.K, kern_ms, "k_sweep_nich1_t"),
             "includes": "leave-one-out score + CRP prior + sample (fused, nothing materialised), accumulate, "
                         "commit + prepare; one rank: no exchange (msc_sweep_step)"}
 
@@ -414,7 +420,7 @@ def extra_c5(a, torch, common_amd, ctx):
     return {"workload": "C5 shard: NICH %d rows x K=%d, one rank's sweep step (no exchange at one rank)" % (nrows, C5_GROUPS),
             "metric": "Gibbs-sweep rows/sec", "value": nrows / (wall_ms * 1e-3), "unit": "rows/s", "ms_per_sweep": wall_ms,
             "evals_per_s": float(nrows) * C5_GROUPS / (wall_ms * 1e-3),
-            "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1")}
+            "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t")}
 
 
 if __name__ == "__main__":
