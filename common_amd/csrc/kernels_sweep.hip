@@ -1078,11 +1078,13 @@ static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int wa
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
-  // enough rows to give every SIMD several 32-row chunks: the transposed draw (k_sweep_nich1_t)
+  // enough rows for a 32-row chunk per wave over most of the chip: the transposed draw (k_sweep_nich1_t)
   // MSC_SWEEP_NICH1 = 1 / 2 pins the row-at-a-time / the transposed kernel whatever the size (tests, A/B timing)
   const char *pin = std::getenv("MSC_SWEEP_NICH1");
   const int which = pin ? std::atoi(pin) : 0;
-  const bool transposed = which == 2 || (which != 1 && nrows >= (uint64_t)num_cus * 4 * 4 * kTRows);
+  // (measured: the transposed kernel is ahead from ~16 k rows on at K = 256 and at K = 1024 alike -- 4 k rows: 15 vs 11 us,
+  // 16 k: 15 vs 18, 64 k: 19 vs 30, 512 k: 74 vs 120)
+  const bool transposed = which == 2 || (which != 1 && nrows >= (uint64_t)num_cus * 64);
   if (transposed && K <= 1024) {
     // one wave per slot the registers leave (4 / 3 / 2 a SIMD for G <= 4 / 8 / 16): the waves split the rows evenly
     const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, K <= 256 ? 16 : K <= 512 ? 12 : 8);
