@@ -39,8 +39,11 @@ C5_GROUPS = 1024
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults (None): 500 / 200 for the C2 pass at N = 1 (0.15 ms a step), 100 / 20 for the C5 sweep at N > 1 (5 ms a step).
+    # The first ~100 launches after an idle stretch run up to 20 % slower while the clocks come up
+    # (profiles/r02_launch_transient.txt): the warm-up has to be longer than that
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--groups", type=int, default=256)
     ap.add_argument("--c5-rows", type=int, default=C5_ROWS_PER_RANK, help="rows per rank of the C5 sweep")
@@ -123,6 +126,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if a.steps is None:
+        a.steps = 500 if world == 1 else 100
+    if a.warmup is None:
+        a.warmup = 200 if world == 1 else 20
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "none"
     if world > 1:
@@ -170,11 +177,11 @@ def c5_setup(a, torch, common_amd, ctx, world, rank, nrows):
     return x, z, view, st, drv
 
 
-def sweep_kernel_ms(torch, st, view, z, steps=5):
+def sweep_kernel_ms(torch, st, view, z, steps=20):
     """average duration of the fused sweep kernel alone (k_sweep_nich1_t), HIP events around msc_sweep_assign on a copy
     of z -- outside the timed region; the rocprof summary in profiles/ must agree"""
     zc = z.clone()
-    _, avg, mn = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), steps, 2)
+    _, avg, mn = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), steps, 5)
     return avg, mn
 
 
@@ -336,8 +343,8 @@ def c2_sweep(a, torch, common_amd, ctx, st, view, z):
     def one():
         drv.sweep(seed=73, sweep_index=idx[0])
         idx[0] += 1
-    steps = max(1, min(a.steps, 20))
-    wall_ms, avg, mn = timed(torch, one, steps, 2)
+    steps = max(1, min(a.steps, 100))
+    wall_ms, avg, mn = timed(torch, one, steps, min(20, steps))
     kern_ms, _ = sweep_kernel_ms(torch, st, view, zs)
     return {"metric": "Gibbs-sweep rows/sec", "value": N / (wall_ms * 1e-3), "unit": "rows/s",
             "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1_t", "kernel_avg_ms": kern_ms,
@@ -356,8 +363,8 @@ def extra_c3(a, torch, common_amd, ctx):
     st = common_amd.State(ctx, spec, K)
     st.accumulate(view, z)
     out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
-    steps = max(3, min(a.steps, 10))
-    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 2)
+    steps = max(3, min(a.steps, 20))
+    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 10)
     rowbytes = sum(c.element_size() * (c.shape[1] if c.dim() > 1 else 1) for c in cols)
     alg = float(N) * rowbytes + 4.0 * N * K
     insts, src = pmc_entry("k_score_tile", "SQ_INSTS_VALU")
@@ -393,8 +400,8 @@ def extra_c4(a, torch, common_amd, ctx):
     st = common_amd.State(ctx, spec, K)
     st.accumulate(view, z)
     out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
-    steps = max(3, min(a.steps, 10))
-    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 2)
+    steps = max(3, min(a.steps, 20))
+    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 10)
     flops = 2.0 * d * d * N * K                 # SURVEY 8d's count (the full d x d contraction per pair)
     tf = flops / (avg * 1e-3) / 1e12
     return {"workload": "C4 NIW dim=32, N=256k, K=128, scoring pass (f64 MFMA)", "ms": avg, "ms_min": mn,
@@ -414,8 +421,8 @@ def extra_c5(a, torch, common_amd, ctx):
     def one():
         drv.sweep(seed=73, sweep_index=idx[0])
         idx[0] += 1
-    steps = max(3, min(a.steps, 10))
-    wall_ms, avg, mn = timed(torch, one, steps, 2)
+    steps = max(3, min(a.steps, 20))
+    wall_ms, avg, mn = timed(torch, one, steps, 5)
     kern_ms, _ = sweep_kernel_ms(torch, st, view, z)
     return {"workload": "C5 shard: NICH %d rows x K=%d, one rank's sweep step (no exchange at one rank)" % (nrows, C5_GROUPS),
             "metric": "Gibbs-sweep rows/sec", "value": nrows / (wall_ms * 1e-3), "unit": "rows/s", "ms_per_sweep": wall_ms,
