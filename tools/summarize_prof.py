@@ -38,6 +38,23 @@ def main():
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]),
                             r["Percentage"], r["MinNs"], r["MaxNs"], "%.1f" % float(r["StdDev"])])
+    # the bench's timed region = the LAST `MSC_TIMED_STEPS` launches of the headline kernel (nothing launches it after
+    # the timed loop): its average is the one bench.py's HIP events must agree with
+    traces = glob.glob(os.path.join(ktdir, "**", "*_kernel_trace.csv"), recursive=True)
+    timed_steps = int(os.environ.get("MSC_TIMED_STEPS", "500"))
+    if traces:
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(traces[0])):
+            if "msc::" in r["Kernel_Name"]:
+                dur[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        with open(os.path.join(out, tag + "_timed_region.txt"), "w") as fh:
+            fh.write("kernel-trace durations (ns), all launches vs the last %d (bench.py's timed region for the headline kernel)\n" % timed_steps)
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+                v.sort()
+                d = [x for _, x in v]
+                last = d[-timed_steps:]
+                fh.write("%-60s launches %5d avg %10.1f | last %4d: avg %10.1f min %9d max %9d\n"
+                         % (k[:60], len(d), sum(d) / len(d), len(last), sum(last) / len(last), min(last), max(last)))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sys.argv[3:]:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
