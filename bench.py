@@ -126,13 +126,21 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if a.steps is None:
-        a.steps = 500 if world == 1 else 100
-    if a.warmup is None:
-        a.warmup = 200 if world == 1 else 20
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "none"
-    if world > 1:
+    # MSC_BENCH_FORCE_C5=1: the N > 1 code path (process group, C5 sweep, all-reduce inside the step) with whatever world
+    # there is -- one rank over nccl on a one-GPU box checks the RCCL branch on hardware
+    force_c5 = os.environ.get("MSC_BENCH_FORCE_C5", "0") not in ("", "0")
+    if force_c5:
+        os.environ.setdefault("MSC_DIST_FORCE_EXCHANGE", "1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if a.steps is None:
+        a.steps = 100 if (world > 1 or force_c5) else 500
+    if a.warmup is None:
+        a.warmup = 20 if (world > 1 or force_c5) else 200
+    if world > 1 or force_c5:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knob for a 1-GPU box: MSC_BENCH_BACKEND=gloo puts every rank on cuda:0
         backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
@@ -149,17 +157,17 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_c5:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or force_c5:
         line = run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all)
     else:
         line = run_c2(a, torch, dist, common_amd, ctx, sync_all)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_c5:
         dist.barrier()
         dist.destroy_process_group()
 

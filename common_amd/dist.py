@@ -6,8 +6,16 @@ of the additive suff-stat tables (int64 counts -> bit-exact, float64 sums) betwe
 payload is K * O(10) * 8 bytes, i.e. latency-bound, so both tables travel in one float64 all-reduce
 (counts below 2**53 add exactly as doubles) and nothing is bucketed or overlapped.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _force_exchange():
+    """MSC_DIST_FORCE_EXCHANGE=1: run the collective path with one rank too (hardware check of the nccl = RCCL branch
+    on a one-GPU box; a one-rank all-reduce returns its input)"""
+    return os.environ.get("MSC_DIST_FORCE_EXCHANGE", "0") not in ("", "0")
 
 
 def shard_rows(nrows, world, rank):
@@ -24,7 +32,7 @@ def allreduce_tables(red_i64, red_f64, group=None, pack=None):
     all-reduce.  The counts ride along as doubles -- integers below 2**53 add exactly and in any order, so they
     come back bit-exact -- and are copied into the int64 table again.  `pack`: a float64 scratch tensor of
     red_i64.numel() + red_f64.numel() elements to reuse (one is allocated otherwise)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _force_exchange()):
         return
     ni, nf = red_i64.numel(), red_f64.numel()
     if ni == 0 or nf == 0:                      # only one kind of table: nothing to merge
@@ -60,7 +68,9 @@ class ShardedSweep(object):
         self.state.commit_reduce()
 
     def _alone(self):
-        return not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return True
+        return dist.get_world_size(self.group) == 1 and not _force_exchange()
 
     def sweep(self, seed, sweep_index):
         if self._alone():         # nothing to exchange: the whole step is one library call (graph-replayed when it repeats)

@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(tmp_path, which, N, K, nsweeps, world=2):
+def _launch(tmp_path, which, N, K, nsweeps, world=2, backend="gloo", **extra_env):
     out = str(tmp_path / ("dist_%s.json" % which))
-    env = dict(os.environ, MSC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MSC_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     port = 29600 + (os.getpid() + len(which)) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -25,8 +25,8 @@ def _launch(tmp_path, which, N, K, nsweeps, world=2):
         return json.load(fh)
 
 
-def _check(r):
-    assert r["world"] == 2
+def _check(r, world=2):
+    assert r["world"] == world
     same = r["same_fraction_per_sweep"]
     # sweep 0 starts from identical tables and the counter-based draw is keyed on the global row: z is identical
     assert same[0] == 1.0
@@ -46,3 +46,11 @@ def test_two_ranks_single_nich_sweeps_equal_the_unsharded_run(gpu_ctx, tmp_path)
 
 def test_two_ranks_mixed_features_sweeps_equal_the_unsharded_run(gpu_ctx, tmp_path):
     _check(_launch(tmp_path, "mixed", 200_000, 48, 2))      # bb + gp + dd + nich, K = 48 (k_narrow), int64 + f64 tables
+
+
+def test_one_rank_over_nccl_runs_the_exchange_path_on_rccl(gpu_ctx, tmp_path):
+    """the nccl (= RCCL) branch on the box's one GPU: a single rank forced through msc_sweep_step_begin -> all_reduce
+    (RCCL, on the library's own reduce buffers) -> msc_state_commit_reduce must equal msc_sweep_step"""
+    r = _launch(tmp_path, "nich", 300_000, 1024, 2, world=1, backend="nccl", MSC_DIST_FORCE_EXCHANGE="1")
+    _check(r, world=1)
+    assert r["backend"] == "nccl" and min(r["same_fraction_per_sweep"]) == 1.0
