@@ -363,6 +363,21 @@ MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, flo
   const double dd = x - mun;
   return t[NLOO_C0G * stride] - 0.5 * log(sig) - t[NLOO_C1 * stride] * log1p(t[NLOO_K2G * stride] * dd * dd / sig);
 }
+// The transposed sweep kernel's form: the downdate and the posterior -- where the cancellations are -- in double as above,
+// the two logarithms and the division in float (log1p_acc: hardware log2 + the compensation term), which is how every
+// other entry of the row is evaluated.  ~14 double fma + ~15 float instructions instead of ~225 double ones.
+MSC_DEV float nich_loo_tab_sweep(const float *hp, const double *t, size_t stride, float mean_f, float ctv_f, float xf) {
+  const double x = xf, mean = mean_f, ctv = ctv_f, mu = hp[0];
+  const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
+  const double v2 = t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2));
+  const double mun = t[NLOO_KMU * stride] + m2 * t[NLOO_N_INV_KN * stride];
+  const double d = mu - m2;
+  const double sig = t[NLOO_NUSIG * stride] + v2 * t[NLOO_INV_NUN * stride] + t[NLOO_NKK * stride] * d * d;
+  const double dd = x - mun;
+  const float sigf = (float)sig, q = (float)(t[NLOO_K2G * stride] * dd * dd);
+  const float tt = q * hw_rcp(sigf);                     // (v_rcp_f32: 1 ulp, far inside what log1p of it keeps)
+  return (float)t[NLOO_C0G * stride] - 0.5f * (hw_log2(sigf) * kLn2f) - (float)t[NLOO_C1 * stride] * log1p_acc(tt);
+}
 // gp leave-one-out: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
 //   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b')
 MSC_DEV double gp_loo(const float *hp, uint32_t count, uint32_t sum, uint32_t v) {

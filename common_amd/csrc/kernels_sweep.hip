@@ -415,12 +415,13 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
     float sloo = 0.f;
     bool single = false;
     if (gz >= 0) {
-      // leave-one-out score + prior of the row's own group, in double (what k_loo_own does for the other kernels)
+      // leave-one-out score + prior of the row's own group
       const float lm1 = crp[kpad + gz];
       single = __builtin_isinf(lm1);                          // the row is its group's only member
-      double s = single ? (double)le1 + (double)crp[2 * (size_t)kpad + 3] : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + gz];
-      if (!my_mask) s += nich_loo_tab(fd.hp, fd.loo64 + gz, kpad, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
-      sloo = (float)s * kLog2e - bound;
+      // (float: the prior's hi part and the float tail of nich_loo_tab_sweep -- what the other entries of the row get)
+      float s = single ? le1 : lm1;
+      if (!my_mask) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + gz, kpad, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
+      sloo = s * kLog2e - bound;
     }
     const bool my_single = single && any_empty;               // (with no other empty group nothing moves)
     const unsigned long long singles = __builtin_amdgcn_ballot_w64(my_single);
