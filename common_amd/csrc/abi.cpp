@@ -542,9 +542,9 @@ static void plan_groups(msc_state *st) {
     FeatDesc &d = t[i];
     d.kind = MSC_KIND_GENERIC;
     if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
-    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8;
-    else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32;
-    else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32;
+    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = 1;
+    else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32, d.run_clamp = d.grp_rows - 1;
+    else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32, d.run_clamp = d.dim - 1;
   }
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
     }
-    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
     // epilogue, row by row (one pass, so nothing of one row outlives its store): + hi of the prior; then the own
     // group's entry becomes the row's pre-computed leave-one-out value (k_loo_own) through a KiB of LDS that belongs
     // to the wave (beyond the table slot, so no barrier) -- park the row, one lane overwrites the entry, read the row

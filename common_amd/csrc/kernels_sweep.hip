@@ -709,7 +709,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
     float4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, lds, acc);
+    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll

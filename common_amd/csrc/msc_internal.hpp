@@ -80,11 +80,21 @@ inline size_t crp_floats(uint32_t kpad) { return 4 * (size_t)kpad + 4; }
 //   bnb  i64 {count, sum}
 //   dm   i64 {counts[dim]}           f64 {ratio}
 struct FeatDesc {
+  // -- what the tile kernels' lookup runs read per feature: one 32-byte block, one scalar load (score_block.hpp) --
+  const void *col;         // bound dataview column (device), null until bound
+  uint32_t grp_off;        // tile kernels, group plan (abi.cpp plan_groups): first row of this feature's table block
+                           // inside the LDS slot
+  uint32_t run_clamp;      // lookup kinds: the largest table row a value may select (dd: dim - 1, gp / bnb: staged rows - 1)
+  uint32_t kind;           // MSC_KIND_*: which inner loop of the tile kernel scores this feature
+  uint32_t run_end;        // lookup kinds: one past the last feature of the run of lookup features this one
+                           // belongs to (within its group); generic: its own index
+  uint32_t grp_rows;       // rows of the block staged in LDS (entries beyond are read from global)
+  uint32_t grp_end;        // one past the last feature of this feature's group
+  // ----------------------------------------------------------------------------------------------------------------
   int32_t family;
   uint32_t dim;
   int32_t col_type;        // msc_primitive_type of the bound column (value type of the family)
   uint32_t pad0;
-  const void *col;         // bound dataview column (device), null until bound
   const uint8_t *mask;     // optional per-element mask column
   const float *hp;         // device copy of the hp block
   float *tab;              // derived score table rows
@@ -104,15 +114,8 @@ struct FeatDesc {
   const uint32_t *dm_meta;    // dm: [dim+1][2] per stage (device): {first table row, entries in the table};
                               //     count v of a stage occupies table rows first + 2v (hi) and first + 2v + 1 (lo)
   const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)
-  // tile kernels, group plan (abi.cpp plan_groups): consecutive features share the LDS slot
-  // (32-bit fields: the kernels read them with scalar loads; a 16-bit field costs a vector load and a full wait)
-  uint32_t grp_off;           // first row of this feature's table block inside the slot
-  uint32_t grp_rows;          // rows of the block staged in LDS (entries beyond are read from global)
-  uint32_t grp_end;           // one past the last feature of this feature's group
-  uint32_t kind;              // MSC_KIND_*: which inner loop of the tile kernel scores this feature
-  uint32_t run_end;           // lookup kinds: one past the last feature of the run of lookup features this one
-                              // belongs to (within its group); generic: its own index
-  uint32_t pad3;
+  // (the group plan's fields are the struct's head; 32-bit on purpose: the kernels read them with scalar loads, a
+  // 16-bit field costs a vector load and a full wait)
   double *loo64;              // nich: per-group constants of the leave-one-out pass, [loo_rows][kpad] (family_math.hpp)
   float *loo_tab;             // bb, gp, bnb, dd: score of value v against the group with one such value removed,
                               // [v][kpad] (k_prepare); the leave-one-out pass is a lookup for these families

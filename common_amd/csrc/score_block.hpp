@@ -364,7 +364,8 @@ MSC_DEV uint32_t run_value(const FeatDesc &fd, uint64_t myrow, bool has_row) {
 
 template <int R, int W, bool DM>
 MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
-                               int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
+                               int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds,
+                               float4 (&acc)[R]) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
@@ -379,22 +380,38 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
       // and the run's end): nothing but the value load, eight ds_read_b128 and the adds.  One entry, one exit,
       // so the accumulators stay where they are.
       const int fe = (int)feats[f].run_end;
-      // the value of the NEXT feature of the run is fetched before this one's lookups go out: a feature is a chain
-      // descriptor -> value -> LDS reads, and the waves spend half their time parked (SQ_WAIT_ANY 0.52 of the wave
-      // cycles); one feature ahead: C3 2.63 -> 2.54 ms
-      uint32_t idx_next = f < fe ? run_value(feats[f], myrow, has_row) : 0u;
-      for (; f < fe; f++) {
-        const FeatDesc &fd = feats[f];
-        const uint32_t kind = fd.kind;
-        uint32_t idx = idx_next;
-        if (f + 1 < fe) idx_next = run_value(feats[f + 1], myrow, has_row);
-        if (kind == MSC_KIND_LOOKUP_I32) {
-          const int v = (int)idx;
-          idx = (uint32_t)(v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v));     // keep the gather in bounds
-        } else if (kind == MSC_KIND_LOOKUP_U32) {
-          idx = idx < fd.grp_rows ? idx : fd.grp_rows - 1;                              // (never taken: rows cover the column's maximum)
-        }
-        const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
+      // A feature is a chain descriptor -> value -> LDS reads, and the waves spent half their time parked on it
+      // (SQ_WAIT_ANY 0.52 of the wave cycles).  So the run is a software pipeline, written so that
+      // the compiler's wait-count bookkeeping can follow it: no branch around a load (past the run's end the last
+      // feature is fetched again; lanes without a row fetch the wave's first row), global -- not flat -- loads (a flat
+      // load counts on lgkmcnt too, and every wait for an LDS read would wait for it), and two features per trip so
+      // that nothing fetched ahead has to be copied from one register to another.  Values: one dword load for either
+      // column type (a bool column: the aligned dword around the byte, then the byte); bool columns as 0 / 1, 32-bit
+      // ones clamped into the staged block (negative -> 0, never taken with valid data: the rows cover the column's
+      // maximum) -- min(max(v, 0), clamp) does both, the clamp of a bool column being 1.
+      struct Head { const void *col; uint32_t off, clamp, kind; };
+      auto head_of = [&](int g) -> Head {
+        const FeatDesc &d = feats[g < fe ? g : fe - 1];
+        return Head{d.col, d.grp_off, d.run_clamp, d.kind};
+      };
+      const uint64_t ldrow = has_row ? myrow : row_safe;      // (a row of the call's range, whatever this wave's share is)
+      auto fetch = [&](const Head &h) -> uint32_t {
+        typedef const __attribute__((address_space(1))) unsigned char *g_u8;
+        const bool u8 = h.kind == MSC_KIND_LOOKUP_U8;
+        const uint64_t byte = u8 ? ldrow : ldrow * 4;
+        const uint64_t base = reinterpret_cast<uint64_t>(h.col);
+        const uint64_t at = (base + byte) & ~(uint64_t)3;     // (the columns are dword-aligned for 32-bit types anyway)
+        return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((g_u8)at);
+      };
+      auto index_of = [&](const Head &h, uint32_t word) -> uint32_t {
+        const bool u8 = h.kind == MSC_KIND_LOOKUP_U8;
+        const uint32_t sh = u8 ? (uint32_t)((reinterpret_cast<uint64_t>(h.col) + ldrow) & 3u) * 8u : 0u;
+        const int v = (int)(u8 ? (word >> sh) & 0xffu : word);
+        return (uint32_t)(v < 0 ? 0 : (v > (int)h.clamp ? (int)h.clamp : v));
+      };
+      auto lookups = [&](const Head &h, uint32_t word) {
+        const uint32_t idx = index_of(h, word);
+        const float4 *buf = lds + (size_t)h.off * 64 + lane;
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 4) {
           float4 t[4];
@@ -404,6 +421,22 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
           for (int j = 0; j < 4; j++) add4(acc[r0 + j], t[j]);
           __builtin_amdgcn_sched_barrier(0);            // four reads in flight, not eight: 16 fewer live registers
         }
+      };
+      if (f < fe) {
+        Head ha = head_of(f), hb = head_of(f + 1);
+        uint32_t wa = fetch(ha);
+        for (; f < fe; f += 2) {
+          const uint32_t wb = fetch(hb);                      // value of f + 1
+          const Head hc = head_of(f + 2);                     // descriptor of f + 2
+          lookups(ha, wa);
+          if (f + 1 >= fe) { f++; break; }
+          wa = fetch(hc);                                     // value of f + 2
+          ha = hc;
+          const Head hd = head_of(f + 3);                     // descriptor of f + 3
+          lookups(hb, wb);
+          hb = hd;
+        }
+        if (f > fe) f = fe;
       }
       if (f >= f1) break;
       const FeatDesc &fd = feats[f];
@@ -431,12 +464,13 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
 // ---------------------------------------------------------------------------
 // acc[r] (+)= sum over features of score_value(row rb+r, groups kb..kb+3).
 // All W waves of the workgroup must call this together (it contains barriers); a wave whose
-// rows are out of range passes nr = 0.  lds: the kGrpRows * 64 float4 slot.
+// rows are out of range passes nr = 0; row_safe = any row of the call's range (lanes without a row read it and
+// drop what they read).  lds: the kGrpRows * 64 float4 slot.
 // ---------------------------------------------------------------------------
 template <int R, int W, bool DM>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nsplit, uint32_t kpad, uint32_t ktile,
-                        int lane, uint64_t row_abs0, int nr, float4 *__restrict__ lds, float4 (&acc)[R]) {
-  score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, lds, acc);
+                        int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds, float4 (&acc)[R]) {
+  score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, row_safe, lds, acc);
   if (nsplit < nfeat) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
