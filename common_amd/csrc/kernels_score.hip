@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nrows) return;
   const int g = z[n];
-  if (g < 0) {
+  if (g < 0 || (uint32_t)g >= kpad) {                       // (an id outside the tables reads as not assigned)
     own[n] = 0.f;
     return;
   }
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   float sloo = 0, erow = le0, erow_lo = le0_lo;
   if (LOO && mine) {
     gz = z[myrow];
+    if ((uint32_t)gz >= K) gz = -1;                         // (an id outside the table: not assigned)
     sloo = own[myrow];
     if (CRP && gz >= 0 && __builtin_isinf(crp[kpad + gz])) {
       erow = le1;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
     int single = 0;                                       // lane r: removing row r empties its group (kept in a VGPR:
     if (LOO && CRP && lane < nr) {                        //  the tile scorer leaves no SGPR pair free across its call)
       const int g0 = z[rb + lane];
-      single = g0 >= 0 && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
+      single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
     }
     if (CRP) {
       const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);

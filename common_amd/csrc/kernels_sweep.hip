@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256, G == 16 ? 3 : 1) void k_sweep_nich1(const Feat
     const int nr = (int)((nrows - rb) < (uint64_t)chunk_rows ? (nrows - rb) : (uint64_t)chunk_rows);
     const bool has_row = lane < nr;
     const float xv = has_row ? xcol[rb + lane] : 0.0f;
-    const int gz = has_row ? z[rb + lane] : -1;
+    int gz = has_row ? z[rb + lane] : -1;
+    if ((uint32_t)gz >= K) gz = -1;                           // (an id outside the table: not assigned, as msc_accumulate reads it)
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     const unsigned long long mbits =
         __builtin_amdgcn_ballot_w64(fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0);
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
     const bool has_row = lane < nr;
     // ---- per-row setup, lane r <-> row r: 64 rows at a time (the uniform and the leave-one-out value are per-lane work) ----
     const float xv = has_row ? xcol[rb + lane] : 0.0f;
-    const int gz = has_row ? z[rb + lane] : -1;
+    int gz = has_row ? z[rb + lane] : -1;
+    if ((uint32_t)gz >= K) gz = -1;                           // (an id outside the table: not assigned, as msc_accumulate reads it)
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     const bool my_mask = fd.mask != nullptr && has_row && fd.mask[row0 + rb + lane] != 0;
     const unsigned long long mbits = __builtin_amdgcn_ballot_w64(my_mask);
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(256) void k_sweep_niw1(const FeatDesc *__restrict__
     if (has_row && fd.mask != nullptr)
 #pragma unroll
       for (int j = 0; j < D; j++) msk |= fd.mask[(row0 + rb + lane) * D + j] != 0;
-    const int gz = has_row ? z[rb + lane] : -1;
+    int gz = has_row ? z[rb + lane] : -1;
+    if ((uint32_t)gz >= K) gz = -1;                           // (an id outside the table: not assigned, as msc_accumulate reads it)
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     const unsigned long long mbits = __builtin_amdgcn_ballot_w64(msk);
     int znew = gz;
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
     float sloo = 0.f, erow = le0;
     if (lane < nr) {
       gz = z[rb + lane];
+      if ((uint32_t)gz >= K) gz = -1;                         // (an id outside the table: not assigned)
       if (gz >= 0) {
         sloo = own[rb + lane];
         erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
@@ -825,6 +829,7 @@ __global__ __launch_bounds__(256) void k_narrow(const FeatDesc *__restrict__ fea
       single[i] = false;
       if (loo && has[i]) {
         gzs[i] = z[nn[i]];
+        if ((uint32_t)gzs[i] >= K) gzs[i] = -1;             // (an id outside the table: not assigned)
         single[i] = pri && gzs[i] >= 0 && __builtin_isinf(crp[kpad + gzs[i]]);
       }
       accs[i] = pri ? crp_prior4_lo(logcnt, logcnt_lo, single[i] ? le1_lo : le0_lo) : make_float4(0, 0, 0, 0);

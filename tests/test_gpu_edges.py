@@ -164,3 +164,41 @@ def test_score_tune_is_explicit_and_changes_no_value(gpu_ctx):
     st2 = common_amd.State(gpu_ctx, [(common_amd.NICH, 0), (common_amd.BB, 0)], K)
     view2 = common_amd.DataView.from_tensors(gpu_ctx, [x, x > 0])
     assert st2.score_tune(view2, out)[0] == -1                           # the tile kernel has no shapes to settle
+
+
+@pytest.mark.parametrize("specs,K", [([(orc.NICH, 0)], 300), ([(orc.NICH, 0)], 40), ([(orc.BB, 0), (orc.NICH, 0), (orc.DD, 4)], 100),
+                                     ([(orc.BB, 0), (orc.GP, 0)], 12)])
+def test_assignment_ids_outside_the_table_read_as_unassigned(gpu_ctx, specs, K, monkeypatch):
+    """z[n] >= K (a caller's slip) must not index the tables: every kernel treats such a row as not assigned, as
+    msc_accumulate does -- same scores and same draws as with -1 in its place"""
+    import common_amd
+    rng = np.random.default_rng(K)
+    N = 3000
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    bad = rng.choice(N, 200, replace=False)
+    z_bad, z_neg = z.copy(), z.copy()
+    z_bad[bad] = rng.choice([K, K + 1, 5 * K + 7, 2 ** 20, 2 ** 31 - 1], 200)
+    z_neg[bad] = -1
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    outs = {}
+    for name, zz in (("bad", z_bad), ("neg", z_neg)):
+        st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+        for i, f in enumerate(feats):
+            st.set_hp(i, orc.Family(f["family"], f["hp"], f["dim"], "f64").hp)
+        zt = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+        st.accumulate(view, zt)
+        st.set_alpha(1.5)
+        counts = st.get_group_counts().copy()
+        loo = st.score_value(view, z=zt).cpu().numpy()
+        picks = []
+        for pin in ("1", "2"):                                   # both single-nich sweep kernels where they apply
+            monkeypatch.setenv("MSC_SWEEP_NICH1", pin)
+            zs = zt.clone()
+            st.sweep_assign(view, zs, seed=3, sweep=1)
+            picks.append(zs.cpu().numpy())
+        outs[name] = (counts, loo, picks)
+    assert np.array_equal(outs["bad"][0], outs["neg"][0])
+    assert np.array_equal(outs["bad"][1], outs["neg"][1])
+    for a, b in zip(outs["bad"][2], outs["neg"][2]):
+        assert np.array_equal(a, b) and a.min() >= 0 and a.max() < K
