@@ -208,7 +208,8 @@ int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, uint32_t ng
  * cols[f] = dataview column feeding state feature f (NULL: identity).
  * z_dev (nullable, int32[nrows] indexed from row0): leave-one-out -- row r is
  * scored against group z[r] with itself removed (remove_value before
- * score_value); z < 0 means unassigned.
+ * score_value); z < 0 means unassigned, and so does an id >= ngroups
+ * (no entry point indexes a table with an id it has not range-checked).
  * out_dev: float[nrows * ld_out], ld_out >= ngroups.
  */
 int msc_score_value(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row0,
