@@ -410,6 +410,8 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
     MSC_REQUIRE(types[i].type >= 0 && types[i].type < MSC_TYPE_NELEMS, "feature %u: bad type", i);
     MSC_REQUIRE(types[i].count >= 1, "feature %u: count must be >= 1", i);
     MSC_REQUIRE(nrows == 0 || dev_columns[i], "feature %u: null column", i);
+    MSC_REQUIRE(reinterpret_cast<uintptr_t>(dev_columns[i]) % primitive_size(types[i].type) == 0,
+                "feature %u: column not aligned to its element size (%u bytes)", i, (unsigned)primitive_size(types[i].type));
     v->types.push_back(types[i]);
     v->cols.push_back(dev_columns[i]);
     v->masks.push_back(dev_masks ? dev_masks[i] : nullptr);

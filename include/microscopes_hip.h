@@ -133,7 +133,7 @@ int msc_dataview_from_records(msc_context *ctx, const void *host_records, const 
 /*
  * Adopt columns that already live in HBM (generated on the device, or a torch
  * tensor): dev_columns[i] has nrows * types[i].count elements of types[i].type,
- * row-major for vector features.  dev_masks may be NULL or hold NULL entries;
+ * row-major for vector features, aligned to the element size (MSC_EINVAL otherwise).  dev_masks may be NULL or hold NULL entries;
  * a non-NULL entry has nrows * count bytes (nonzero = masked).  Borrowed, not
  * owned: the caller keeps them alive for the life of the view.
  */

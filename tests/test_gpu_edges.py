@@ -202,3 +202,44 @@ def test_assignment_ids_outside_the_table_read_as_unassigned(gpu_ctx, specs, K, 
     assert np.array_equal(outs["bad"][1], outs["neg"][1])
     for a, b in zip(outs["bad"][2], outs["neg"][2]):
         assert np.array_equal(a, b) and a.min() >= 0 and a.max() < K
+
+
+def test_device_columns_must_be_aligned_to_their_element_size(gpu_ctx):
+    import ctypes as C
+    from common_amd import _lib as L
+    buf = torch.zeros(64, dtype=torch.uint8, device=gpu_ctx.torch_device)
+    rt = (L.RuntimeType * 1)(L.RuntimeType(L.TYPE_F32, 1))
+    h = C.c_void_p()
+    for off, ok in ((0, True), (1, False), (2, False), (4, True)):
+        ptrs = (C.c_void_p * 1)(buf.data_ptr() + off)
+        rc = gpu_ctx.lib.msc_dataview_from_device_columns(gpu_ctx._h, 8, rt, 1, ptrs, None, C.byref(h))
+        assert (rc == 0) == ok, (off, rc)
+        if rc == 0:
+            gpu_ctx.lib.msc_dataview_destroy(h)
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3, 5])
+def test_bool_columns_at_any_byte_offset(gpu_ctx, offset):
+    """the tile kernels fetch a bool value as the aligned dword around its byte: every base alignment, rows up to the
+    last byte of the buffer"""
+    import common_amd
+    rng = np.random.default_rng(offset)
+    N, K = 1003, 70                                                   # K > 64: the tile kernel, not k_narrow
+    feats = [make_feature(orc.BB, N, K, rng), make_feature(orc.BB, N, K, rng), make_feature(orc.NICH, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    dev = gpu_ctx.torch_device
+    cols = []
+    for f in feats[:2]:
+        raw = torch.zeros(offset + N, dtype=torch.bool, device=dev)   # the column ends with the buffer
+        raw[offset:] = torch.from_numpy(f["values"].astype(np.bool_)).to(dev)
+        cols.append(raw[offset:])
+    cols.append(torch.from_numpy(feats[2]["values"]).to(dev))
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols)
+    st = common_amd.State(gpu_ctx, [(orc.BB, 0), (orc.BB, 0), (orc.NICH, 0)], K)
+    load_state(st, fs)
+    got = st.score_value(view).cpu().numpy()
+    assert rel_err(got, oracle_scores(feats, fs)).max() <= TOL
+    for row0, nrows in ((1, 129), (5, 998), (1002, 1)):               # ranges that start and end anywhere
+        part = st.score_value(view, row0=row0, nrows=nrows).cpu().numpy()
+        assert np.array_equal(part, got[row0:row0 + nrows])
