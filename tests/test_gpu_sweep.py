@@ -344,3 +344,39 @@ def test_sweep_small_niw_with_masked_vectors_and_singletons(gpu_ctx):
             lo, hi = sorted((int(got[n]), int(pick)))
             assert abs(cdf[lo] - orc.uniform01(seed, 0, n)) < 1e-5 or p[lo + 1:hi + 1].sum() < 1e-5, n
     assert agree >= 0.997 * N
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_single_nich_kernels_agree_on_random_shapes(gpu_ctx, monkeypatch, seed):
+    """differential fuzz of the two single-nich sweep kernels: random row / group counts (every G of the templates,
+    chunk remainders), concentration, share of empty groups, singletons, unassigned and masked rows, shard offsets"""
+    import common_amd
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.choice([1, 2, 3, 17, 64, 65, 100, 128, 129, 255, 256, 257, 400, 512, 513, 900, 1024]))
+    N = int(rng.choice([1, 2, 31, 33, 63, 64, 65, 127, 500, 1000, 4097, 20000]))
+    f = make_feature(orc.NICH, N, K, rng)
+    used = max(1, K - int(rng.integers(0, max(1, K // 3) + 1)))
+    z = rng.integers(0, used, N).astype(np.int32)
+    if N > 40:
+        z[rng.choice(N, N // 10, replace=False)] = -1
+    mask = rng.random(N) < rng.choice([0.0, 0.05, 0.5])
+    rec = np.ma.masked_array(np.zeros(N, dtype=[("f0", np.float32)]), mask=[(bool(m),) for m in mask])
+    rec.data["f0"] = f["values"]
+    view = common_amd.DataView.from_recarray(gpu_ctx, rec)
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, orc.Family(orc.NICH, f["hp"], 0, "f64").hp)
+    z0 = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, z0)
+    st.set_alpha(float(rng.choice([0.1, 1.0, 7.5])))
+    row0 = int(rng.integers(0, max(1, N // 3)))
+    nrows = N - row0
+    picks = {}
+    for name, pin in (("rowwise", "1"), ("transposed", "2")):
+        monkeypatch.setenv("MSC_SWEEP_NICH1", pin)
+        zt = z0[row0:].clone()
+        st.sweep_assign(view, zt, seed=seed, sweep=3, row0=row0, nrows=nrows, row_id0=10 * row0)
+        picks[name] = zt.cpu().numpy()
+    a, b = picks["rowwise"], picks["transposed"]
+    assert a.min() >= 0 and a.max() < K and b.min() >= 0 and b.max() < K
+    differ = int((a != b).sum())
+    assert differ <= max(1, nrows // 2000), (differ, nrows, K)      # a dart within rounding of a CDF step, if any
