@@ -1403,7 +1403,7 @@ static bool sweep_is_fused(const msc_state *st) {
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
   for (uint32_t f = 0; f < st->nfeat; f++)
     if (st->feats[f].family == MSC_NIW || gp_beyond_table(st, f)) return false;
-  return nich1 ? st->K <= 1024 : st->K <= 256;
+  return nich1 ? st->K <= sweep_nich1_rows_max_groups() : st->K <= 256;
 }
 
 // the sampling kernels read (seed, sweep) from the state's device pair and the step ends by incrementing the sweep
@@ -1446,7 +1446,15 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     }
     uint32_t narrow_rows = 0;
     const int nl = nich1 ? 0 : narrow_lanes(st, &narrow_rows);
-    if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    if (nich1 && st->K > 1024) {                          // beyond the register-resident table: lane <-> row
+      if (!st->rows_table) {
+        void *p = nullptr;
+        MSC_HIP(hipMalloc(&p, sweep_nich1_rows_table_floats(st->kpad) * sizeof(float)));
+        st->owned.push_back(p);
+        st->rows_table = static_cast<float *>(p);
+      }
+      rc = launch_sweep_nich1_rows(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->logpc, st->rng_dev, zero, st->rows_table);
+    } else if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
     else rc = launch_sweep_mixed(s, cus, has_dm, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);

@@ -356,7 +356,9 @@ MSC_DEV void nich_loo_prepare(const float *hp, uint32_t count, float mean_f, dou
 MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, float mean_f, float ctv_f, float xf) {
   const double x = xf, mean = mean_f, ctv = ctv_f, mu = hp[0];
   const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
-  const double v2 = t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2));
+  // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
+  // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
+  const double v2 = fmax(t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2)), 0.0);
   const double mun = t[NLOO_KMU * stride] + m2 * t[NLOO_N_INV_KN * stride];
   const double d = mu - m2;
   const double sig = t[NLOO_NUSIG * stride] + v2 * t[NLOO_INV_NUN * stride] + t[NLOO_NKK * stride] * d * d;
@@ -369,7 +371,9 @@ MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, flo
 MSC_DEV float nich_loo_tab_sweep(const float *hp, const double *t, size_t stride, float mean_f, float ctv_f, float xf) {
   const double x = xf, mean = mean_f, ctv = ctv_f, mu = hp[0];
   const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
-  const double v2 = t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2));
+  // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
+  // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
+  const double v2 = fmax(t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2)), 0.0);
   const double mun = t[NLOO_KMU * stride] + m2 * t[NLOO_N_INV_KN * stride];
   const double d = mu - m2;
   const double sig = t[NLOO_NUSIG * stride] + v2 * t[NLOO_INV_NUN * stride] + t[NLOO_NKK * stride] * d * d;

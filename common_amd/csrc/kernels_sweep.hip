@@ -539,6 +539,277 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_nich1_rows: the single-nich step for tables beyond 1024 groups (what the registers of k_sweep_nich1_t hold).
+// LANE <-> ROW here, two rows per lane, 128 rows per wave visit; the groups stream past as SCALAR operands: a helper
+// kernel writes every group's constants as 32 bytes (log2 units, prior and -bound folded; the prior alone and the
+// singleton shift beside them for masked rows and rows that are their group's only member), the wave reads them with
+// s_load_dwordx4 pairs and every lane evaluates its two rows against the same group -- no cross-lane operation
+// anywhere.  A lane keeps the running sum of its rows' probabilities per block of B groups (<= 32 blocks; LDS, a
+// column per lane), then finishes alone: recomputes the block of the row's own group with the leave-one-out value
+// in place, adds the block sums up, throws the dart, finds the block, recomputes that block's entries (per-lane
+// gathers from the same table: an L2 hit) to find the group.  K + 2 B evaluations per row instead of K, 6-12 % more;
+// the materialise-and-sample path this replaces ran 4.5 / 9.4 ms per million rows at K = 2048 / 4096.
+// Rows whose total leaves the float range are redone by the wave with the exact maximum (three passes over the table).
+// ---------------------------------------------------------------------------
+#ifndef MSC_DBG_ALWAYS_REDO
+#define MSC_DBG_ALWAYS_REDO 0
+#endif
+constexpr int kRowsNb = 16;                      // block sums per row
+constexpr uint32_t kRowsMaxK = 32768;            // (linear in K up to 16384: 2.9 ms per 200 k rows there; 19 ms at 32768, where the
+                                                 //  per-lane passes over blocks of 2048 groups weigh in -- the materialised path: 25 ms)
+struct RowsGeom {
+  uint32_t B, nb;
+};
+inline RowsGeom rows_geom(uint32_t kpad) {
+  RowsGeom g;
+  g.B = ((kpad + kRowsNb - 1) / kRowsNb + 63) / 64 * 64;
+  g.nb = (kpad + g.B - 1) / g.B;
+  return g;
+}
+enum { RT_MH = 0, RT_ML, RT_C0, RT_C1, RT_C2, RT_PRIOR, RT_DLE, RT_PAD, RT_WORDS };
+
+__global__ __launch_bounds__(1024) void k_nich_rows_table(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
+                                                           const float *__restrict__ crp, float *__restrict__ tab, uint32_t nent) {
+  __shared__ float red[16];
+  const FeatDesc fd = feats[0];
+  constexpr float kLog2e = 1.44269504088896340736f;
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const bool any_empty = !__builtin_isinf(le0);
+  const float dle = any_empty ? (le1 - le0) * kLog2e : 0.f;
+  float mx = -INFINITY;
+  for (uint32_t k = threadIdx.x; k < K; k += 1024) {
+    const float lc = crp[k];
+    mx = fmaxf(mx, (fd.tab[(size_t)NICH_C0 * kpad + k] + (__builtin_isinf(lc) ? le0 : lc)) * kLog2e);
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  float bound = red[0];
+  for (int w = 1; w < 16; w++) bound = fmaxf(bound, red[w]);
+  bound += 16.f;                                 // (headroom as in k_sweep_nich1_t; the total is checked)
+  for (uint32_t k = threadIdx.x; k < nent; k += 1024) {
+    float *e = tab + (size_t)k * RT_WORDS;
+    const bool in = k < K;
+    const uint32_t kc = in ? k : 0u;
+    const float lc = crp[kc];
+    const bool empty = __builtin_isinf(lc);
+    const float pr = empty ? le0 : lc;
+    e[RT_MH] = in ? fd.tab[(size_t)NICH_MU_HI * kpad + kc] : 0.f;
+    e[RT_ML] = in ? fd.tab[(size_t)NICH_MU_LO * kpad + kc] : 0.f;
+    e[RT_C0] = in ? (fd.tab[(size_t)NICH_C0 * kpad + kc] + pr) * kLog2e - bound : -INFINITY;
+    e[RT_C1] = in ? fd.tab[(size_t)NICH_C1 * kpad + kc] : 0.f;
+    e[RT_C2] = in ? fd.tab[(size_t)NICH_C2 * kpad + kc] : 0.f;
+    e[RT_PRIOR] = in ? pr * kLog2e - bound : -INFINITY;
+    e[RT_DLE] = in && empty ? dle : 0.f;
+    e[RT_PAD] = 0.f;
+  }
+  if (threadIdx.x < 8 * RT_WORDS) tab[(size_t)nent * RT_WORDS + threadIdx.x] = 0.f;          // the spare entries
+  if (threadIdx.x == 0) tab[((size_t)nent + 8) * RT_WORDS] = bound;
+}
+
+// two rows against one table entry, as packed arithmetic: the probabilities 2^s (nich_eval_log2_est's steps, bit for bit)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+MSC_DEV f32x2 rows_eval2(f32x2 x, f32x4 e0, float c2) {
+#pragma clang fp contract(off)
+  const f32x2 mh = {e0.x, e0.x}, ml = {e0.y, e0.y}, c0 = {e0.z, e0.z}, nc1 = {-e0.w, -e0.w}, sc = {c2, c2};
+  const f32x2 one = {1.0f, 1.0f}, l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+  const f32x2 a = __builtin_elementwise_fma(x, sc, -mh) - ml;
+  const f32x2 t = a * a, u = one + t;
+  const u32x2 magic = {0x7EF311C7u, 0x7EF311C7u};
+  const f32x2 ru = __builtin_bit_cast(f32x2, magic - __builtin_bit_cast(u32x2, u));
+  const f32x2 r = (t - (u - one)) * ru;
+  const f32x2 lg = {hw_log2(u.x), hw_log2(u.y)};
+  const f32x2 s = __builtin_elementwise_fma(nc1, __builtin_elementwise_fma(r, l2e, lg), c0);
+  return f32x2{__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
+}
+// one row against one table entry (unnormalised log2 probability)
+MSC_DEV float rows_entry(float x, f32x4 e0, f32x4 e1, bool masked, bool single) {
+  float s = nich_eval_log2_est(x, e0.x, e0.y, e0.z, e0.w, e1.x);
+  s += single ? e1.z : 0.f;
+  return masked ? e1.y + (single ? e1.z : 0.f) : s;
+}
+
+__global__ __launch_bounds__(128) void k_sweep_nich1_rows(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad,
+                                                           uint64_t row0, uint64_t nrows, uint64_t row_id0,
+                                                           int32_t *__restrict__ z, const float *__restrict__ crp,
+                                                           const uint64_t *__restrict__ rng, ZeroSpans zero,
+                                                           const float *__restrict__ tab, uint32_t B, uint32_t nb) {
+  __shared__ float blk_all[2][kRowsNb * 2 * 64];
+  typedef const __attribute__((address_space(4))) f32x4 *scalar_f4;
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  const FeatDesc fd = feats[0];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *blk = blk_all[wave];
+  constexpr float kLog2e = 1.44269504088896340736f;
+  const uint32_t nent = nb * B;
+  const float bound = tab[((size_t)nent + 8) * RT_WORDS];
+  const float le1 = crp[2 * (size_t)kpad + 1];
+  const bool any_empty = !__builtin_isinf(crp[2 * (size_t)kpad]);
+  const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
+  const scalar_f4 stab = (scalar_f4)tab;
+  const f32x4 *gtab = reinterpret_cast<const f32x4 *>(tab);
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 2 + wave, nwaves = (uint64_t)gridDim.x * 2;
+  const uint64_t per = nrows / nwaves, extra = nrows % nwaves;
+  const uint64_t rbeg = wave_id * per + (wave_id < extra ? wave_id : extra), rend = rbeg + per + (wave_id < extra ? 1 : 0);
+  for (uint64_t rb = rbeg; rb < rend; rb += 128) {
+    float x[2], u01[2], sloo[2];
+    int gz[2], pick[2];
+    bool has[2], masked[2], single[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint64_t n = rb + 64 * i + lane;
+      has[i] = n < rend;
+      x[i] = has[i] ? xcol[n] : 0.f;
+      gz[i] = has[i] ? z[n] : -1;
+      if ((uint32_t)gz[i] >= K) gz[i] = -1;                 // (an id outside the table: not assigned)
+      u01[i] = philox_uniform01(seed, sweep, row_id0 + n);
+      masked[i] = fd.mask != nullptr && has[i] && fd.mask[row0 + n] != 0;
+      sloo[i] = 0.f;
+      single[i] = false;
+      if (gz[i] >= 0) {
+        const float lm1 = crp[kpad + gz[i]];
+        const bool only = __builtin_isinf(lm1);                // the row is its group's only member
+        float s = only ? le1 : lm1;
+        if (!masked[i]) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + gz[i], kpad, fd.raw_f32[gz[i]], fd.raw_f32[kpad + gz[i]], x[i]);
+        sloo[i] = s * kLog2e - bound;
+        single[i] = only && any_empty;
+      }
+      pick[i] = gz[i];
+    }
+    const bool odd = __builtin_amdgcn_ballot_w64(masked[0] || masked[1] || single[0] || single[1]) != 0ull;
+    // ---- 1. the groups stream past: block sums per row ----
+    for (uint32_t b = 0; b < nb; b++) {
+      float run0 = 0.f, run1 = 0.f;
+      if (!odd) {
+        // the lane's two rows as the halves of packed operations (one v_pk_* for both), four groups per trip with the
+        // next four's constants already on their way (B is a multiple of 64; past the table's end: the first entries
+        // again, never used)
+        f32x2 run = {0.f, 0.f};
+        const f32x2 xx = {x[0], x[1]};
+        typedef const __attribute__((address_space(4))) float *scalar_f;
+        const scalar_f sflt = (scalar_f)tab;
+        // (eight groups a trip in two halves that take turns: nothing fetched ahead is copied from one scalar register
+        // to another, and every address is the trip's base plus a constant -- the table carries eight spare entries)
+        scalar_f4 t4 = stab + 2 * (size_t)(b * B);
+        scalar_f tf = sflt + (size_t)RT_WORDS * (b * B);
+        f32x4 ca[4], cb[4];
+        float sa[4], sb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ca[q] = t4[2 * q], sa[q] = tf[RT_WORDS * q + RT_C2];
+        for (uint32_t j = 0; j < B; j += 8, t4 += 16, tf += 8 * RT_WORDS) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) cb[q] = t4[2 * (4 + q)], sb[q] = tf[RT_WORDS * (4 + q) + RT_C2];
+          __builtin_amdgcn_sched_barrier(0);                 // (the loads stay up here: their wait belongs after the arithmetic)
+#pragma unroll
+          for (int q = 0; q < 4; q++) run += rows_eval2(xx, ca[q], sa[q]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) ca[q] = t4[2 * (8 + q)], sa[q] = tf[RT_WORDS * (8 + q) + RT_C2];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) run += rows_eval2(xx, cb[q], sb[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        run0 = run.x, run1 = run.y;
+      } else {
+        for (uint32_t j = 0; j < B; j++) {
+          const uint32_t k = b * B + j;
+          const f32x4 e0 = stab[2 * k], e1 = stab[2 * k + 1];
+          run0 += __builtin_amdgcn_exp2f(rows_entry(x[0], e0, e1, masked[0], single[0]));
+          run1 += __builtin_amdgcn_exp2f(rows_entry(x[1], e0, e1, masked[1], single[1]));
+        }
+      }
+      blk[(b * 2 + 0) * 64 + lane] = run0;
+      blk[(b * 2 + 1) * 64 + lane] = run1;
+    }
+    // ---- 2. / 3. every lane finishes its rows ----
+    bool redo[2] = {false, false};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (!has[i]) continue;
+      // the B entries of block `base / B` for this row, in order, eight gathers in flight at a time (one at a time the
+      // loop is two dependent L2 latencies per entry: 256 of them per visit cost more than the streaming pass);
+      // the row's own group: its leave-one-out value
+      auto block_pass = [&](uint32_t base, auto &&consume) {
+        for (uint32_t j = 0; j < B; j += 4) {
+          f32x4 ea[4], eb[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) ea[q] = gtab[2 * (base + j + q)], eb[q] = gtab[2 * (base + j + q) + 1];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float sc = rows_entry(x[i], ea[q], eb[q], masked[i], single[i]);
+            consume(j + q, __builtin_amdgcn_exp2f((int)(base + j + q) == gz[i] ? sloo[i] : sc));
+          }
+        }
+      };
+      if (gz[i] >= 0) {
+        const uint32_t bo = (uint32_t)gz[i] / B;
+        float sum = 0.f;
+        block_pass(bo * B, [&](uint32_t, float p) { sum += p; });
+        blk[(bo * 2 + i) * 64 + lane] = sum;
+      }
+      float total = 0.f;
+      for (uint32_t b = 0; b < nb; b++) total += blk[(b * 2 + i) * 64 + lane];
+      if (MSC_DBG_ALWAYS_REDO || !(total > 0x1p-60f && total < 0x1p100f)) {
+        redo[i] = true;
+        continue;
+      }
+      const float dart = u01[i] * total;
+      float c0 = 0.f;
+      uint32_t b0 = 0;
+      for (uint32_t b = 0; b + 1 < nb; b++) {                 // (monotone: step over the blocks that do not reach the dart)
+        const float v = blk[(b * 2 + i) * 64 + lane];
+        const bool miss = b0 == b && c0 + v < dart;
+        c0 = miss ? c0 + v : c0;
+        b0 += miss ? 1u : 0u;
+      }
+      uint32_t j0 = 0;
+      block_pass(b0 * B, [&](uint32_t j, float v) {
+        const bool miss = j0 == j && j + 1 < B && c0 + v < dart;
+        c0 = miss ? c0 + v : c0;
+        j0 += miss ? 1u : 0u;
+      });
+      const uint32_t k = b0 * B + j0;
+      pick[i] = (int)(k < K ? k : K - 1);
+    }
+    // rows whose total left the float range: exact maximum, total, search -- three passes over the table for the wave
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (__builtin_amdgcn_ballot_w64(redo[i]) == 0ull) continue;
+      float m = -INFINITY;
+      for (uint32_t k = 0; k < K; k++) {
+        const f32x4 e0 = stab[2 * k], e1 = stab[2 * k + 1];
+        const float s = (int)k == gz[i] ? sloo[i] : rows_entry(x[i], e0, e1, masked[i], single[i]);
+        m = fmaxf(m, s);
+      }
+      double total = 0.0;                                      // (thousands of terms in one running sum: in double)
+      for (uint32_t k = 0; k < K; k++) {
+        const f32x4 e0 = stab[2 * k], e1 = stab[2 * k + 1];
+        const float s = (int)k == gz[i] ? sloo[i] : rows_entry(x[i], e0, e1, masked[i], single[i]);
+        total += (double)__builtin_amdgcn_exp2f(s - m);
+      }
+      const double dart = (double)u01[i] * total;
+      double c0 = 0.0;
+      uint32_t k0 = 0;
+      for (uint32_t k = 0; k + 1 < K; k++) {
+        const f32x4 e0 = stab[2 * k], e1 = stab[2 * k + 1];
+        const float s = (int)k == gz[i] ? sloo[i] : rows_entry(x[i], e0, e1, masked[i], single[i]);
+        const double v = (double)__builtin_amdgcn_exp2f(s - m);
+        const bool miss = k0 == k && c0 + v < dart;
+        c0 = miss ? c0 + v : c0;
+        k0 += miss ? 1u : 0u;
+      }
+      if (redo[i]) pick[i] = (int)k0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (has[i]) z[rb + 64 * i + lane] = pick[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // One niw feature of small dimension, K <= 64 -- a Gaussian mixture on low-dimensional vectors, the textbook use of
 // the family: the whole Gibbs step fused like k_sweep_nich1.  A lane keeps one group (lower triangle of W_k, W_k mu_k
 // and the constants in registers), the rows of a chunk stream past as wave-uniform values, and q = |W_k (x - mu_k)|^2
@@ -1081,6 +1352,25 @@ static uint64_t grid_for(uint64_t work_items_per_wave_chunk, int num_cus, int wa
   const uint64_t cap = (uint64_t)num_cus * waves_per_cu_cap / 4;
   if (gx > cap) gx = cap;
   return gx ? gx : 1;
+}
+
+size_t sweep_nich1_rows_table_floats(uint32_t kpad) {
+  const RowsGeom g = rows_geom(kpad);
+  return ((size_t)g.nb * g.B + 8) * RT_WORDS + 16;       // (eight spare entries: the streaming pass fetches ahead)
+}
+uint32_t sweep_nich1_rows_max_groups() { return kRowsMaxK; }
+int launch_sweep_nich1_rows(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad,
+                            uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp,
+                            const uint64_t *rng, ZeroSpans zero, float *table) {
+  const RowsGeom g = rows_geom(kpad);
+  hipLaunchKernelGGL(k_nich_rows_table, dim3(1), dim3(1024), 0, stream, feats_dev, K, kpad, crp, table, g.nb * g.B);
+  uint64_t gx = (nrows + 255) / 256;                       // two waves a workgroup, 128 rows a wave visit
+  const uint64_t cap = (uint64_t)num_cus * 10;             // (16 KiB of block sums per workgroup: ten per CU)
+  if (gx > cap) gx = cap;
+  if (gx == 0) gx = 1;
+  hipLaunchKernelGGL(k_sweep_nich1_rows, dim3((unsigned)gx), dim3(128), 0, stream, feats_dev, K, kpad, row0, nrows, row_id0,
+                     z, crp, rng, zero, table, g.B, g.nb);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,

@@ -312,6 +312,7 @@ struct msc_state {
   std::vector<void *> owned;
   float *scratch = nullptr;       // score chunk for the generic sweep path
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
+  float *rows_table = nullptr;    // k_sweep_nich1_rows: per-group constants as scalar operands (single nich, K > 1024)
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;
   size_t scratch_floats = 0;

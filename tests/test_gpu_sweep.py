@@ -380,3 +380,65 @@ def test_single_nich_kernels_agree_on_random_shapes(gpu_ctx, monkeypatch, seed):
     assert a.min() >= 0 and a.max() < K and b.min() >= 0 and b.max() < K
     differ = int((a != b).sum())
     assert differ <= max(1, nrows // 2000), (differ, nrows, K)      # a dart within rounding of a CDF step, if any
+
+
+@pytest.mark.parametrize("K,N", [(1025, 3000), (2048, 5000), (3000, 260), (4096, 1), (5000, 129)])
+def test_sweep_single_nich_beyond_1024_groups_matches_oracle(gpu_ctx, K, N):
+    """k_sweep_nich1_rows (lane <-> row, the groups as scalar operands): against the oracle sweep, with singletons,
+    unassigned rows, empty groups and a few far outliers (rows that take the exact-maximum pass)"""
+    import common_amd
+    seed, sweep_idx, alpha = 100 + K, 2, 1.9
+    rng = np.random.default_rng(seed)
+    f = make_feature(orc.NICH, N, K, rng)
+    used = K - K // 8
+    z = rng.integers(0, used - 30, N).astype(np.int32)
+    if N > 100:
+        z[rng.choice(N, 20, replace=False)] = np.arange(used - 30, used - 10)      # twenty singletons
+        z[rng.choice(np.nonzero(z < used - 30)[0], N // 20, replace=False)] = -1
+        far = rng.choice(N, 10, replace=False)
+        f["values"][far] = (rng.choice([-1.0, 1.0], 10) * 10.0 ** rng.uniform(4, 7, 10)).astype(np.float32)
+    F = orc.Family(orc.NICH, f["hp"], 0, "f64")
+    ss64 = F.accumulate(K, f["values"], z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of([f]))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, F.hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    st.set_alpha(alpha)
+    st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
+    got = zt.cpu().numpy()
+    assert got.min() >= 0 and got.max() < K
+    want, scores = orc.sweep([(F, ss64, f["values"])], K, alpha, z, seed, sweep_idx, "f64", want_scores=True)
+    _check_agreement(got, want, scores, seed, sweep_idx, 0.99 if N > 200 else 0.97)
+
+
+def test_sweep_beyond_1024_groups_masked_rows_follow_the_prior_and_shards_agree(gpu_ctx):
+    import common_amd
+    K, N = 1500, 40000
+    rng = np.random.default_rng(9)
+    f = make_feature(orc.NICH, N, K, rng)
+    z = rng.integers(0, 60, N).astype(np.int32)                    # 60 groups in use, 1440 empty
+    mask = np.zeros(N, dtype=bool)
+    mask[:20000] = True                                             # the first half: prior only
+    rec = np.ma.masked_array(np.zeros(N, dtype=[("f0", np.float32)]), mask=[(bool(m),) for m in mask])
+    rec.data["f0"] = f["values"]
+    view = common_amd.DataView.from_recarray(gpu_ctx, rec)
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, orc.Family(orc.NICH, f["hp"], 0, "f64").hp)
+    z0 = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, z0)
+    st.set_alpha(3.0)
+    whole = torch.full((N,), -1, dtype=torch.int32, device=gpu_ctx.torch_device)   # unassigned: no leave-one-out
+    st.sweep_assign(view, whole, seed=6, sweep=0)
+    got = whole.cpu().numpy()
+    counts = st.get_group_counts().astype(np.float64)
+    pc = np.where(counts > 0, counts, 3.0 / (counts == 0).sum())
+    emp_used = np.bincount(got[:20000], minlength=K)[:60] / 20000.0
+    assert np.abs(emp_used - (pc / pc.sum())[:60]).max() < 0.012           # masked rows: the CRP prior
+    assert abs((got[:20000] >= 60).mean() - 3.0 / pc.sum()) < 0.01        # ... alpha's share spread over the empty groups
+    parts = torch.full((N,), -1, dtype=torch.int32, device=gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=6, sweep=0, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
