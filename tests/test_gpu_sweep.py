@@ -442,3 +442,29 @@ def test_sweep_beyond_1024_groups_masked_rows_follow_the_prior_and_shards_agree(
         st.sweep_assign(view, zs, seed=6, sweep=0, row0=lo, nrows=n, row_id0=lo)
         parts[lo:lo + n] = zs
     assert torch.equal(whole, parts)
+
+
+def test_outliers_in_tiny_groups_keep_a_finite_leave_one_out_score(gpu_ctx, nich1_kernel):
+    """a row 1e6 away in a group of three: count_times_variance is ~1e12 as a float (ulp 1e5), so the variance rebuilt
+    without the row can come out below zero -- it is clamped at zero instead of turning the score into NaN (which sent
+    such rows to group 0)"""
+    import common_amd
+    K, N, seed, sweep_idx, alpha = 1000, 3000, 1125, 2, 1.9
+    rng = np.random.default_rng(seed)
+    f = make_feature(orc.NICH, N, K, rng)
+    z = rng.integers(0, 850, N).astype(np.int32)
+    far = rng.choice(N, 30, replace=False)
+    f["values"][far] = (rng.choice([-1.0, 1.0], 30) * 10.0 ** rng.uniform(4, 7, 30)).astype(np.float32)
+    F = orc.Family(orc.NICH, f["hp"], 0, "f64")
+    ss64 = F.accumulate(K, f["values"], z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of([f]))
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], K)
+    st.set_hp(0, F.hp)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.accumulate(view, zt)
+    st.set_alpha(alpha)
+    loo = st.score_value(view, z=zt).cpu().numpy()
+    assert np.isfinite(loo[:, :850]).all()
+    st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
+    want, scores = orc.sweep([(F, ss64, f["values"])], K, alpha, z, seed, sweep_idx, "f64", want_scores=True)
+    _check_agreement(zt.cpu().numpy(), want, scores, seed, sweep_idx, 0.995)
