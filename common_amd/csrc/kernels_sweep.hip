@@ -551,6 +551,8 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
 // the materialise-and-sample path this replaces ran 4.5 / 9.4 ms per million rows at K = 2048 / 4096.
 // Rows whose total leaves the float range are redone by the wave with the exact maximum (three passes over the table).
 // ---------------------------------------------------------------------------
+// (-DMSC_DBG_ALWAYS_REDO=1 sends every row of k_sweep_nich1_rows through the exact-maximum pass, which outliers alone
+// reach otherwise: how that pass was checked against the oracle tests)
 #ifndef MSC_DBG_ALWAYS_REDO
 #define MSC_DBG_ALWAYS_REDO 0
 #endif
