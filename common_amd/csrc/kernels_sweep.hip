@@ -738,7 +738,11 @@ __global__ __launch_bounds__(128) void k_sweep_nich1_rows(const FeatDesc *__rest
         for (uint32_t j = 0; j < B; j += 4) {
           f32x4 ea[4], eb[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) ea[q] = gtab[2 * (base + j + q)], eb[q] = gtab[2 * (base + j + q) + 1];
+          for (int q = 0; q < 4; q++) {                       // (32-bit byte offsets from the uniform base: one address register)
+            const uint32_t at = (base + j + q) * (uint32_t)(RT_WORDS * sizeof(float));
+            ea[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(gtab) + at);
+            eb[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(gtab) + at + 16u);
+          }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const float sc = rows_entry(x[i], ea[q], eb[q], masked[i], single[i]);
