@@ -86,6 +86,15 @@ extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
   ctx->mailbox_bytes = 192 * 1024;       // niw at dim 128: a 66 KB record + a 66 KB hp block
   MSC_HIP(hipHostMalloc(&ctx->mailbox_host, ctx->mailbox_bytes, hipHostMallocMapped));
   MSC_HIP(hipHostGetDevicePointer(&ctx->mailbox_dev, ctx->mailbox_host, 0));
+  const char *sw = std::getenv("MSC_SYNC_WORD");           // 0: plain hipStreamSynchronize (A/B knob)
+  if (sw && std::atoi(sw) == 0) ctx->sync_word_ok = false;
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->sync_word_host), 64, hipHostMallocMapped) == hipSuccess) {
+    *ctx->sync_word_host = 0;
+    if (hipHostGetDevicePointer(&ctx->sync_word_dev, ctx->sync_word_host, 0) != hipSuccess) ctx->sync_word_ok = false;
+  } else {
+    (void)hipGetLastError();
+    ctx->sync_word_host = nullptr;
+  }
   *out = ctx.release();
   return MSC_OK;
 }
@@ -98,6 +107,7 @@ extern "C" int msc_context_destroy(msc_context *ctx) {
   for (auto &a : ctx->vmm) vmm_free(a);
   ctx->vmm.clear();
   if (ctx->mailbox_host) (void)hipHostFree(ctx->mailbox_host);
+  if (ctx->sync_word_host) (void)hipHostFree(ctx->sync_word_host);
   if (ctx->record_stream) (void)hipStreamDestroy(ctx->record_stream);
   delete ctx;
   return MSC_OK;
@@ -111,6 +121,23 @@ extern "C" int msc_context_set_stream(msc_context *ctx, void *stream) {
 
 extern "C" int msc_context_synchronize(msc_context *ctx) {
   MSC_REQUIRE(ctx, "null context");
+  // The per-entity paths (hip::mixture_state: remove, score, add) wait here once per move, for kernels that take a few
+  // microseconds: waking up from hipStreamSynchronize costs as much again.  So the stream writes a sequence number
+  // into a pinned word when it gets here and the host watches the word; bounded, the stream wait is the fallback.
+  if (ctx->sync_word_host && ctx->sync_word_ok) {
+    const uint32_t seq = ++ctx->sync_seq;
+    if (hipStreamWriteValue32(ctx->stream, ctx->sync_word_dev, seq, 0) == hipSuccess) {
+      volatile uint32_t *w = ctx->sync_word_host;
+      for (int spin = 0; spin < 400000; spin++)
+        if (*w == seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          return MSC_OK;
+        }
+    } else {
+      (void)hipGetLastError();
+      ctx->sync_word_ok = false;
+    }
+  }
   MSC_HIP(hipStreamSynchronize(ctx->stream));
   return MSC_OK;
 }
@@ -1744,7 +1771,15 @@ extern "C" int msc_value_op_single(msc_context *ctx, int family, uint32_t dim, i
   if (host_value) std::memcpy(mb + hd.value_off, host_value, v_bytes);
   if (launch_value_op(ctx->stream, ctx->mailbox_dev, dim, family))
     return fail(MSC_EHIP, "k_value_op launch failed: %s", hipGetErrorString(hipGetLastError()));
-  MSC_HIP(hipStreamSynchronize(ctx->stream));
+  // the kernel's last act is status = 1 in this (pinned, host-coherent) mailbox: watching for it costs a PCIe write's
+  // latency, waking up from hipStreamSynchronize several microseconds more.  Bounded: the stream wait is the fallback.
+  {
+    volatile int32_t *flag = &reinterpret_cast<volatile MailboxHeader *>(mb)->status;
+    bool seen = false;
+    for (int spin = 0; spin < 200000 && !seen; spin++) seen = *flag == 1;
+    if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+    else MSC_HIP(hipStreamSynchronize(ctx->stream));
+  }
   MailboxHeader back;
   std::memcpy(&back, mb, sizeof back);
   if (back.status != 1) return fail(MSC_EHIP, "k_value_op did not complete");

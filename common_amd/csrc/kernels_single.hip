@@ -190,9 +190,14 @@ __global__ __launch_bounds__(64) void k_value_op(unsigned char *__restrict__ mb)
       default: break;   // noop model
     }
   }
+  // the host spins on `status` in the pinned mailbox instead of waiting for the stream: everything any thread wrote
+  // must be visible to the host before the flag is
+  __threadfence_system();
+  __syncthreads();
   if (t == 0) {
     h->score = (float)score;
-    h->status = 1;
+    __threadfence_system();
+    __hip_atomic_store(&h->status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -248,6 +248,12 @@ struct msc_context {
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;
   size_t mailbox_bytes = 0;
+  // msc_context_synchronize: a word of pinned memory the stream writes a sequence number into (hipStreamWriteValue32)
+  // and the host watches, instead of sleeping in hipStreamSynchronize
+  uint32_t *sync_word_host = nullptr;
+  void *sync_word_dev = nullptr;
+  uint32_t sync_seq = 0;
+  bool sync_word_ok = true;                // cleared when the stream operation is refused: plain stream waits from then on
 };
 
 struct msc_dataview {
