@@ -7,9 +7,10 @@
 // together; the workgroup copies a group with global_load_lds, synchronises once, and every wave
 // then adds the group's features for its rows into registers on its own: conflict-free
 // ds_read_b128 (lane <-> 4 groups, 1 KiB table rows), runs of plain lookup features in a loop of
-// their own.  What bounds it is the instruction count per (row, feature), not the copies
-// (profiles/r01_c3_stage_costs.txt); a lane <-> 1 group tiling (512 rows per workgroup, 4x fewer
-// table bytes) was measured 2x slower for that reason.
+// their own (a software pipeline: descriptor head two features ahead, value one ahead).  What bounds it: the lookup
+// phase the CU's LDS port (a wave's ds_read_b128 is 1 KiB = 8 cycles), the nich phase the vector ALUs, one after the
+// other; a lane <-> 1 group tiling (512 rows per workgroup, 4x fewer table bytes) was measured
+// 2x slower (more instructions per evaluation).
 // Nothing in here evaluates a transcendental in double: leave-one-out terms arrive precomputed
 // per row (k_loo_own), counts beyond the tables are patched afterwards (k_gp_large_fix).
 // Table rows beyond the 64 a feature may stage are gathered from L2; Dirichlet-Multinomial tables
@@ -353,13 +354,6 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
     }
     f0 = f1;
   }
-}
-
-// the raw value of this lane's row for a lookup feature of a run (bool columns as 0 / 1)
-MSC_DEV uint32_t run_value(const FeatDesc &fd, uint64_t myrow, bool has_row) {
-  if (!has_row) return 0u;
-  if (fd.kind == MSC_KIND_LOOKUP_U8) return (uint32_t)(reinterpret_cast<const uint8_t *>(fd.col)[myrow] != 0);
-  return reinterpret_cast<const uint32_t *>(fd.col)[myrow];
 }
 
 template <int R, int W, bool DM>
