@@ -259,6 +259,9 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
                    "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
                    "backend": backend},
         "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
+        "one_rank_reference": "the N = 1 line reports this workload at one rank as c5_shard.value (rows/s): weak-scaling "
+                              "ratio at N ranks = value / (N * c5_shard.value); the N = 1 line's own `value` is the C2 "
+                              "scoring pass (evals/s), the metric BASELINE.json quotes for one GPU",
         "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t"),
     }
 
