@@ -229,7 +229,8 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
         drv.sweep(seed=73, sweep_index=idx[0])
         idx[0] += 1
 
-    for _ in range(a.warmup):
+    prewarm = max(0, 5 - a.warmup)                           # (25 ms of work before anything counts: the clocks, as in run_c2)
+    for _ in range(prewarm + a.warmup):
         one()
     sync_all()
     t0 = time.perf_counter()
@@ -257,7 +258,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
                                                                             "RCCL" if backend == "nccl" else backend),
                    "rows_per_gpu": nrows, "groups": C5_GROUPS, "features": 1, "parallelism": "row-shard x%d" % world,
                    "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
-                   "backend": backend},
+                   "backend": backend, "clock_prewarm_steps": prewarm},
         "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
         "one_rank_reference": "the N = 1 line reports this workload at one rank as c5_shard.value (rows/s): weak-scaling "
                               "ratio at N ranks = value / (N * c5_shard.value); the N = 1 line's own `value` is the C2 "
