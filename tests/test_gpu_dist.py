@@ -44,6 +44,10 @@ def test_two_ranks_single_nich_sweeps_equal_the_unsharded_run(gpu_ctx, tmp_path)
     _check(_launch(tmp_path, "nich", 400_000, 1024, 3))     # C5's shape (one nich feature, K = 1024: k_sweep_nich1)
 
 
+def test_two_ranks_single_nich_beyond_1024_groups(gpu_ctx, tmp_path):
+    _check(_launch(tmp_path, "nich", 200_000, 1500, 2))     # k_sweep_nich1_rows (lane <-> row) in the sharded step
+
+
 def test_two_ranks_mixed_features_sweeps_equal_the_unsharded_run(gpu_ctx, tmp_path):
     _check(_launch(tmp_path, "mixed", 200_000, 48, 2))      # bb + gp + dd + nich, K = 48 (k_narrow), int64 + f64 tables
 
