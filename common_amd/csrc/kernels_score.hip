@@ -468,7 +468,8 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
       const int g0 = z[rb + lane];
       single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
     }
-    if (CRP) {
+    const bool tail_only = nsplit == 0;                  // (score_tile, SPLIT: the prior's lo part is added afterwards then)
+    if (CRP && !tail_only) {
       const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
       const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
 #pragma unroll
@@ -477,7 +478,13 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
     }
-    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
+    score_tile<R, W, DM, true>(feats, nfeat, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
+    if (CRP && tail_only) {
+      const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
+      const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
+#pragma unroll
+      for (int r = 0; r < R; r++) add4(acc[r], crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0));
+    }
     // epilogue, row by row (one pass, so nothing of one row outlives its store): + hi of the prior; then the own
     // group's entry becomes the row's pre-computed leave-one-out value (k_loo_own) through a KiB of LDS that belongs
     // to the wave (beyond the table slot, so no barrier) -- park the row, one lane overwrites the entry, read the row
@@ -491,6 +498,136 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
     float4 hi = make_float4(0, 0, 0, 0);
     if (CRP) {                                            // fetched again (an L2 hit per chunk) rather than held across
       const float *again = crp;                           // the tile scorer: 4 VGPRs and 4 SGPR pairs of isinf masks
+      asm volatile("" : "+s"(again));
+      hi = ld4(again + kb);
+    }
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+    }
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
+      if (LOO) {
+        const int g = lane_bcast(gz, r);
+        if (g >= 0) {                                     // (wave-uniform)
+          mine[lane] = acc[r];
+          if (lane == 0) reinterpret_cast<float *>(mine)[(uint32_t)g % kGroupTile] = lane_bcast(sloo, r);
+          __builtin_amdgcn_wave_barrier();
+          acc[r] = mine[lane];
+        }
+      }
+      if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_score_tile_roles: the general path when a state has BOTH staged lookup features and unmasked nich features and
+// enough rows to fill the chip.  In k_score_tile every wave runs the lookup phase (bound by the CU's LDS port: a
+// wave's ds_read_b128 is 1 KiB = 8 cycles) and then the nich phase (bound by the vector ALUs), and a chunk costs the
+// SUM of the two (C3: ~60 k + ~95 k cycles of 193 k).  Here the workgroup's sixteen waves split the phases between
+// them: waves 0-7 take the lookups of all 128 rows (16 rows each), waves 8-15 the nich features of the same rows --
+// their constants straight from the tables in L2, no LDS, so nothing ties them to the staging of the lookup groups
+// except the workgroup barriers, which they meet a feature apart -- and at the end of a chunk wave 8 + p hands its
+// sums to wave p through the (then idle) table slot.  (prior + lookups) + (nich features): the sum score_tile<SPLIT>
+// forms, so a row gets the same bits from either kernel.
+// ---------------------------------------------------------------------------
+constexpr int kRoleRows = 16;          // rows per wave pair
+template <bool LOO, bool CRP>
+__global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
+                                                               uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                               const int32_t *__restrict__ z, const float *__restrict__ own,
+                                                               const float *__restrict__ crp, float *__restrict__ out,
+                                                               uint64_t ld) {
+  constexpr int R = kRoleRows;
+  __shared__ float4 lds[kGrpRows * 64 + (LOO ? 8 * 64 : 0)];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool looker = wave < 8;                           // waves 0-7: lookups; 8-15: nich
+  const int pair = wave & 7;
+  const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  int ngroups = 0;                                        // staged groups of the lookup phase: two barriers each
+  for (int f = 0; f < nsplit; f = (int)feats[f].grp_end) ngroups++;
+  const int nnich = nfeat - nsplit;
+  const int per_interval = (nnich + 2 * ngroups - 1) / (2 * ngroups);
+  float4 logcnt = make_float4(0, 0, 0, 0);
+  float le0 = 0, le1 = 0;
+  if (CRP && looker) {
+    logcnt = ld4(crp + kb);
+    le0 = crp[2 * (size_t)kpad];
+    le1 = crp[2 * (size_t)kpad + 1];
+  }
+  const uint64_t rows_per_wg = 8 * R;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;       // relative to row0
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    float4 acc[R];
+    if (!looker) {
+      // ---- the nich waves: constants from L2, one batch of features between consecutive barriers ----
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+      int f = nsplit;
+      const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
+      for (int b = 0; b <= 2 * ngroups; b++) {
+        const int upto = b < 2 * ngroups ? (f + per_interval < nfeat ? f + per_interval : nfeat) : nfeat;
+        for (; f < upto; f++) {
+          const FeatDesc &fd = feats[f];
+          const float *t = fd.tab + kb;
+          const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
+                       c0 = ld4(t + (size_t)NICH_C0 * kpad), c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
+                       c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
+          const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const float x = lane_bcast(xv, r);
+            acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+            acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+            acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+            acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two rows' temporaries at a time: 64 registers are the sums
+          }
+        }
+        __syncthreads();                                  // barriers 0 .. 2 ngroups - 1: the lookup waves' staging; the last: slot free
+      }
+      float4 *mine = lds + (size_t)pair * R * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < R; r++) mine[r * 64] = acc[r];
+      __syncthreads();                                    // the sums are in the slot
+      continue;
+    }
+    // ---- the lookup waves ----
+    int single = 0;                                       // lane r: removing row r empties its group
+    if (LOO && CRP && lane < nr) {
+      const int g0 = z[rb + lane];
+      single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
+    }
+    if (CRP) {
+      const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
+      const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+    }
+    score_tile_groups<R, 8, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
+    __syncthreads();                                      // every lookup wave is done with the slot
+    __syncthreads();                                      // the nich sums are in it
+    {
+      const float4 *theirs = lds + (size_t)pair * R * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < R; r++) add4(acc[r], theirs[r * 64]);
+    }
+    // epilogue as in k_score_tile: + hi of the prior, the own group's leave-one-out value through the wave's KiB of LDS
+    float4 *mine = lds + (size_t)kGrpRows * 64 + (size_t)wave * 64;
+    int gz = -1;
+    float sloo = 0.f;
+    float4 hi = make_float4(0, 0, 0, 0);
+    if (CRP) {
+      const float *again = crp;
       asm volatile("" : "+s"(again));
       hi = ld4(again + kb);
     }
@@ -615,6 +752,14 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+bool tile_roles_enabled() {
+  static const bool on = [] {
+    const char *e = std::getenv("MSC_TILE_ROLES");      // A/B knob: 0 keeps every wave on both phases (k_score_tile)
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+
 int tile_rows_per_wave() {
   static const int r = [] {
     const char *e = std::getenv("MSC_TILE_ROWS");   // tuning knob: rows per wave, 8 (default) | 16
@@ -668,6 +813,9 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
     const dim3 grid((unsigned)gx, ktiles);
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+                         nrows, z, own, crp, out, ld);
+    else if (!small4 && nsplit > 0 && nsplit < nfeat && tile_roles_enabled())
+      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (small2)
       hipLaunchKernelGGL((k_score_tile<2, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,

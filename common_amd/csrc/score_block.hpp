@@ -461,13 +461,27 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
 // rows are out of range passes nr = 0; row_safe = any row of the call's range (lanes without a row read it and
 // drop what they read).  lds: the kGrpRows * 64 float4 slot.
 // ---------------------------------------------------------------------------
-template <int R, int W, bool DM>
+// SPLIT (the scoring kernels): the unmasked nich features are summed on their own, from zero, and the two sums added
+// at the end -- (what acc held + the first phase's features) + (the second phase's) -- so that the kernel whose waves
+// split the two phases between them (k_score_tile_roles) and the ones that run them one after the other give a row
+// the same bits.  A state of unmasked nich features only (nsplit == 0) has nothing in the first sum: its caller
+// starts acc at zero and adds what it would have started from afterwards (the same sum, one accumulator alive).
+template <int R, int W, bool DM, bool SPLIT = false>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nsplit, uint32_t kpad, uint32_t ktile,
                         int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds, float4 (&acc)[R]) {
   score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, row_safe, lds, acc);
   if (nsplit < nfeat) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
+    if (!SPLIT || nsplit == 0) {
+      score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
+    } else {
+      float4 accn[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) accn[r] = make_float4(0, 0, 0, 0);
+      score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, accn);
+#pragma unroll
+      for (int r = 0; r < R; r++) add4(acc[r], accn[r]);
+    }
   }
 }
 

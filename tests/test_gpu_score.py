@@ -261,3 +261,34 @@ def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
     niw = fs[1][0].score_matrix(fs[1][1], feats[1]["values"])
     niw[hide] = 0.0
     assert rel_err(got, want + niw).max() <= TOL
+
+
+@pytest.mark.parametrize("K", [100, 300])
+def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K):
+    """40k rows take the kernel whose waves split the lookup and the nich phase between them (k_score_tile_roles), a
+    few hundred rows the ones that run the phases one after the other: (prior + lookups) + (nich) in both, so the
+    same row must come out bit for bit -- plain, leave-one-out, with the prior"""
+    import common_amd
+    rng = np.random.default_rng(K)
+    N = 40_000
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BB, 0), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(1.2)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    for kw in ({}, {"z": zt}, {"z": zt, "crp_prior": True}):
+        whole = st.score_value(view, **kw)
+        for row0, n in ((0, 200), (12_345, 64), (39_900, 100)):
+            kk = dict(kw)
+            if "z" in kk:
+                kk["z"] = zt[row0:row0 + n].contiguous()
+            part = st.score_value(view, row0=row0, nrows=n, **kk)
+            assert torch.equal(part, whole[row0:row0 + n]), (kw.keys(), row0)
+    got = st.score_value(view).cpu().numpy()
+    rows = rng.choice(N, 300, replace=False)
+    assert rel_err(got[rows], oracle_scores(feats, fs, rows=rows)).max() <= TOL
