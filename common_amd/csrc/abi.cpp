@@ -575,6 +575,13 @@ static void plan_groups(msc_state *st) {
     else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32, d.run_clamp = d.grp_rows - 1;
     else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32, d.run_clamp = d.dim - 1;
   }
+  bool has_dm = false;
+  st->tile_roles_ok = split > 0 && split < n;
+  for (uint32_t i = 0; i < n; i++) {
+    has_dm |= t[i].family == MSC_DM;
+    if (i < split && t[i].kind == MSC_KIND_GENERIC) st->tile_roles_ok = false;
+  }
+  if (has_dm) st->tile_roles_ok = false;
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
@@ -1169,7 +1176,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   if (n_niw < st->nfeat || crp) {
     bool has_dm = false;
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
-    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : MSC_PATH_TILE;
+    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
     auto launch = [&](int shape) {
       return launch_score(s, st->ctx->num_cus, path, shape, descs, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,

@@ -543,15 +543,15 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
                                                                uint64_t ld) {
   constexpr int R = kRoleRows;
   __shared__ float4 lds[kGrpRows * 64 + (LOO ? 8 * 64 : 0)];
+  __shared__ uint32_t lookers_arrived;                    // the lookup waves' own barrier (WaveSubsetBarrier)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool looker = wave < 8;                           // waves 0-7: lookups; 8-15: nich
+  if (threadIdx.x == 0) lookers_arrived = 0u;
+  __syncthreads();
+  WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
   const int pair = wave & 7;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  int ngroups = 0;                                        // staged groups of the lookup phase: two barriers each
-  for (int f = 0; f < nsplit; f = (int)feats[f].grp_end) ngroups++;
-  const int nnich = nfeat - nsplit;
-  const int per_interval = (nnich + 2 * ngroups - 1) / (2 * ngroups);
   float4 logcnt = make_float4(0, 0, 0, 0);
   float le0 = 0, le1 = 0;
   if (CRP && looker) {
@@ -569,29 +569,25 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
       // ---- the nich waves: constants from L2, one batch of features between consecutive barriers ----
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
-      int f = nsplit;
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      for (int b = 0; b <= 2 * ngroups; b++) {
-        const int upto = b < 2 * ngroups ? (f + per_interval < nfeat ? f + per_interval : nfeat) : nfeat;
-        for (; f < upto; f++) {
-          const FeatDesc &fd = feats[f];
-          const float *t = fd.tab + kb;
-          const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
-                       c0 = ld4(t + (size_t)NICH_C0 * kpad), c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
-                       c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
-          const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
+      for (int f = nsplit; f < nfeat; f++) {
+        const FeatDesc &fd = feats[f];
+        const float *t = fd.tab + kb;
+        const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
+                     c0 = ld4(t + (size_t)NICH_C0 * kpad), c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
+                     c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
+        const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
 #pragma unroll
-          for (int r = 0; r < R; r++) {
-            const float x = lane_bcast(xv, r);
-            acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-            acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-            acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-            acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two rows' temporaries at a time: 64 registers are the sums
-          }
+        for (int r = 0; r < R; r++) {
+          const float x = lane_bcast(xv, r);
+          acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+          acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+          acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+          acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+          if (r & 1) __builtin_amdgcn_sched_barrier(0);     // two rows' temporaries at a time: 64 registers are the sums
         }
-        __syncthreads();                                  // barriers 0 .. 2 ngroups - 1: the lookup waves' staging; the last: slot free
       }
+      __syncthreads();                                    // every lookup wave is done with the slot
       float4 *mine = lds + (size_t)pair * R * 64 + lane;
 #pragma unroll
       for (int r = 0; r < R; r++) mine[r * 64] = acc[r];
@@ -613,7 +609,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
     }
-    score_tile_groups<R, 8, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
+    score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
     __syncthreads();                                      // every lookup wave is done with the slot
     __syncthreads();                                      // the nich sums are in it
     {
@@ -814,7 +810,7 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int nich1_
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
-    else if (!small4 && nsplit > 0 && nsplit < nfeat && tile_roles_enabled())
+    else if (!small4 && path == MSC_PATH_TILE_ROLES && tile_roles_enabled())
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (small2)

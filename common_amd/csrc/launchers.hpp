@@ -47,7 +47,9 @@ int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);
 // which scoring kernel a state takes (abi.cpp decides from its feature list)
-enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2 };
+// (TILE_ROLES: a tile state whose first phase is lookup runs only and whose second phase is not empty -- with enough
+// rows its workgroups split the phases between their waves, k_score_tile_roles)
+enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TILE_ROLES = 3 };
 // k_score_nich1 launch shapes: a wave visits `visits` blocks of q consecutive rows (index 0 = the default)
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;

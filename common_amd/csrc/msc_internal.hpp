@@ -318,6 +318,7 @@ struct msc_state {
   std::vector<void *> owned;
   float *scratch = nullptr;       // score chunk for the generic sweep path
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
+  bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
   float *rows_table = nullptr;    // k_sweep_nich1_rows: per-group constants as scalar operands (single nich, K > 1024)
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;

@@ -310,10 +310,34 @@ MSC_DEV void score_dm_feature_staged(const FeatDesc &fd, int lane, uint64_t myro
 // this costs ~1000 cycles where a barrier per feature cost ~2500 (profiles/r01_c3_stage_costs.txt).
 // ---------------------------------------------------------------------------
 // copy the table blocks of the feature group [f0, f1) into the slot and wait for them (two barriers)
-template <int W>
+// (the barrier is a policy: the whole workgroup, or -- k_score_tile_roles -- only the waves that share the slot)
+struct WorkgroupBarrier {
+  MSC_DEV void operator()() const { __syncthreads(); }
+};
+// A barrier among the first NW waves of the workgroup, through a counter in LDS: every wave adds one and waits until
+// the count reaches NW times the number of barriers it has passed.  The waves that take part must execute the same
+// sequence of barriers (they do: the same loop over the same feature groups); the wait is bounded all the same, so
+// that a mistake costs wrong numbers and not a hung GPU.
+template <int NW>
+struct WaveSubsetBarrier {
+  uint32_t *counter;                                    // in LDS, zeroed by the workgroup before first use
+  uint32_t passed;
+  MSC_DEV void operator()() {
+    passed++;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t want = passed * (uint32_t)NW;
+    for (int spin = 0; spin < (1 << 22); spin++) {
+      if ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+template <int W, typename Barrier = WorkgroupBarrier>
 MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uint32_t kpad, uint32_t ktile, int lane,
-                         int wave, float4 *__restrict__ lds) {
-  __syncthreads();                                      // the slot's previous readers are done
+                         int wave, float4 *__restrict__ lds, Barrier &&bar = Barrier()) {
+  bar();                                                // the slot's previous readers are done
   for (int f = f0; f < f1; f++) {
     const FeatDesc &fd = feats[f];
     const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
@@ -323,7 +347,7 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
       glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the group's tables has landed
-  __syncthreads();                                      // ... everyone's
+  bar();                                                // ... everyone's
 }
 
 // second phase: the unmasked nich features (the host puts them last, abi.cpp plan_groups), group by group,
@@ -356,10 +380,12 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
   }
 }
 
-template <int R, int W, bool DM>
+// GENERIC = false: the caller knows every feature of the phase to be of a lookup kind (k_score_tile_roles: the host
+// checks the plan), and the branch for everything else -- with its temporaries -- is not compiled in
+template <int R, int W, bool DM, bool GENERIC = true, typename Barrier = WorkgroupBarrier>
 MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                                int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds,
-                               float4 (&acc)[R]) {
+                               float4 (&acc)[R], Barrier &&bar = Barrier()) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
@@ -367,7 +393,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
   int f0 = 0;
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].grp_end;
-    stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
+    stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds, bar);
     int f = f0;
     while (f < f1) {
       // A run of unmasked lookup features (bb, gp, bnb, dd with their whole table staged; the host marks them
@@ -433,6 +459,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         if (f > fe) f = fe;
       }
       if (f >= f1) break;
+      if (!GENERIC) continue;                           // (the next run starts here)
       const FeatDesc &fd = feats[f];
       if (fd.kind != MSC_KIND_GENERIC) continue;        // the next run starts here
       if (DM && fd.family == MSC_DM) {
