@@ -988,9 +988,14 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
       }
     }
     float4 acc[R];
+    const bool tail_only = nsplit == 0;                    // (score_tile, SPLIT: the prior is added afterwards then)
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile<R, W, DM>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
+    for (int r = 0; r < R; r++) acc[r] = tail_only ? make_float4(0, 0, 0, 0) : crp_prior4(logcnt, lane_bcast(erow, r));
+    score_tile<R, W, DM, true>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
+    if (tail_only) {
+#pragma unroll
+      for (int r = 0; r < R; r++) add4(acc[r], crp_prior4(logcnt, lane_bcast(erow, r)));
+    }
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll
@@ -1003,6 +1008,102 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
       for (int j = 0; j < 4; j++)
         if (kb + j >= K) s[j] = -INFINITY;
       const int pick = sample_from_scores<4>(s, lane_bcast(u01, r), lane, K);
+      if (lane == r) znew = pick;
+    }
+    if (lane < nr) z[rb + lane] = znew;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_sweep_tile_roles: k_sweep_tile with the workgroup's waves split between the lookup phase (waves 0-7, sixteen rows
+// each, the table slot and a barrier of their own) and the nich phase (waves 8-15, the same rows, constants from L2) --
+// kernels_score.hip k_score_tile_roles, where the why is written down.  The lookup waves take the sums over and draw.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
+                                                               uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                               uint64_t row_id0, int32_t *__restrict__ z,
+                                                               const float *__restrict__ own, const float *__restrict__ crp,
+                                                               const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  constexpr int R = 16;
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  __shared__ float4 lds[kGrpRows * 64];
+  __shared__ uint32_t lookers_arrived;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool looker = wave < 8;
+  const int pair = wave & 7;
+  if (threadIdx.x == 0) lookers_arrived = 0u;
+  __syncthreads();
+  WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
+  const uint32_t kb = lane * 4;            // single k-tile: K <= 256
+  const float4 logcnt = ld4(crp + kb);
+  const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+  const uint64_t rows_per_wg = 8 * R;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    float4 acc[R];
+    if (!looker) {
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+      const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
+      for (int f = nsplit; f < nfeat; f++) {
+        const FeatDesc &fd = feats[f];
+        const float *t = fd.tab + kb;
+        const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
+                     c0 = ld4(t + (size_t)NICH_C0 * kpad), c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
+                     c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
+        const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float x = lane_bcast(xv, r);
+          acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
+          acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
+          acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
+          acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+          if (r & 1) __builtin_amdgcn_sched_barrier(0);     // two rows' temporaries at a time
+        }
+      }
+      __syncthreads();                                    // every lookup wave is done with the slot
+      float4 *mine = lds + (size_t)pair * R * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < R; r++) mine[r * 64] = acc[r];
+      __syncthreads();                                    // the sums are in the slot
+      continue;
+    }
+    int gz = -1;
+    float sloo = 0.f, erow = le0;
+    if (lane < nr) {
+      gz = z[rb + lane];
+      if ((uint32_t)gz >= K) gz = -1;                     // (an id outside the table: not assigned)
+      if (gz >= 0) {
+        sloo = own[rb + lane];
+        erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
+    score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc, lbar);
+    __syncthreads();
+    __syncthreads();
+    {
+      const float4 *theirs = lds + (size_t)pair * R * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < R; r++) add4(acc[r], theirs[r * 64]);
+    }
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    int znew = gz;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float4 s4 = acc[r];
+      const int g = lane_bcast(gz, r);
+      if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
+      float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (kb + j >= K) sc[j] = -INFINITY;
+      const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
       if (lane == r) znew = pick;
     }
     if (lane < nr) z[rb + lane] = znew;
@@ -1425,8 +1526,8 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
-                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, const FeatDesc *feats_dev, int nfeat, int nsplit,
+                       uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
   const int R = tile_rows_per_wave();
@@ -1447,6 +1548,9 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatD
                        row_id0, z, own, crp, rng, zero);
   else if (small)
     hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, rng, zero);
+  else if (roles_ok && tile_roles_enabled())
+    hipLaunchKernelGGL(k_sweep_tile_roles, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (R == 16)
     hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,

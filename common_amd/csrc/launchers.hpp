@@ -70,9 +70,10 @@ struct ZeroSpans {
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
-                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
-                       const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
+bool tile_roles_enabled();
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, const FeatDesc *feats_dev, int nfeat, int nsplit,
+                       uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
+                       const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero);
 int sweep_niw1_max_groups(uint32_t dim);
 // single nich feature beyond 1024 groups (lane <-> row, groups as scalar operands); `table`: device scratch of
 // sweep_nich1_rows_table_floats(kpad) floats, rewritten by every call

@@ -468,3 +468,30 @@ def test_outliers_in_tiny_groups_keep_a_finite_leave_one_out_score(gpu_ctx, nich
     st.sweep_assign(view, zt, seed=seed, sweep=sweep_idx)
     want, scores = orc.sweep([(F, ss64, f["values"])], K, alpha, z, seed, sweep_idx, "f64", want_scores=True)
     _check_agreement(zt.cpu().numpy(), want, scores, seed, sweep_idx, 0.995)
+
+
+def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
+    """40k rows take the kernel whose waves split the lookup and the nich phase (k_sweep_tile_roles), a third of them
+    the ones that run the phases in turn: the same scores bit for bit, hence the same draws (what lets a shard of any
+    size reproduce the unsharded sweep)"""
+    import common_amd
+    rng = np.random.default_rng(77)
+    N, K = 40_000, 120
+    specs = [(orc.BB, 0), (orc.NICH, 0), (orc.GP, 0), (orc.DD, 6), (orc.NICH, 0), (orc.BB, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K - 5, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(1.1)
+    whole = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, whole, seed=12, sweep=4)
+    parts = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=12, sweep=4, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
+    assert (whole.cpu().numpy() != z).mean() > 0.05
