@@ -396,7 +396,7 @@ def extra_c3(a, torch, common_amd, ctx):
     alg = float(N) * rowbytes + 4.0 * N * K
     insts, src = pmc_entry("k_score_tile", "SQ_INSTS_VALU")
     r = {"workload": "C3 mixed bb+gp+dd32+nich x16, N=1M, K=256, D=64, scoring pass", "ms": avg, "ms_min": mn,
-         "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": "k_score_tile",
+         "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": "k_score_tile_roles",
          "roofline": {"bound": "hbm", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
                       "note": "not what binds it (SURVEY 8d): vector issue rate, see valu_issue"}}

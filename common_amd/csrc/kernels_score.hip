@@ -584,7 +584,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
           acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
           acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
           acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-          if (r & 1) __builtin_amdgcn_sched_barrier(0);     // two rows' temporaries at a time: 64 registers are the sums
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time: 64 registers are the sums
         }
       }
       __syncthreads();                                    // every lookup wave is done with the slot
