@@ -292,3 +292,35 @@ def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K):
     got = st.score_value(view).cpu().numpy()
     rows = rng.choice(N, 300, replace=False)
     assert rel_err(got[rows], oracle_scores(feats, fs, rows=rows)).max() <= TOL
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_wave_role_kernels_on_random_feature_lists(gpu_ctx, seed):
+    """random lists of lookup + nich features, group counts over one to four 256-group tiles, row counts just past the
+    point where the role-split kernels take over and not a multiple of anything: sampled rows against the oracle,
+    slices against the whole (bit for bit), leave-one-out + prior included"""
+    import common_amd
+    rng = np.random.default_rng(500 + seed)
+    K = int(rng.choice([70, 256, 257, 600, 1000]))
+    ktiles = (K + 255) // 256
+    N = 128 * 256 // ktiles + int(rng.integers(1, 3000))
+    fams = [(orc.BB, 0), (orc.GP, 0), (orc.DD, int(rng.integers(2, 40))), (orc.NICH, 0)]
+    specs = [fams[i] for i in rng.integers(0, 4, int(rng.integers(3, 12)))] + [(orc.NICH, 0), (orc.BB, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(0.7)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    rows = rng.choice(N, 200, replace=False)
+    plain = st.score_value(view)
+    assert rel_err(plain.cpu().numpy()[rows], oracle_scores(feats, fs, rows=rows)).max() <= TOL
+    loo = st.score_value(view, z=zt)
+    assert rel_err(loo.cpu().numpy()[rows], oracle_scores(feats, fs, z=z, rows=rows)).max() <= TOL
+    for row0, n in ((0, 129), (N - 77, 77), (N // 2 + 3, 500)):
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True),
+                           st.score_value(view, z=zt, crp_prior=True)[row0:row0 + n])
