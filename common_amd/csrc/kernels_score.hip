@@ -530,8 +530,8 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
 // SUM of the two (C3: ~60 k + ~95 k cycles of 193 k).  Here the workgroup's sixteen waves split the phases between
 // them: waves 0-7 take the lookups of all 128 rows (16 rows each), waves 8-15 the nich features of the same rows --
 // their constants straight from the tables in L2, no LDS, so nothing ties them to the staging of the lookup groups
-// except the workgroup barriers, which they meet a feature apart -- and at the end of a chunk wave 8 + p hands its
-// sums to wave p through the (then idle) table slot.  (prior + lookups) + (nich features): the sum score_tile<SPLIT>
+// (the lookup waves synchronise among themselves: WaveSubsetBarrier) -- and at the end of a chunk wave 8 + p hands its
+// sums to wave p through the (then idle) table slot, the one place where the whole workgroup meets.  (prior + lookups) + (nich features): the sum score_tile<SPLIT>
 // forms, so a row gets the same bits from either kernel.
 // ---------------------------------------------------------------------------
 constexpr int kRoleRows = 16;          // rows per wave pair
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
     float4 acc[R];
     if (!looker) {
-      // ---- the nich waves: constants from L2, one batch of features between consecutive barriers ----
+      // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over ----
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
