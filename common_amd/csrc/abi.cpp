@@ -1159,7 +1159,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   hipStream_t s = st->ctx->stream;
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
   }
   uint32_t n_niw = 0;
@@ -1475,7 +1475,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   } else if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
-      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
     uint32_t narrow_rows = 0;

@@ -84,7 +84,7 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32
       nich_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k], o);
 #pragma unroll
       for (int i = 0; i < NICH_ROWS; i++) fd.tab[(size_t)i * kpad + k] = o[i];
-      if (fd.loo64 != nullptr) nich_loo_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.loo64 + k, kpad);
+      if (fd.loo64 != nullptr) nich_loo_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.loo64 + (size_t)k * kNlooStride, 1);
     } break;
     default: break;
   }
@@ -270,8 +270,43 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
     s = __builtin_isinf(lm1) ? (double)crp[2 * (size_t)kpad + 1] + (double)crp[2 * (size_t)kpad + 3]
                              : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + g];
   }
-  for (int f = 0; f < nfeat; f++) {
-    const FeatDesc fd = feats[f];
+  // The kernel walks the tile plan's copy of the descriptors (abi.cpp plan_groups): runs of unmasked lookup features
+  // first.  For those a feature is value -> table entry, two dependent loads and nothing else, and with one row per
+  // thread nobody hides them: four features at a time, without a branch between the loads (the value fetch and the
+  // clamp of the tile kernels' lookup runs), so that four loads are in flight where one was.  Everything else --
+  // masked columns, counts beyond the tables, nich, dm -- goes through the switch below, feature by feature.
+  auto run_word = [&](const FeatDesc &d) -> uint32_t {
+    typedef const __attribute__((address_space(1))) unsigned char *g_u8;
+    const bool u8 = d.kind == MSC_KIND_LOOKUP_U8;
+    const uint64_t at = (reinterpret_cast<uint64_t>(d.col) + (u8 ? row : row * 4)) & ~(uint64_t)3;
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((g_u8)at);
+  };
+  auto run_entry = [&](const FeatDesc &d, uint32_t word) -> float {
+    const bool u8 = d.kind == MSC_KIND_LOOKUP_U8;
+    const uint32_t sh = u8 ? (uint32_t)((reinterpret_cast<uint64_t>(d.col) + row) & 3u) * 8u : 0u;
+    const int v = (int)(u8 ? (word >> sh) & 0xffu : word);
+    const uint32_t idx = (uint32_t)(v < 0 ? 0 : (v > (int)d.run_clamp ? (int)d.run_clamp : v));
+    const float *src = d.family == MSC_BBNC ? d.tab : d.loo_tab;      // (bbnc: p does not move when a row leaves)
+    return src[(size_t)idx * kpad + g];
+  };
+  int f = 0;
+  while (f < nfeat) {
+    if (feats[f].kind != MSC_KIND_GENERIC) {
+      const int fe = (int)feats[f].run_end;
+      for (; f + 4 <= fe; f += 4) {
+        uint32_t w[4];
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = run_word(feats[f + j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = run_entry(feats[f + j], w[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) s += (double)e[j];
+      }
+      for (; f < fe; f++) s += (double)run_entry(feats[f], run_word(feats[f]));
+      continue;
+    }
+    const FeatDesc fd = feats[f++];
     if (fd.family != MSC_NIW && load_masked(fd, row, true)) continue;
     switch (fd.family) {
       case MSC_BB:       // lookup families: the table k_prepare made of "this value against the group minus one of it"
@@ -310,8 +345,11 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         s += (double)fd.loo_tab[(size_t)v * kpad + g];
       } break;
       case MSC_NICH:
-        s += nich_loo_tab(fd.hp, fd.loo64 + g, kpad, fd.raw_f32[g], fd.raw_f32[kpad + g],
-                          reinterpret_cast<const float *>(fd.col)[row]);
+        // (downdate and posterior in double, the two logarithms and the division in float like every other entry of
+        // the row: family_math.hpp nich_loo_tab_sweep -- the all-double form was ~225 double instructions per feature,
+        // 0.18 of this kernel's 0.32 ms on C3)
+        s += (double)nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)g * kNlooStride, 1, fd.raw_f32[g], fd.raw_f32[kpad + g],
+                                        reinterpret_cast<const float *>(fd.col)[row]);
         break;
       default: break;
     }

@@ -116,7 +116,7 @@ struct FeatDesc {
   const uint32_t *dm_tot;     // dm: row totals of the bound column (device, owned by the view)
   // (the group plan's fields are the struct's head; 32-bit on purpose: the kernels read them with scalar loads, a
   // 16-bit field costs a vector load and a full wait)
-  double *loo64;              // nich: per-group constants of the leave-one-out pass, [loo_rows][kpad] (family_math.hpp)
+  double *loo64;              // nich: per-group constants of the leave-one-out pass, [kpad][kNlooStride] (family_math.hpp)
   float *loo_tab;             // bb, gp, bnb, dd: score of value v against the group with one such value removed,
                               // [v][kpad] (k_prepare); the leave-one-out pass is a lookup for these families
 };
@@ -138,7 +138,10 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
     default: return 0;
   }
 }
-inline uint32_t loo_rows(int family) { return family == MSC_NICH ? 11u : 0u; }
+// (nich: kNlooStride doubles per group, group-major -- a row's leave-one-out pass reads ONE group's eleven constants: side
+// by side they are two cache lines, a table row apiece they were eleven)
+constexpr uint32_t kNlooStride = 12;
+inline uint32_t loo_rows(int family) { return family == MSC_NICH ? kNlooStride : 0u; }
 inline uint32_t loo_tab_rows(int family, uint32_t dim) {
   return family == MSC_BB ? 2u : (family == MSC_GP || family == MSC_BNB) ? kGpMaxTable : family == MSC_DD ? dim : 0u;
 }
