@@ -336,9 +336,12 @@ MSC_DEV float nich_eval_log2_est(float x, float smu_hi, float smu_lo, float c0, 
 // It runs through per-group constants (k_prepare fills them; rows of FeatDesc::loo64): what depends on
 // the group alone -- reciprocals, the lgamma difference, logs -- is computed once per group, the row
 // keeps ~15 fma, one division, one log and one log1p.
+// NLOO_STATS: the group's own float fields (mean in the low word, count_times_variance in the high one), so that a row
+// reads one block per (feature, group) and nothing else
 enum { NLOO_TOTAL = 0, NLOO_INV_N, NLOO_HAS_V2, NLOO_KMU, NLOO_N_INV_KN, NLOO_NUSIG, NLOO_INV_NUN, NLOO_NKK,
-       NLOO_C0G, NLOO_C1, NLOO_K2G, NLOO_ROWS };
-MSC_DEV void nich_loo_prepare(const float *hp, uint32_t count, float mean_f, double *out, size_t stride) {
+       NLOO_C0G, NLOO_C1, NLOO_K2G, NLOO_STATS, NLOO_ROWS };
+MSC_DEV void nich_loo_prepare(const float *hp, uint32_t count, float mean_f, float ctv_f, double *out, size_t stride) {
+  out[NLOO_STATS * stride] = __hiloint2double(__float_as_int(ctv_f), __float_as_int(mean_f));
   const double mu = hp[0], kappa = hp[1], sigmasq = hp[2], nu = hp[3];
   const double n = (double)count - 1.0, kn = kappa + n, nun = nu + n, kfac = kn / (kn + 1.0);
   out[NLOO_TOTAL * stride] = (double)mean_f * (double)count;
@@ -353,8 +356,9 @@ MSC_DEV void nich_loo_prepare(const float *hp, uint32_t count, float mean_f, dou
   out[NLOO_C1 * stride] = 0.5 * nun + 0.5;
   out[NLOO_K2G * stride] = kfac / nun;
 }
-MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, float mean_f, float ctv_f, float xf) {
-  const double x = xf, mean = mean_f, ctv = ctv_f, mu = hp[0];
+MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, float xf) {
+  const double stats = t[NLOO_STATS * stride];
+  const double x = xf, mean = __int_as_float(__double2loint(stats)), ctv = __int_as_float(__double2hiint(stats)), mu = hp[0];
   const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
   // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
   // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
@@ -368,8 +372,9 @@ MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, flo
 // The transposed sweep kernel's form: the downdate and the posterior -- where the cancellations are -- in double as above,
 // the two logarithms and the division in float (log1p_acc: hardware log2 + the compensation term), which is how every
 // other entry of the row is evaluated.  ~14 double fma + ~15 float instructions instead of ~225 double ones.
-MSC_DEV float nich_loo_tab_sweep(const float *hp, const double *t, size_t stride, float mean_f, float ctv_f, float xf) {
-  const double x = xf, mean = mean_f, ctv = ctv_f, mu = hp[0];
+MSC_DEV float nich_loo_tab_sweep(const float *hp, const double *t, size_t stride, float xf) {
+  const double stats = t[NLOO_STATS * stride];
+  const double x = xf, mean = __int_as_float(__double2loint(stats)), ctv = __int_as_float(__double2hiint(stats)), mu = hp[0];
   const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
   // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
   // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)

@@ -84,7 +84,7 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32
       nich_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k], o);
 #pragma unroll
       for (int i = 0; i < NICH_ROWS; i++) fd.tab[(size_t)i * kpad + k] = o[i];
-      if (fd.loo64 != nullptr) nich_loo_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.loo64 + (size_t)k * kNlooStride, 1);
+      if (fd.loo64 != nullptr) nich_loo_prepare(fd.hp, fd.raw_u32[k], fd.raw_f32[k], fd.raw_f32[kpad + k], fd.loo64 + (size_t)k * kNlooStride, 1);
     } break;
     default: break;
   }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
         // (downdate and posterior in double, the two logarithms and the division in float like every other entry of
         // the row: family_math.hpp nich_loo_tab_sweep -- the all-double form was ~225 double instructions per feature,
         // 0.18 of this kernel's 0.32 ms on C3)
-        s += (double)nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)g * kNlooStride, 1, fd.raw_f32[g], fd.raw_f32[kpad + g],
+        s += (double)nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)g * kNlooStride, 1,
                                         reinterpret_cast<const float *>(fd.col)[row]);
         break;
       default: break;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, G == 16 ? 3 : 1) void k_sweep_nich1(const Feat
       single = __builtin_isinf(lm1);                          // the row is its group's only member
       double s = single ? (double)le1 + (double)crp[2 * (size_t)kpad + 3] : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + gz];
       if (!((mbits >> lane) & 1ull))
-        s += nich_loo_tab(fd.hp, fd.loo64 + (size_t)gz * kNlooStride, 1, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
+        s += nich_loo_tab(fd.hp, fd.loo64 + (size_t)gz * kNlooStride, 1, xv);
       sloo = (float)s * kLog2e - bound;
     }
     // rows that leave the straight path: masked ones, and singletons while other groups are empty
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_sweep_nich1_t(const FeatDesc *__restric
       single = __builtin_isinf(lm1);                          // the row is its group's only member
       // (float: the prior's hi part and the float tail of nich_loo_tab_sweep -- what the other entries of the row get)
       float s = single ? le1 : lm1;
-      if (!my_mask) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)gz * kNlooStride, 1, fd.raw_f32[gz], fd.raw_f32[kpad + gz], xv);
+      if (!my_mask) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)gz * kNlooStride, 1, xv);
       sloo = s * kLog2e - bound;
     }
     const bool my_single = single && any_empty;               // (with no other empty group nothing moves)
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(128) void k_sweep_nich1_rows(const FeatDesc *__rest
         const float lm1 = crp[kpad + gz[i]];
         const bool only = __builtin_isinf(lm1);                // the row is its group's only member
         float s = only ? le1 : lm1;
-        if (!masked[i]) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)gz[i] * kNlooStride, 1, fd.raw_f32[gz[i]], fd.raw_f32[kpad + gz[i]], x[i]);
+        if (!masked[i]) s += nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)gz[i] * kNlooStride, 1, x[i]);
         sloo[i] = s * kLog2e - bound;
         single[i] = only && any_empty;
       }
