@@ -62,6 +62,19 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
     __syncthreads();
   }
 
+  // A workgroup's slice is at most four rows per thread in the usual launch (launch_accumulate): their groups are read
+  // once, and an unmasked scalar column's four values go out together before the first LDS atomic -- a column was
+  // four dependent (group, value) load pairs per thread behind three barriers, and the waves mostly waited
+  const bool few = hi - lo <= 4ull * blockDim.x;
+  int zr[4];
+  uint64_t rr[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint64_t n = lo + threadIdx.x + (uint64_t)j * blockDim.x;
+    rr[j] = row0 + n;
+    zr[j] = (few && n < hi) ? z[n] : -1;
+    if ((uint32_t)zr[j] >= K) zr[j] = -1;
+  }
   const int f_lo = spread ? (int)blockIdx.y - 1 : 0, f_hi = spread ? f_lo + 1 : nfeat;
   for (int f = f_lo; f < f_hi; f++) {
     const FeatDesc fd = feats[f];
@@ -80,6 +93,49 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
       for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) u64[i] = 0ull;
       for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += blockDim.x) u32[i] = 0u;
       __syncthreads();
+      const bool scalar_col = fd.family == MSC_BB || fd.family == MSC_BBNC || fd.family == MSC_GP || fd.family == MSC_BNB ||
+                              fd.family == MSC_DD || fd.family == MSC_NICH;
+      if (few && scalar_col && fd.mask == nullptr) {
+        const bool u8 = fd.family == MSC_BB || fd.family == MSC_BBNC;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                               // (a bool column: the aligned dword around the byte)
+          w[j] = 0u;
+          if (zr[j] >= 0) {
+            const uint64_t at = (reinterpret_cast<uint64_t>(fd.col) + (u8 ? rr[j] : rr[j] * 4)) & ~(uint64_t)3;
+            w[j] = *reinterpret_cast<const uint32_t *>(at);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int g = zr[j];
+          if (g < 0) continue;
+          const uint32_t raw = u8 ? (w[j] >> (((reinterpret_cast<uint64_t>(fd.col) + rr[j]) & 3u) * 8u)) & 0xffu : w[j];
+          switch (fd.family) {
+            case MSC_BBNC:
+            case MSC_BB: atomicAdd(&u32[(raw != 0 ? 0 : K) + g], 1u); break;
+            case MSC_GP:
+              atomicAdd(&u32[g], 1u);
+              atomicAdd(&u64[g], (unsigned long long)raw);
+              atomicAdd(&f64[g], log_factorial(raw));        // ln Gamma(v + 1)
+              break;
+            case MSC_BNB:
+              atomicAdd(&u32[g], 1u);
+              atomicAdd(&u64[g], (unsigned long long)raw);
+              break;
+            case MSC_DD: {
+              const int v = (int)raw;
+              if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + g], 1u);
+            } break;
+            default: {                                             // nich
+              const double x = __uint_as_float(raw);
+              atomicAdd(&u32[g], 1u);
+              atomicAdd(&f64[g], x);
+              atomicAdd(&f64[K + g], x * x);
+            } break;
+          }
+        }
+      } else
       for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
         const int g = z[n];
         if (g < 0 || (uint32_t)g >= K) continue;
