@@ -118,8 +118,35 @@ def c2_data(torch, dev, N, K, seed):
     return x, z
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  N child ranks under torch.distributed.run
+    (fresh processes; this one has made no HIP call -- torch.cuda.device_count() does not initialise the GPU on this
+    image -- and only waits for them), rank 0's JSON line goes straight to our stdout, the exit code is the child's."""
+    import torch
+    backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < a.gpus:
+        print("bench.py: --gpus %d but %d GPU(s) visible; one rank per GPU over RCCL needs %d (MSC_BENCH_BACKEND=gloo "
+              "puts every rank on cuda:0 as a rehearsal and says so in the line)" % (a.gpus, ndev, a.gpus), file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MSC_BENCH_SPAWNED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
     import common_amd
@@ -140,6 +167,12 @@ def main():
         a.steps = 100 if (world > 1 or force_c5) else 500
     if a.warmup is None:
         a.warmup = 20 if (world > 1 or force_c5) else 200
+    if a.gpus != world and not force_c5:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d: launch %d ranks, or run `python bench.py --gpus %d` and let it "
+                  "launch them" % (a.gpus, world, a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
+    one_rank = None
     if world > 1 or force_c5:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knob for a 1-GPU box: MSC_BENCH_BACKEND=gloo puts every rank on cuda:0
@@ -147,13 +180,17 @@ def main():
         if backend != "nccl":
             local = 0
         torch.cuda.set_device(local)
+    ctx = common_amd.Context(device=local)
+    if world > 1 or force_c5:
+        # the one-rank reference of the weak-scaling ratio, in this very job: rank 0 runs its shard's sweep step alone,
+        # before the process group forms (the other ranks wait in the rendezvous, their GPUs idle)
+        if rank == 0:
+            one_rank = extra_c5(a, torch, common_amd, ctx)
+            torch.cuda.empty_cache()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    if a.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
-    ctx = common_amd.Context(device=local)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -162,7 +199,7 @@ def main():
             torch.cuda.synchronize()
 
     if world > 1 or force_c5:
-        line = run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all)
+        line = run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_rank)
     else:
         line = run_c2(a, torch, dist, common_amd, ctx, sync_all)
     if rank == 0:
@@ -220,7 +257,21 @@ def sweep_roofline(nrows, K, kern_ms, kernel):
     return r
 
 
-def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
+def rccl_version(torch, backend):
+    """the collective library the all-reduce ran on, as the process group itself reports it"""
+    if backend != "nccl":
+        return None
+    try:
+        import torch.distributed as dist
+        pg = dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda"))
+        return {"runtime": str(pg.get_runtime_nccl_version()), "build": str(pg.get_build_nccl_version()),
+                "hip": torch.version.hip, "note": 'torch.distributed backend "nccl" on ROCm is RCCL'}
+    except Exception:
+        v = torch.cuda.nccl.version()
+        return {"runtime": ".".join(str(i) for i in v), "hip": torch.version.hip}
+
+
+def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_rank=None):
     nrows = a.c5_rows
     x, z, view, st, drv = c5_setup(a, torch, common_amd, ctx, world, rank, nrows)
     idx = [0]
@@ -237,10 +288,18 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
     for _ in range(a.steps):
         one()
     sync_all()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=ctx.torch_device, dtype=torch.float64)
+    dt_own = time.perf_counter() - t0
+    # max over ranks = the job's time; min beside it (the spread between ranks), and a count of the ranks that took part:
+    # every rank adds 1 over the same process group the sweeps' all-reduce used
+    t = torch.tensor([dt_own, -dt_own], device=ctx.torch_device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, dt_min = float(t[0].item()), -float(t[1].item())
+    seen = torch.ones(1, device=ctx.torch_device, dtype=torch.int64)
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ranks_seen = int(seen.item())
+    devices = [None] * world
+    dist.all_gather_object(devices, "%s cuda:%d %s" % (os.uname().nodename, ctx.device,
+                                                        torch.cuda.get_device_properties(ctx.device).name))
     kern_ms, kern_min = sweep_kernel_ms(torch, st, view, z)
     # every rank holds the same tables after the exchange: group sizes sum to the global row count
     total = int(st.get_group_counts().astype("int64").sum())
@@ -248,9 +307,19 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
     if rank != 0:
         return None
     ms = dt / a.steps * 1e3
+    value = float(nrows) * world / (dt / a.steps)
+    ref = None
+    if one_rank is not None:
+        ref = {"value": one_rank["value"], "unit": "rows/s", "ms_per_sweep": one_rank["ms_per_sweep"],
+               "how": "rank 0 alone, its own %d-row shard, msc_sweep_step (no exchange), before the process group formed" % nrows}
     return {
-        "metric": "Gibbs-sweep rows/sec", "value": float(nrows) * world / (dt / a.steps), "unit": "rows/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "metric": "Gibbs-sweep rows/sec", "value": value, "unit": "rows/s",
+        "n_gpus": world, "ranks_seen": ranks_seen, "rccl_version": rccl_version(torch, backend),
+        "rank_devices": devices,
+        "ms_per_step_ranks": {"max": ms, "min": dt_min / a.steps * 1e3},
+        "one_rank_reference": ref,
+        "weak_scaling_eff": (value / (world * ref["value"])) if ref else None,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C5 NICH N=%d rows (%d per GPU) x K=%d groups, row-sharded synchronous Gibbs sweep: fused "
                                "leave-one-out score + CRP prior + sample, accumulate, ONE sum all-reduce of the additive "
@@ -260,9 +329,9 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all):
                    "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
                    "backend": backend, "clock_prewarm_steps": prewarm},
         "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
-        "one_rank_reference": "the N = 1 line reports this workload at one rank as c5_shard.value (rows/s): weak-scaling "
-                              "ratio at N ranks = value / (N * c5_shard.value); the N = 1 line's own `value` is the C2 "
-                              "scoring pass (evals/s), the metric BASELINE.json quotes for one GPU",
+        "note": "weak_scaling_eff = value / (n_gpus * one_rank_reference.value); the N = 1 line reports the same one-rank "
+                "workload as c5_shard, its own `value` is the C2 scoring pass (evals/s), the metric BASELINE.json quotes "
+                "for one GPU",
         "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t"),
     }
 

@@ -96,7 +96,7 @@ int main(int argc, char **argv) {
     int32_t *z = nullptr;
     float *out = nullptr;
     hipMalloc(reinterpret_cast<void **>(&z), 4);
-    hipMemset(z, 0, 4);
+    hipMemset(z, 0xff, 4);                                   // (row 0 starts unassigned: -1)
     hipMalloc(reinterpret_cast<void **>(&out), 4);
     const size_t niters = 2000;
     // the iteration as downstream code would write it against the batched entry points: the row joins the group, leaves

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <new>
 
 #include "launchers.hpp"
@@ -63,6 +64,44 @@ extern "C" const char *msc_build_info(void) {
   return "microscopes_hip abi " "1" " gfx950 (CDNA4) hipcc " __VERSION__;
 }
 
+// ---- device-side errors (device_error.hpp) ----------------------------------------------------------------------------
+// One pinned pair of words per device, bound into every kernel translation unit the first time a context is created on
+// the device; it lives as long as the library.
+static int device_error_word(int device, volatile uint32_t **host_out) {
+  static std::mutex mu;
+  static uint32_t *words[64] = {};
+  MSC_REQUIRE(device >= 0 && device < 64, "device %d: at most 64 devices", device);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!words[device]) {
+    uint32_t *h = nullptr;
+    void *d = nullptr;
+    MSC_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), 64, hipHostMallocMapped));
+    h[0] = h[1] = 0;
+    MSC_HIP(hipHostGetDevicePointer(&d, h, 0));
+    uint32_t *w = static_cast<uint32_t *>(d);
+    if (bind_error_word_score(w) || bind_error_word_sweep(w) || bind_error_word_state(w))
+      return fail(MSC_EHIP, "binding the device error word failed: %s", hipGetErrorString(hipGetLastError()));
+    words[device] = h;
+  }
+  *host_out = words[device];
+  return MSC_OK;
+}
+// what the launching and synchronising entry points call first / last: an error a kernel of an earlier call reported
+static int device_error_check(msc_context *ctx) {
+  volatile uint32_t *w = ctx ? ctx->err_host : nullptr;
+  if (!w || w[0] == 0) return MSC_OK;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const uint32_t code = w[0], detail = w[1];
+  w[0] = 0;
+  const char *what = (code & 1u) ? "a wave-subset barrier of a tile kernel timed out (workgroup %u): rows of that launch are wrong"
+                     : (code & 2u) ? "msc_entity_op: leave from a group the row is not in / an empty group, or join of an assigned row (group %u)"
+                     : (code & 4u) ? "msc_relation_slice_scores: a block offset beyond the score row (cell %u)"
+                                   : "unknown device-side error (detail %u)";
+  char buf[256];
+  std::snprintf(buf, sizeof buf, what, detail);
+  return fail(MSC_EDEVICE, "reported by an earlier kernel on device %d: %s; rebuild the affected state's tables", ctx->device, buf);
+}
+
 extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
   MSC_REQUIRE(out != nullptr, "msc_context_create: out is null");
   *out = nullptr;
@@ -95,6 +134,7 @@ extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
     (void)hipGetLastError();
     ctx->sync_word_host = nullptr;
   }
+  MSC_TRY(device_error_word(device, &ctx->err_host));
   *out = ctx.release();
   return MSC_OK;
 }
@@ -131,7 +171,7 @@ extern "C" int msc_context_synchronize(msc_context *ctx) {
       for (int spin = 0; spin < 400000; spin++)
         if (*w == seq) {
           std::atomic_thread_fence(std::memory_order_acquire);
-          return MSC_OK;
+          return device_error_check(ctx);
         }
     } else {
       (void)hipGetLastError();
@@ -139,7 +179,7 @@ extern "C" int msc_context_synchronize(msc_context *ctx) {
     }
   }
   MSC_HIP(hipStreamSynchronize(ctx->stream));
-  return MSC_OK;
+  return device_error_check(ctx);
 }
 
 // plain device buffers for callers that hold no HIP headers of their own (the assignment vector, score rows)
@@ -332,7 +372,7 @@ extern "C" int msc_device_download(msc_context *ctx, void *dst_host, const void 
   MSC_HIP(hipSetDevice(ctx->device));
   MSC_HIP(hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
   MSC_HIP(hipStreamSynchronize(ctx->stream));
-  return MSC_OK;
+  return device_error_check(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -917,6 +957,53 @@ extern "C" int msc_state_get_group_counts(msc_state *st, uint32_t *host_counts, 
 // ---------------------------------------------------------------------------
 // dm: one exact count table per category and one for the row totals, each covering 0..max of what the
 // bound column holds (capped at kGpMaxTable); the maxima are found once per view column.
+// The column as the model's value type.  The reference converts per value, whatever primitive type the column holds
+// (runtime_cast::cast, runtime_type.hpp:145-166 -- its own niw descriptor pairs a float64 numpy dtype with a TYPE_F32[dim]
+// model, microscopes/models.pyx:259); here the conversion happens once, when a state first binds the column to a model
+// of another value type: a device copy through k_unpack's cast (the column read as one-feature records), kept with
+// the view.  make = false: only look the copy up (null when there is none yet).
+static int column_as(const msc_dataview *view, uint32_t c, int want, bool make, const void **out) {
+  *out = nullptr;
+  const msc_runtime_type t = view->types[c];
+  if (t.type == want) {
+    *out = view->cols[c];
+    return MSC_OK;
+  }
+  if (view->converted.size() < view->cols.size()) view->converted.resize(view->cols.size());
+  for (const auto &e : view->converted[c])
+    if (e.first == want) {
+      *out = e.second;
+      return MSC_OK;
+    }
+  if (!make) return MSC_OK;
+  hipStream_t s = view->ctx->stream;
+  void *dst = nullptr;
+  MSC_HIP(hipMalloc(&dst, std::max<size_t>(1, (size_t)view->nrows * t.count * primitive_size(want))));
+  view->owned_lazy.push_back(dst);
+  if (view->nrows > 0) {
+    UnpackFeat uf{};
+    uf.dst = dst;
+    uf.dst_mask = nullptr;                              // (the mask column is per element, whatever the value type)
+    uf.offset = 0;
+    uf.mask_offset = 0;
+    uf.src_type = t.type;
+    uf.dst_type = want;
+    uf.count = t.count;
+    void *uf_dev = nullptr;
+    MSC_HIP(hipMalloc(&uf_dev, sizeof uf));
+    hipError_t e = hipMemcpyAsync(uf_dev, &uf, sizeof uf, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && launch_unpack(s, static_cast<const uint8_t *>(view->cols[c]), nullptr, view->nrows,
+                                         (uint32_t)(primitive_size(t.type) * t.count), 0, uf_dev, 1))
+      e = hipErrorLaunchFailure;
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(uf_dev);
+    if (e != hipSuccess) return fail(MSC_EHIP, "column conversion failed: %s", hipGetErrorString(e));
+  }
+  view->converted[c].emplace_back(want, dst);
+  *out = dst;
+  return MSC_OK;
+}
+
 static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, uint32_t c) {
   msc_feature_host &h = st->feats[f];
   FeatDesc &d = st->desc_host[f];
@@ -932,7 +1019,7 @@ static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, u
       view->owned_lazy.push_back(tot);
       view->dm_tot[c] = static_cast<uint32_t *>(tot);
       MSC_HIP(hipMemsetAsync(tmp, 0, sizeof(uint32_t) * nst, s));
-      if (launch_dm_stats(s, static_cast<const uint32_t *>(view->cols[c]), view->nrows, h.dim,
+      if (launch_dm_stats(s, static_cast<const uint32_t *>(d.col), view->nrows, h.dim,
                           static_cast<uint32_t *>(tmp), view->dm_tot[c]))
         return fail(MSC_EHIP, "k_dm_stats launch failed");
       MSC_HIP(hipMemcpyAsync(mx.data(), tmp, sizeof(uint32_t) * nst, hipMemcpyDeviceToHost, s));
@@ -983,8 +1070,12 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
   bool same = st->bound_view == view && st->bound_serial == view->serial && st->bound_cols.size() == st->nfeat;
   for (uint32_t f = 0; f < st->nfeat && same; f++) same = st->bound_cols[f] == (cols ? cols[f] : f);
   if (same) {
-    for (uint32_t f = 0; f < st->nfeat && same; f++)
-      same = st->desc_host[f].col == view->cols[st->bound_cols[f]];
+    for (uint32_t f = 0; f < st->nfeat && same; f++) {
+      const void *eff = nullptr;
+      if (st->feats[f].family == MSC_NOOP) eff = view->cols[st->bound_cols[f]];
+      else MSC_TRY(column_as(view, st->bound_cols[f], value_type_of(st->feats[f].family), false, &eff));
+      same = st->desc_host[f].col == eff;
+    }
   }
   if (same) return MSC_OK;
   st->bound_cols.resize(st->nfeat);
@@ -996,22 +1087,24 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
     const msc_runtime_type t = view->types[c];
     if (h.family != MSC_NOOP) {
       const uint32_t want_n = h.family == MSC_NIW || h.family == MSC_DM ? h.dim : 1;
-      // model::get_runtime_type() must match the column (distributions.hpp:398-403, _dataview.pyx:27-44)
-      MSC_REQUIRE(t.type == value_type_of(h.family) && t.count == want_n,
-                  "feature %u: column %u has type (%d x %u) but the model wants (%d x %u); convert at upload",
-                  f, c, t.type, t.count, value_type_of(h.family), want_n);
+      // model::get_runtime_type() fixes the element count (distributions.hpp:398-403, _dataview.pyx:27-44); the element
+      // type is converted per value upstream (runtime_cast::cast) and once per column here (column_as)
+      MSC_REQUIRE(t.count == want_n, "feature %u: column %u holds %u elements per value but the model wants %u", f, c,
+                  t.count, want_n);
     }
     st->bound_cols[f] = c;
-    st->desc_host[f].col = view->cols[c];
+    const void *eff = view->cols[c];
+    if (h.family != MSC_NOOP) MSC_TRY(column_as(view, c, value_type_of(h.family), true, &eff));
+    st->desc_host[f].col = eff;
     st->desc_host[f].mask = static_cast<const uint8_t *>(view->masks[c]);
-    st->desc_host[f].col_type = t.type;
+    st->desc_host[f].col_type = h.family != MSC_NOOP ? value_type_of(h.family) : t.type;
     if (is_count_family(h.family)) {
       // the exact table covers counts 0..max of the bound column (capped): find the max once
       if (view->col_max[c] < 0) {
         uint32_t mx = 0;
         if (view->nrows > 0) {
           MSC_HIP(hipMemsetAsync(st->colmax_dev, 0, 4, st->ctx->stream));
-          if (launch_col_max_u32(st->ctx->stream, static_cast<const uint32_t *>(view->cols[c]), view->nrows, st->colmax_dev))
+          if (launch_col_max_u32(st->ctx->stream, static_cast<const uint32_t *>(eff), view->nrows, st->colmax_dev))
             return fail(MSC_EHIP, "k_col_max_u32 launch failed");
           MSC_HIP(hipMemcpyAsync(&mx, st->colmax_dev, 4, hipMemcpyDeviceToHost, st->ctx->stream));
           MSC_HIP(hipStreamSynchronize(st->ctx->stream));
@@ -1159,7 +1252,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   hipStream_t s = st->ctx->stream;
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
   }
   uint32_t n_niw = 0;
@@ -1218,6 +1311,7 @@ extern "C" int msc_score_value(msc_state *st, const msc_dataview *view, const ui
   MSC_REQUIRE(ld_out >= st->K, "ld_out %llu < ngroups %u", (unsigned long long)ld_out, st->K);
   MSC_REQUIRE((flags & ~(MSC_SCORE_CRP_PRIOR | MSC_SCORE_NIW_F32)) == 0, "unknown flags 0x%x", flags);
   MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(device_error_check(st->ctx));
   MSC_TRY(bind_view(st, view, cols, row0, nrows));
   if (nrows == 0) return MSC_OK;
   MSC_TRY(ensure_derived(st));
@@ -1369,6 +1463,7 @@ extern "C" int msc_accumulate(msc_state *st, const msc_dataview *view, const uin
   MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
   MSC_REQUIRE((flags & ~(MSC_ACC_RESET | MSC_ACC_SUBTRACT | MSC_ACC_NO_COMMIT)) == 0, "unknown flags 0x%x", flags);
   MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(device_error_check(st->ctx));
   return accumulate_impl(st, view, cols, row0, nrows, z_dev, flags);
 }
 
@@ -1377,6 +1472,9 @@ extern "C" int msc_entity_op(msc_state *st, const msc_dataview *view, const uint
   MSC_REQUIRE(st && view, "null argument");
   MSC_REQUIRE(sign != 0, "sign must be +1 (join) or -1 (leave)");
   MSC_REQUIRE(group < st->K, "group %u outside [0,%u)", group, st->K);
+  MSC_REQUIRE(!st->rng_bump_pending, "msc_entity_op between msc_sweep_step_begin and msc_state_commit_reduce: the additive "
+                                     "tables hold uncommitted sums");
+  MSC_TRY(device_error_check(st->ctx));
   MSC_HIP(hipSetDevice(st->ctx->device));
   MSC_TRY(bind_view(st, view, cols, row, 1));
   hipStream_t s = st->ctx->stream;
@@ -1475,7 +1573,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   } else if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
-      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
     uint32_t narrow_rows = 0;
@@ -1531,6 +1629,7 @@ extern "C" int msc_sweep_assign(msc_state *st, const msc_dataview *view, const u
                                 uint64_t seed, uint64_t sweep) {
   MSC_REQUIRE(st && (z_dev || nrows == 0), "null argument");
   MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(device_error_check(st->ctx));
   return sweep_assign_impl(st, view, cols, row0, nrows, row_id0, z_dev, seed, sweep);
 }
 
@@ -1566,6 +1665,7 @@ extern "C" int msc_sweep_step(msc_state *st, const msc_dataview *view, const uin
                               uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep) {
   MSC_REQUIRE(st && view && (z_dev || nrows == 0), "null argument");
   MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(device_error_check(st->ctx));
   hipStream_t s = st->ctx->stream;
   auto eager = [&]() -> int {
     st->step_graph.n_eager++;
@@ -1656,6 +1756,7 @@ extern "C" int msc_sweep_step_begin(msc_state *st, const msc_dataview *view, con
                                     uint64_t nrows, uint64_t row_id0, int32_t *z_dev, uint64_t seed, uint64_t sweep) {
   MSC_REQUIRE(st && view && (z_dev || nrows == 0), "null argument");
   MSC_HIP(hipSetDevice(st->ctx->device));
+  MSC_TRY(device_error_check(st->ctx));
   if (nrows == 0) return accumulate_impl(st, view, cols, row0, 0, z_dev, MSC_ACC_RESET | MSC_ACC_NO_COMMIT);
   bool zeroed = false;
   MSC_TRY(sweep_assign_impl(st, view, cols, row0, nrows, row_id0, z_dev, seed, sweep, &zeroed));
@@ -1734,6 +1835,7 @@ extern "C" int msc_relation_slice_scores(msc_context *ctx, const float *scores_d
               (unsigned long long)shape[dim]);
   MSC_REQUIRE(nent < (1ull << 31), "too many entities for one launch");
   MSC_HIP(hipSetDevice(ctx->device));
+  MSC_TRY(device_error_check(ctx));
   if (launch_relation_slice_scores(ctx->stream, scores_dev, ld, ndim, shape, dim, seg_dev, ids_dev, off_dev, ncand, cand_stride,
                                    nent, out_dev, ld_out))
     return fail(MSC_EHIP, "k_relation_slice_scores launch failed");

@@ -195,11 +195,23 @@ __global__ __launch_bounds__(256) void k_entity_op(const FeatDesc *__restrict__ 
                                                     uint32_t *__restrict__ cnt_u32, float alpha, float *__restrict__ crp,
                                                     int32_t *__restrict__ z_slot) {
   const long long sgn = sign;
+  // What the host-side group manager of hip::mixture_state guarantees, a direct caller of msc_entity_op may not: a leave
+  // needs a group with something in it (else the u32 count wraps to 4e9 and its logarithm lands in the CRP table) and,
+  // when the assignment vector is at hand, a row that is in that group; a join needs an unassigned row.  The blocks run
+  // side by side, so each refuses on what it can see without reading what another block writes -- this one the group
+  // size and the row's slot, a feature block its own count of the group -- and reports (MSC_DEVERR_ENTITY_OP: the call
+  // that notices returns MSC_EDEVICE and the state's tables are to be rebuilt).
   if ((int)blockIdx.x == nfeat) {
     if (threadIdx.x == 0) {
-      cnt_acc[g] += sgn;
-      cnt_u32[g] = (uint32_t)cnt_acc[g];
-      if (z_slot != nullptr) *z_slot = sign > 0 ? (int32_t)g : -1;
+      const int32_t zs = z_slot != nullptr ? *z_slot : (sign > 0 ? -1 : (int32_t)g);
+      const bool ok = sign > 0 ? (zs < 0 || (uint32_t)zs >= K) : (cnt_acc[g] > 0 && zs == (int32_t)g);
+      if (ok) {
+        cnt_acc[g] += sgn;
+        cnt_u32[g] = (uint32_t)cnt_acc[g];
+        if (z_slot != nullptr) *z_slot = sign > 0 ? (int32_t)g : -1;
+      } else {
+        report_device_error(MSC_DEVERR_ENTITY_OP, g);
+      }
     }
     __syncthreads();
     crp_prepare_block(cnt_u32, K, kpad, alpha, crp);
@@ -207,7 +219,22 @@ __global__ __launch_bounds__(256) void k_entity_op(const FeatDesc *__restrict__ 
   }
   const FeatDesc fd = feats[blockIdx.x];
   if (threadIdx.x == 0 && fd.col != nullptr && !load_masked(fd, row, true)) {
-    switch (fd.family) {
+    // (a leave takes one unit out of a counter of this feature: refuse when that counter is empty)
+    bool has = true;
+    if (sign < 0) switch (fd.family) {
+      case MSC_BBNC:
+      case MSC_BB: has = fd.acc_i64[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 0 : kpad) + g] > 0; break;
+      case MSC_GP:
+      case MSC_BNB:
+      case MSC_NICH: has = fd.acc_i64[g] > 0; break;
+      case MSC_DD: {
+        const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+        has = !(v >= 0 && v < (int)fd.dim) || fd.acc_i64[(size_t)v * kpad + g] > 0;
+      } break;
+      default: break;
+    }
+    if (!has) report_device_error(MSC_DEVERR_ENTITY_OP, g);
+    else switch (fd.family) {
       case MSC_BBNC:
       case MSC_BB:
         fd.acc_i64[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? 0 : kpad) + g] += sgn;
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(256) void k_entity_op(const FeatDesc *__restrict__ 
 // HEAVY = false leaves out the branches with lgamma chains in them (gp / bnb counts beyond the table, dm): with them
 // inlined the kernel sits at 225 VGPRs, 2 waves per SIMD, for rows that never take them (launch_loo_own picks)
 template <bool HEAVY>
-__global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ feats, int nfeat,
+__global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K,
                                                   uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                   const int32_t *__restrict__ z,
                                                   const float *__restrict__ crp, float *__restrict__ own) {
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   const uint64_t n = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nrows) return;
   const int g = z[n];
-  if (g < 0 || (uint32_t)g >= kpad) {                       // (an id outside the tables reads as not assigned)
+  if (g < 0 || (uint32_t)g >= K) {                          // (an id outside [0, ngroups) reads as not assigned)
     own[n] = 0.f;
     return;
   }
@@ -732,6 +759,8 @@ __global__ __launch_bounds__(256) void k_gp_large_fix(const FeatDesc *__restrict
 // ---------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp)
 // ---------------------------------------------------------------------------
+MSC_DEFINE_BIND_ERROR_WORD(bind_error_word_score)
+
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad, uint32_t value_slices) {
   dim3 grid((kpad + 255) / 256, nfeat, value_slices ? value_slices : 1);
   hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, stream, feats_dev, kpad);
@@ -764,15 +793,15 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
+int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own) {
   (void)num_cus;
   if (heavy)
     hipLaunchKernelGGL(k_loo_own<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
-                       kpad, row0, nrows, z, crp, own);
+                       K, kpad, row0, nrows, z, crp, own);
   else
     hipLaunchKernelGGL(k_loo_own<false>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
-                       kpad, row0, nrows, z, crp, own);
+                       K, kpad, row0, nrows, z, crp, own);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -5,6 +5,7 @@
 //   k_score_data   marginal likelihood of every (feature, group)
 //   k_unpack       packed row-major records -> one typed column per feature
 #include "commit_ops.hpp"
+#include "device_error.hpp"
 #include "family_math.hpp"
 #include "launchers.hpp"
 
@@ -519,7 +520,11 @@ __global__ __launch_bounds__(256) void k_relation_slice_scores(const float *__re
       else c = ((m / a.inner) * a.extent + e) * a.inner + m % a.inner;
       const int o = off[c];                                  // (wave-uniform)
       if (o < 0) continue;
-      if (g < ncand) acc += (double)scores[c * ld + (uint64_t)g * cand_stride + (uint32_t)o];
+      // off is the caller's data (msc_relation_blocks with possibly other cluster counts): a block index past the
+      // score row is skipped and reported, never read
+      const uint64_t col = (uint64_t)g * cand_stride + (uint32_t)o;
+      if (g < ncand && col < ld) acc += (double)scores[c * ld + col];
+      else if (g < ncand) report_device_error(MSC_DEVERR_RELATION_RANGE, (uint32_t)c);
     }
     part[wave][lane] = acc;
     __syncthreads();
@@ -531,6 +536,8 @@ __global__ __launch_bounds__(256) void k_relation_slice_scores(const float *__re
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+MSC_DEFINE_BIND_ERROR_WORD(bind_error_word_state)
+
 int launch_relation_slice_scores(hipStream_t stream, const float *scores, uint64_t ld, uint32_t ndim, const uint64_t *shape,
                                  uint32_t dim, const uint32_t *seg_dev, const uint32_t *ids_dev, const int32_t *off_dev,
                                  uint32_t ncand, uint32_t cand_stride, uint64_t nent, float *out_dev, uint64_t ld_out) {

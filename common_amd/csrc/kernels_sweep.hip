@@ -926,6 +926,8 @@ static void launch_sweep_niw1_t(hipStream_t stream, int num_cus, const FeatDesc 
 // groups per lane the registers allow at a dimension: D (D + 3) / 2 doubles per group, up to 56 in all
 int sweep_niw1_max_groups(uint32_t dim) { return dim <= 4 ? 256 : dim == 5 ? 128 : dim <= 8 ? 64 : 0; }
 // one niw feature, K <= sweep_niw1_max_groups(dim)
+MSC_DEFINE_BIND_ERROR_WORD(bind_error_word_sweep)
+
 int launch_sweep_niw1(hipStream_t stream, int num_cus, uint32_t dim, const FeatDesc *feats_dev, uint32_t K, uint32_t kpad,
                       uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *crp, const uint64_t *rng,
                       ZeroSpans zero) {

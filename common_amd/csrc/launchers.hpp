@@ -33,6 +33,12 @@ struct MailboxHeader {
 };
 int launch_value_op(hipStream_t stream, void *mailbox_dev, uint32_t dim, int family);
 
+// every kernel translation unit that can report a device-side error (device_error.hpp): point its copy of the pointer at
+// the device's pinned word; called once per device by msc_context_create
+int bind_error_word_score(uint32_t *word_dev);
+int bind_error_word_sweep(uint32_t *word_dev);
+int bind_error_word_state(uint32_t *word_dev);
+
 // kernels_score.hip
 int launch_prepare(hipStream_t stream, const FeatDesc *feats_dev, uint32_t nfeat, uint32_t kpad, uint32_t value_slices);
 int launch_dm_prepare(hipStream_t stream, const FeatDesc *feats_dev, int f, uint32_t dim, uint32_t kpad, uint32_t value_slices);
@@ -42,7 +48,7 @@ int launch_entity_op(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, u
                      uint32_t group, int sign, long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, int32_t *z_slot);
 int launch_set_i32(hipStream_t stream, int32_t *dst, int32_t value);
 int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
-int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t kpad, uint64_t row0,
+int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);

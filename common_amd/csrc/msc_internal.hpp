@@ -257,6 +257,8 @@ struct msc_context {
   void *sync_word_dev = nullptr;
   uint32_t sync_seq = 0;
   bool sync_word_ok = true;                // cleared when the stream operation is refused: plain stream waits from then on
+  // the device's error word {code, detail} (device_error.hpp), pinned and shared by every context on the device
+  volatile uint32_t *err_host = nullptr;
 };
 
 struct msc_dataview {
@@ -271,6 +273,9 @@ struct msc_dataview {
   mutable std::vector<std::vector<uint32_t>> dm_max;  // dm columns: maxima of each category and of the row totals (lazy)
   mutable std::vector<uint32_t *> dm_tot;             // dm columns: row totals (device, owned)
   mutable std::vector<void *> owned_lazy;
+  // copies of a column converted to another primitive type with runtime_cast semantics, made the first time a state
+  // binds the column to a model whose value type differs (abi.cpp column_as): per column, (type, device copy)
+  mutable std::vector<std::vector<std::pair<int, const void *>>> converted;
 };
 
 struct msc_feature_host {

@@ -17,6 +17,7 @@
 // always are.
 #pragma once
 
+#include "device_error.hpp"
 #include "family_math.hpp"
 
 namespace msc {
@@ -317,7 +318,7 @@ struct WorkgroupBarrier {
 // A barrier among the first NW waves of the workgroup, through a counter in LDS: every wave adds one and waits until
 // the count reaches NW times the number of barriers it has passed.  The waves that take part must execute the same
 // sequence of barriers (they do: the same loop over the same feature groups); the wait is bounded all the same, so
-// that a mistake costs wrong numbers and not a hung GPU.
+// that a mistake costs a reported error (MSC_DEVERR_BARRIER_TIMEOUT) and not a hung GPU.
 template <int NW>
 struct WaveSubsetBarrier {
   uint32_t *counter;                                    // in LDS, zeroed by the workgroup before first use
@@ -327,10 +328,17 @@ struct WaveSubsetBarrier {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t want = passed * (uint32_t)NW;
+    bool met = false;
     for (int spin = 0; spin < (1 << 22); spin++) {
-      if ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) >= 0) break;
+      if ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) >= 0) {
+        met = true;
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
+    // (never seen; if it happens the rows of this workgroup are wrong and the host must hear of it: the next
+    // synchronising or launching call on the context returns MSC_EDEVICE, device_error.hpp)
+    if (!met && (threadIdx.x & 63) == 0) report_device_error(MSC_DEVERR_BARRIER_TIMEOUT, blockIdx.x);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 };

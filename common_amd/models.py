@@ -30,8 +30,9 @@ class c_model(object):
 
 
 class py_model(object):
-    """dtype carrier and dict <-> protobuf-bytes converters (microscopes/models.pyx:53-94).  `dtype` is the column
-    dtype the device kernels read (the reference takes it from the absent library's `Value`)."""
+    """dtype carrier and dict <-> protobuf-bytes converters (microscopes/models.pyx:53-94).  `dtype` is the dtype a
+    caller's recarray column carries (the reference takes it from the absent library's `Value`; niw's is upstream's own
+    float64); a column of any other primitive type is accepted too and converted when a state binds it."""
 
     def __init__(self, name, dtype):
         self._name = name
@@ -146,7 +147,9 @@ def dd(size):
 def niw(dim):
     if dim <= 0:
         raise ValueError("dim must be positive")
-    return model_descriptor("niw", py_model("niw", np.dtype((np.float32, (dim,)))), c_model(L.NIW, dim),
+    # (float64, as upstream: microscopes/models.pyx:259 `np.dtype((float, (dim,)))` against a TYPE_F32[dim] model -- the
+    # column is converted when a state binds it, as runtime_cast::cast does per value upstream)
+    return model_descriptor("niw", py_model("niw", np.dtype((np.float64, (dim,)))), c_model(L.NIW, dim),
                             {"mu": np.array([0.] * dim), "kappa": 1.0, "psi": np.eye(dim),
                              "nu": float(dim)}, {}, [])
 

@@ -40,7 +40,11 @@ typedef enum msc_status {
   MSC_EHIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
   MSC_ENODEVICE = -3,    /* no gfx950 device / extension not usable */
   MSC_EUNSUPPORTED = -4, /* valid request outside what is built (e.g. dd dim > 128) */
-  MSC_ENOMEM = -5
+  MSC_ENOMEM = -5,
+  MSC_EDEVICE = -6       /* a kernel of an EARLIER call on this device reported that something it relies on did not hold
+                            (an entity leaving a group it is not in, a relation offset past the score row, a wave barrier
+                            that timed out); noticed at the synchronising and launching calls, reported once; the tables of
+                            the state that call touched are to be rebuilt (msc_accumulate with MSC_ACC_RESET) */
 } msc_status;
 
 /* likelihood families; one kernel family each (distributions.hpp:58-64) */
@@ -249,6 +253,10 @@ int msc_accumulate(msc_state *st, const msc_dataview *view, const uint32_t *cols
  * changed), so a Gibbs move -- leave, msc_score_value of the row, join -- is three launches and one copy back;
  * niw / dm features take the general accumulate path.  z_dev (nullable): the caller's device assignment vector, of
  * which entry `row` is set to the group (join) or -1 (leave).  Asynchronous.
+ * Preconditions the device checks (the reference asserts them, group_manager.hpp:218-248): a leave needs a non-empty
+ * group -- and, with z_dev, z_dev[row] == group --, a join with z_dev needs z_dev[row] unassigned.  A violation skips the
+ * update it concerns and surfaces as MSC_EDEVICE at the next synchronising or launching call.  MSC_EINVAL between
+ * msc_sweep_step_begin and msc_state_commit_reduce (the additive tables hold one rank's uncommitted sums then).
  */
 int msc_entity_op(msc_state *st, const msc_dataview *view, const uint32_t *cols, uint64_t row, uint32_t group,
                   int sign, int32_t *z_dev);

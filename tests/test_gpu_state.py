@@ -161,15 +161,48 @@ def test_masked_recarray_keeps_mask_columns(gpu_ctx):
         assert bool(view.column_to_numpy(f)[0]) == case["rows"][0][f]
 
 
-def test_wrong_column_type_is_refused(gpu_ctx):
+def test_column_of_another_type_is_converted_at_bind(gpu_ctx):
+    """runtime_cast::cast (runtime_type.hpp:145-166) converts whatever primitive type a column holds, per value; here the
+    column is converted once, when a state binds it.  The reference's own dtypes -- niw's float64 vectors
+    (microscopes/models.pyx:259), numpy-default float64 for nich, int64 counts and categories -- must score and accumulate
+    exactly like the same values cast beforehand, bit for bit; a wrong element COUNT is still refused."""
     import common_amd
-    arr = np.zeros(10, dtype=[("f0", np.float64)])
-    view = common_amd.DataView.from_recarray(gpu_ctx, arr)
-    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], 4)
+    from common_amd import models
+    rng = np.random.default_rng(5)
+    N, K, d = 3000, 7, 4
+    specs = [(orc.NICH, 0), (orc.GP, 0), (orc.DD, 6), (orc.NIW, d), (orc.BB, 0), (orc.DM, 3)]
+    feats = [make_feature(f, N, K, rng, dd_) for f, dd_ in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    native = recarray_of(feats)
+    wide_dt = np.dtype([("f0", np.float64), ("f1", np.int64), ("f2", np.int64),
+                        ("f3", models.niw(d).py_desc().get_np_dtype()), ("f4", np.uint8), ("f5", np.int64, (3,))])
+    assert wide_dt["f3"].base == np.float64 and wide_dt["f3"].shape == (d,)
+    wide = np.zeros(N, dtype=wide_dt)
+    for name in native.dtype.names:
+        wide[name] = native[name]                      # (float32 -> float64 and back is exact; counts fit)
+
+    def run(arr):
+        view = common_amd.DataView.from_recarray(gpu_ctx, arr)
+        st = common_amd.State(gpu_ctx, specs, K)
+        for i, f in enumerate(feats):
+            st.set_hp(i, orc.Family(f["family"], f["hp"], f["dim"], "f64").hp)
+        st.accumulate(view, zt)
+        return view, st, st.score_value(view).cpu().numpy(), [st.get_ss(i) for i in range(len(specs))]
+    v0, s0, sc0, ss0 = run(native)
+    v1, s1, sc1, ss1 = run(wide)
+    assert v1.column_type(0)[0] == orc.TYPE_F64 and v1.column_type(1)[0] == orc.TYPE_I64      # the view keeps the caller's types
+    assert np.array_equal(sc0, sc1)
+    for a, b in zip(ss0, ss1):
+        assert a.tobytes() == b.tobytes()
+    # device tensors take the same road (float64 columns from torch)
+    cols = [torch.from_numpy(np.ascontiguousarray(wide[n])).to(gpu_ctx.torch_device) for n in wide.dtype.names]
+    vt = common_amd.DataView.from_tensors(gpu_ctx, cols)
+    assert np.array_equal(s1.score_value(vt).cpu().numpy(), sc0)
+    # the element count is the model's: a scalar column cannot feed niw(4)
+    st = common_amd.State(gpu_ctx, [(orc.NIW, d)], K)
     with pytest.raises(common_amd.MicroscopesHipError):
-        st.score_value(view)
-    view32 = common_amd.DataView.from_recarray(gpu_ctx, arr, col_types=[orc.TYPE_F32])
-    assert st.score_value(view32).shape == (10, 4)
+        st.score_value(v0, cols=[0])
 
 
 def test_accumulate_with_more_groups_than_lds_histograms_hold(gpu_ctx):

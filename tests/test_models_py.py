@@ -24,6 +24,7 @@ def test_model_callable():                                   # test/test_models.
 def test_models_dtype():                                     # test/test_models.py:21-23
     assert niw(3).py_desc().get_np_dtype().shape == (3,)
     assert niw(5).py_desc().get_np_dtype().shape == (5,)
+    assert niw(5).py_desc().get_np_dtype().base == np.float64   # microscopes/models.pyx:259: np.dtype((float, (dim,)))
     assert dm(4).py_desc().get_np_dtype().shape == (4,)
 
 
