@@ -1,8 +1,10 @@
 """Model descriptors: the Python surface of microscopes/models.pyx:96-290.
 
 Same names (`bb`, `bnb`, `gp`, `nich`, `dd(n)`, `niw(d)`, ...), same accessor
-methods and the same default hyper-parameters; `c_desc()` returns the handle the
-HIP state consumes (family tag + dimension) instead of a `shared_ptr[model]`.
+methods and the same default hyper-parameters; `c_desc()` returns the Cython
+extension object of common_amd/cy/_models.pyx (`_bb`, `_dd(size)`, ...: a
+`shared_ptr[model]` behind `get()` / `create_hypers()`, as microscopes/_models.pyx:16-52),
+which also carries the family tag + dimension the batched HIP state consumes.
 All eight models of microscopes/models.pyx:185-290 have a HIP kernel family.
 """
 import itertools as it
@@ -14,19 +16,25 @@ from . import wire
 from .scalar_functions import log_exponential, log_noninformative_beta_prior, log_normal
 
 
+_CY_CLASS = {L.BB: "_bb", L.BNB: "_bnb", L.GP: "_gp", L.NICH: "_nich", L.DD: "_dd", L.NIW: "_niw", L.BBNC: "_bbnc",
+             L.DM: "_dm", L.NOOP: "_noop"}
+
+
 class c_model(object):
-    """What `_base.get()` hands to a state object (microscopes/_models.pyx:16-20)."""
+    """(family, dim) of a descriptor and the factory of its Cython handle: `make()` builds the extension object of
+    common_amd/cy/_models.pyx that `_base.get()` / `create_hypers()` live on (microscopes/_models.pyx:16-52)."""
 
     def __init__(self, family, dim=0):
         self.family, self.dim = int(family), int(dim)
 
-    def get_runtime_type(self):
-        """(primitive type, count): model::get_runtime_type, distributions.hpp:398-403,497-505."""
-        from .runtime import VALUE_TYPE
-        return VALUE_TYPE[self.family], (self.dim if self.family in (L.NIW, L.DM) else 1)
-
-    def __repr__(self):
-        return "c_model(family=%d, dim=%d)" % (self.family, self.dim)
+    def make(self):
+        try:
+            from .cy import _models as cy
+        except ImportError as e:
+            raise ImportError("common_amd/cy/_models is not built (python common_amd/cy/build.py, or "
+                              "__graft_entry__.build()): %s" % e)
+        cls = getattr(cy, _CY_CLASS[self.family])
+        return cls(self.dim) if self.family in (L.DD, L.NIW, L.DM) else cls()
 
 
 class py_model(object):
@@ -59,7 +67,8 @@ class model_descriptor(object):
                  default_partial_hypergrid):
         self._name = name
         self._py_descriptor = py_descriptor
-        self._c_descriptor = c_descriptor
+        self._c_spec = c_descriptor          # (family, dim); the Cython handle is made on first use
+        self._c_descriptor = None
         self._default_hyperparams = default_hyperparams
         self._default_hyperpriors = default_hyperpriors
         self._default_partial_hypergrid = default_partial_hypergrid
@@ -71,8 +80,9 @@ class model_descriptor(object):
         return self._py_descriptor
 
     def c_desc(self):
+        """the model's Cython handle (`_bb`, `_dd`, ...): what downstream cdef code calls `.get()` on"""
         if self._c_descriptor is None:
-            raise NotImplementedError("model '%s' has no HIP kernel family yet" % self._name)
+            self._c_descriptor = self._c_spec.make()
         return self._c_descriptor
 
     def default_hyperparams(self):
@@ -87,11 +97,11 @@ class model_descriptor(object):
     # convenience for State(...)
     @property
     def family(self):
-        return self.c_desc().family
+        return self._c_spec.family
 
     @property
     def dim(self):
-        return self.c_desc().dim
+        return self._c_spec.dim
 
     def _param(self):
         name = self.name()

@@ -73,6 +73,8 @@ class Context(object):
         h = C.c_void_p()
         L.check(self.lib.msc_context_create(self.device, C.c_void_p(s.cuda_stream), C.byref(h)))
         self._h = h
+        import weakref
+        self._buffers = weakref.WeakSet()      # live msc_device_alloc* buffers that tensors alias (alloc / alloc_probed)
 
     def set_stream(self, stream):
         self._stream = stream
@@ -102,6 +104,17 @@ class Context(object):
                                              C.byref(score)))
         return float(score.value)
 
+    def alloc(self, shape, dtype=torch.float32):
+        """A zero-filled device tensor from msc_device_alloc -- the library's default allocator: from 64 MiB on the buffer
+        is placed for the write stream of a score matrix (include/microscopes_hip.h).  The tensor owns the buffer."""
+        n = 1
+        for s in shape:
+            n *= int(s)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        p = C.c_void_p()
+        L.check(self.lib.msc_device_alloc(self._h, nbytes, C.byref(p)))
+        return _alias_tensor(p.value, n, dtype, self.torch_device, owner=_DeviceBuffer(self, p.value)).reshape(*shape)
+
     def alloc_probed(self, shape, dtype=torch.float32, candidates=8):
         """A zero-filled device tensor in the best-placed of `candidates` allocations (msc_device_alloc_probed; the
         write stream of a large score matrix runs 5.6 or 7.0 TB/s depending on where the driver put it).
@@ -116,7 +129,13 @@ class Context(object):
         return t, [float(r) for r in rates], int(chosen.value)
 
     def close(self):
+        """destroy the context.  Refused while tensors from alloc() / alloc_probed() are alive: destroying the context
+        unmaps their memory (the buffers hold a reference to the context, so garbage collection never gets here first)"""
         if getattr(self, "_h", None):
+            live = [b for b in getattr(self, "_buffers", ()) if b.ptr]
+            if live:
+                raise RuntimeError("Context.close(): %d device buffer(s) from alloc()/alloc_probed() are still referenced "
+                                   "by tensors; drop those first" % len(live))
             self.lib.msc_context_destroy(self._h)
             self._h = None
 
@@ -443,6 +462,7 @@ class _DeviceBuffer(object):
 
     def __init__(self, ctx, ptr):
         self.ctx, self.ptr = ctx, ptr
+        ctx._buffers.add(self)
 
     def __del__(self):
         try:
@@ -466,6 +486,19 @@ def _alias_tensor(ptr, n, dtype, device, owner=None):
     typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4",
                torch.int32: "<i4"}[dtype]
     return torch.as_tensor(_CudaArrayView(ptr, n, typestr, owner), device=device)
+
+
+def _check_slice_args(scores, dim, ngroups, nd):
+    """a slice reduction indexes score columns up to prod(ngroups): the matrix must have them all (the kernel skips and
+    reports an offset past the row, MSC_EDEVICE, but a consistent caller never gets there)"""
+    if len(ngroups) != nd or not 0 <= int(dim) < nd:
+        raise ValueError("one cluster count per dimension and a dimension inside the relation")
+    nblocks = 1
+    for k in ngroups:
+        nblocks *= int(k)
+    if scores.dim() != 2 or scores.shape[1] < nblocks:
+        raise ValueError("scores has %d columns but the cluster counts %s make %d blocks" %
+                         (scores.shape[1] if scores.dim() == 2 else -1, list(ngroups), nblocks))
 
 
 class RelationView(object):
@@ -517,6 +550,7 @@ class RelationView(object):
         cell's score against block (g, the cell's other clusters).  scores: [ncells, >= prod(ngroups)] from
         State.score_value on self.cells; off: slice_offsets(...).  -> float32 [shape[dim], ngroups[dim]]"""
         nd = len(self.shape)
+        _check_slice_args(scores, dim, ngroups, nd)
         if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1 or scores.shape[0] != self.cells.nrows:
             raise ValueError("scores must be a row-major float32 [ncells, nblocks] tensor")
         if off.dtype != torch.int32 or off.numel() != self.cells.nrows or not off.is_contiguous():
@@ -588,6 +622,7 @@ class SparseRelationView(object):
     def slice_scores(self, scores, off, dim, ngroups):
         """out[e, g] = sum over the stored cells of row / column e of the cell's score against block (g, the other
         entity's cluster) -- msc_relation_slice_scores with the CSR rows (dim 0) or the transpose's (dim 1)"""
+        _check_slice_args(scores, dim, ngroups, 2)
         if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1 or scores.shape[0] != self.nnz():
             raise ValueError("scores must be a row-major float32 [nnz, nblocks] tensor")
         if off.dtype != torch.int32 or off.numel() != self.nnz() or not off.is_contiguous():
