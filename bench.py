@@ -52,8 +52,12 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c4 / c5_shard objects at N = 1")
     ap.add_argument("--tune", action="store_true", help="msc_score_tune before the C2 pass (off: the default launch shape)")
-    ap.add_argument("--probe-alloc", type=int, default=24, help="candidates of msc_device_alloc_probed for the C2 score matrix")
-    ap.add_argument("--no-probe-alloc", action="store_true", help="plain torch allocation for the score matrix")
+    ap.add_argument("--alloc", choices=("default", "probed", "torch"), default="default",
+                    help="where the C2 score matrix comes from: msc_device_alloc (the library's default, placed), "
+                         "msc_device_alloc_probed (--probe-alloc candidates, all probed), or a plain torch.empty")
+    ap.add_argument("--probe-alloc", type=int, default=24, help="candidates of msc_device_alloc_probed (--alloc probed)")
+    ap.add_argument("--min-region-ms", type=float, default=10.0,
+                    help="a timed region shorter than this is re-run with more steps (reported as steps, with steps_requested)")
     return ap.parse_args()
 
 
@@ -264,7 +268,8 @@ def rccl_version(torch, backend):
     try:
         import torch.distributed as dist
         pg = dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda"))
-        return {"runtime": str(pg.get_runtime_nccl_version()), "build": str(pg.get_build_nccl_version()),
+        ver = lambda v: ".".join(str(i) for i in v) if isinstance(v, (tuple, list)) else str(v)   # noqa: E731
+        return {"runtime": ver(pg.get_runtime_nccl_version()), "build": ver(pg.get_build_nccl_version()),
                 "hip": torch.version.hip, "note": 'torch.distributed backend "nccl" on ROCm is RCCL'}
     except Exception:
         v = torch.cuda.nccl.version()
@@ -319,7 +324,8 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_
         "ms_per_step_ranks": {"max": ms, "min": dt_min / a.steps * 1e3},
         "one_rank_reference": ref,
         "weak_scaling_eff": (value / (world * ref["value"])) if ref else None,
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "steps": a.steps, "warmup": prewarm + a.warmup, "warmup_requested": a.warmup, "ms_per_step": ms,
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C5 NICH N=%d rows (%d per GPU) x K=%d groups, row-sharded synchronous Gibbs sweep: fused "
                                "leave-one-out score + CRP prior + sample, accumulate, ONE sum all-reduce of the additive "
@@ -327,7 +333,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_
                                                                             "RCCL" if backend == "nccl" else backend),
                    "rows_per_gpu": nrows, "groups": C5_GROUPS, "features": 1, "parallelism": "row-shard x%d" % world,
                    "collective": "1 x all_reduce(sum, f64[%d]) per sweep" % (drv.red_i64.numel() + drv.red_f64.numel()),
-                   "backend": backend, "clock_prewarm_steps": prewarm},
+                   "backend": backend},
         "evals_per_s": float(nrows) * world * C5_GROUPS / (dt / a.steps),
         "note": "weak_scaling_eff = value / (n_gpus * one_rank_reference.value); the N = 1 line reports the same one-rank "
                 "workload as c5_shard, its own `value` is the C2 scoring pass (evals/s), the metric BASELINE.json quotes "
@@ -346,38 +352,53 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     view = common_amd.DataView.from_tensors(ctx, [x])
     st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)   # default hp mu=0,kappa=1,sigmasq=1,nu=1
     st.accumulate(view, z)                                   # suff-stats from the true components
-    # the [N, K] matrix is caller-owned; where the driver places it decides between ~5.6 and ~7.0 TB/s for the same
-    # kernel (profiles/r02_placement_study.txt), so the library offers a probed allocation: the best of two dozen
-    # candidates held side by side (24 GB for a moment, ~60 ms, before anything is timed)
-    placement = {"allocator": "torch.empty"}
-    if a.no_probe_alloc or a.probe_alloc <= 1:
+    # the [N, K] matrix is caller-owned; where the driver places it decides between ~5.5 and ~7.0 TB/s for the same
+    # kernel (profiles/r02_placement_study.txt).  The headline uses the library's DEFAULT allocator (msc_device_alloc:
+    # from 64 MiB on a buffer mapped from 32 MiB chunks, up to six candidates tried until one fills at 6.6 TB/s); the
+    # same pass into a plain torch.empty is measured beside it (roofline.frac_caller_alloc)
+    if a.alloc == "torch":
         out = torch.empty((N, K), dtype=torch.float32, device=dev)
-    else:
+        placement = {"allocator": "torch.empty"}
+    elif a.alloc == "probed":
         out, rates, kept = ctx.alloc_probed((N, K), torch.float32, candidates=a.probe_alloc)
         placement = {"allocator": "msc_device_alloc_probed", "candidates_fill_GBps": [round(r, 1) for r in rates], "kept": kept}
+    else:
+        out = ctx.alloc((N, K), torch.float32)
+        rates, kept = ctx.alloc_stats()
+        placement = {"allocator": "msc_device_alloc (library default)", "candidates_fill_GBps": [round(r, 1) for r in rates],
+                     "kept": kept}
     tuned = None
     if a.tune:
         tuned = st.score_tune(view, out)                     # explicit and synchronous; never inside msc_score_value
     st.score_value(view, out=out)                            # derived tables (k_prepare) are built here, once
-    # the clocks need ~100 launches (~15 ms) after an idle stretch (profiles/r02_launch_transient.txt): when the caller's
-    # --warmup is shorter than that, the difference is spent here, before the W warm-up steps, and reported
-    prewarm = max(0, 200 - a.warmup)
-    for _ in range(prewarm):
+    # the clocks need ~100 launches (~15 ms) after an idle stretch (profiles/r02_launch_transient.txt): the warm-up is
+    # never shorter than 200 passes, and `warmup` in the line is what actually ran (`warmup_requested` what was asked)
+    warmup_run = max(a.warmup, 200)
+    for _ in range(warmup_run):
         st.score_value(view, out=out)
-    for _ in range(a.warmup):
-        st.score_value(view, out=out)
-    # HIP events over the timed region, on the stream the library launches on: ONE pair around the K launches (a pair
-    # per launch puts two event packets between consecutive kernels and reads ~5 % long against the rocprof trace)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync_all()
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(a.steps):
-        st.score_value(view, out=out)
-    ev1.record()
-    sync_all()
-    dt = time.perf_counter() - t0
-    kern_avg_ms = ev0.elapsed_time(ev1) / a.steps
+
+    def region(buf, steps):
+        """HIP events over the timed region, on the stream the library launches on: ONE pair around the launches (a
+        pair per launch puts two event packets between consecutive kernels and reads ~5 % long against the rocprof
+        trace) -> (wall seconds, kernel ms per step)"""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            st.score_value(view, out=buf)
+        ev1.record()
+        sync_all()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+    steps_requested = a.steps
+    dt, kern_avg_ms = region(out, a.steps)
+    short_region = None
+    if dt * 1e3 < a.min_region_ms:
+        # a 3 ms region is a handful of clock ticks of the driver's sampling: the line reports a region of >= 200 steps
+        # (and what the short one read, for the record)
+        short_region = {"steps": a.steps, "ms_per_step": dt / a.steps * 1e3, "kernel_avg_ms": kern_avg_ms}
+        a.steps = max(200, int(a.min_region_ms / (dt / a.steps * 1e3)) + 1)
+        dt, kern_avg_ms = region(out, a.steps)
     # (per-launch spread, outside the timed region)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 50))]
     for s_, e_ in ev:
@@ -392,9 +413,20 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     alg_bytes = 4.0 * N + 4.0 * N * K          # 4.016 B per eval for C2
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_entry("k_score_nich1", "hbm_bytes_per_launch")
+    # the same pass into a caller-owned torch.empty (what a caller gets who does not ask the library for the matrix)
+    caller = None
+    if a.alloc != "torch":
+        tbuf = torch.empty((N, K), dtype=torch.float32, device=dev)
+        for _ in range(50):
+            st.score_value(view, out=tbuf)
+        _, c_ms = region(tbuf, max(200, min(a.steps, 500)))
+        caller = {"allocator": "torch.empty", "kernel_avg_ms": c_ms, "achieved": alg_bytes / (c_ms * 1e-3) / 1e9,
+                  "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del tbuf
     line = {
         "metric": "score_value evals/sec", "value": evals / (dt / a.steps), "unit": "evals/s",
-        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+        "n_gpus": 1, "steps": a.steps, "steps_requested": steps_requested, "warmup": warmup_run,
+        "warmup_requested": a.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "C2 NICH scalar-Gaussian score_value pass, N=%d rows/GPU x K=%d groups x D=1, "
@@ -402,10 +434,11 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                                "9 us, runs when suff-stats change)" % (N, K),
                    "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x1",
                    "launch_shape": "msc_score_tune -> %s" % (tuned,) if tuned else "default (4 rows x 2 visits)",
-                   "clock_prewarm_passes": prewarm,
+                   "short_region": short_region,
                    "score_matrix": placement},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
+                     "frac_caller_alloc": caller["frac"] if caller else None, "caller_alloc": caller,
                      "traffic": traffic if (N, K) == (1_000_000, 256) else None,
                      "traffic_source": traffic_src,
                      "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,

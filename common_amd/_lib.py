@@ -47,6 +47,8 @@ _SIGS = {
     "msc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "msc_device_alloc_probed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "msc_device_alloc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32)]),
     "msc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "msc_pinned_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "msc_pinned_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -182,20 +182,6 @@ extern "C" int msc_context_synchronize(msc_context *ctx) {
   return device_error_check(ctx);
 }
 
-// plain device buffers for callers that hold no HIP headers of their own (the assignment vector, score rows)
-extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
-  MSC_REQUIRE(ctx && out, "null argument");
-  MSC_HIP(hipSetDevice(ctx->device));
-  void *p = nullptr;
-  MSC_HIP(hipMalloc(&p, nbytes ? nbytes : 1));
-  const hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);
-  if (e != hipSuccess) {
-    (void)hipFree(p);
-    return fail(MSC_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-  }
-  *out = p;
-  return MSC_OK;
-}
 // One candidate of msc_device_alloc_probed: nbytes of device memory mapped from 32 MiB physical chunks that are created
 // one by one (hipMemCreate) and mapped side by side into one reserved VA range.  Measured
 // (tools/microbench/placement_stitch.hip, four rounds): such buffers take the C2 store stream at 6.2-7.0 TB/s where
@@ -253,15 +239,17 @@ static void vmm_free(msc_context::VmmAlloc &a) {
   a.va = nullptr;
 }
 
-extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out,
-                                       float *rates_gbps, uint32_t *chosen) {
-  MSC_REQUIRE(ctx && out, "null argument");
-  MSC_REQUIRE(candidates >= 1 && candidates <= 64, "candidates %u outside 1..64", candidates);
-  *out = nullptr;
-  MSC_HIP(hipSetDevice(ctx->device));
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-    return fail(MSC_EINVAL, "msc_device_alloc_probed waits for the device: not on a capturing stream");
+// Large buffers (from 64 MiB on: score matrices) are PLACED: the same store stream runs 5.5 or 7.0 TB/s depending on where
+// the driver put the pages (profiles/r02_placement_study.txt), no allocator argument selects that, and buffers mapped
+// from separately created 32 MiB chunks land in the upper band more often than hipMalloc'ed ones.  So a candidate is
+// mapped from chunks, stream-filled a few times with the score kernels' store pattern, and kept when it takes the stream
+// at `accept_gbps` or better; otherwise the next candidate is tried while the rejected ones are still held (released
+// first, the driver would hand the same pages back), up to `max_candidates`, and the fastest wins.  Per-chunk selection
+// was tried and does not work: a chunk's rate inside a fill follows its position in the launch, not the chunk
+// (tools/microbench/placement_chunks.hip, profiles/r03_placement_chunks.txt).  Synchronous (about 1 ms per candidate
+// and GB).
+static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates, float accept_gbps, void **out,
+                        float *rates_gbps, uint32_t *chosen) {
   static const bool no_vmm = std::getenv("MSC_ALLOC_NO_VMM") != nullptr;       // (A/B knob: plain hipMalloc candidates)
   struct Cand { void *p; bool vmm; msc_context::VmmAlloc v; };
   std::vector<Cand> bufs;
@@ -278,7 +266,14 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
   int rc = MSC_OK;
   const int reps = nbytes >= (256u << 20) ? 3 : 8;
   const bool want_vmm = !no_vmm && nbytes >= (64u << 20);                      // small buffers: not worth 32 MiB chunks
-  for (uint32_t i = 0; i < candidates; i++) {
+  for (uint32_t i = 0; i < max_candidates; i++) {
+    if (i > 0) {                                                               // never take the device's last memory for a probe
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * nbytes + (1ull << 30)) {
+        (void)hipGetLastError();
+        break;
+      }
+    }
     Cand c{nullptr, false, {}};
     if (want_vmm && vmm_alloc(ctx->device, nbytes, &c.v)) {
       c.p = c.v.va;
@@ -289,17 +284,23 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
     }
     bufs.push_back(c);
     void *p = c.p;
-    hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);          // (zero-filled, like msc_device_alloc)
-    if (e == hipSuccess && launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-    for (int r = 0; r < reps && e == hipSuccess; r++)
-      if (launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
-    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e != hipSuccess) { rc = fail(MSC_EHIP, "placement probe failed: %s", hipGetErrorString(e)); break; }
-    rate.push_back(ms > 0.f ? (float)((double)nbytes * reps / (ms * 1e-3) / 1e9) : 0.f);
+    hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);          // (zero-filled, like every msc_device_alloc)
+    if (max_candidates > 1) {
+      if (e == hipSuccess && launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
+      if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+      for (int r = 0; r < reps && e == hipSuccess; r++)
+        if (launch_stream_fill(ctx->stream, ctx->num_cus, p, nbytes)) e = hipErrorLaunchFailure;
+      if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess) { rc = fail(MSC_EHIP, "placement probe failed: %s", hipGetErrorString(e)); break; }
+      rate.push_back(ms > 0.f ? (float)((double)nbytes * reps / (ms * 1e-3) / 1e9) : 0.f);
+      if (rate.back() >= accept_gbps) break;
+    } else {
+      if (e != hipSuccess) { rc = fail(MSC_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e)); break; }
+      rate.push_back(0.f);
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -311,12 +312,59 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
   int best = 0;
   for (size_t i = 1; i < rate.size(); i++)
     if (rate[i] > rate[best]) best = (int)i;
+  if (bufs.size() > 1) (void)hipStreamSynchronize(ctx->stream);
   release(best);
   if (bufs[best].vmm) ctx->vmm.push_back(bufs[best].v);
+  ctx->last_alloc_rates = rate;
+  ctx->last_alloc_chosen = (uint32_t)best;
   if (rates_gbps)
-    for (uint32_t i = 0; i < candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
+    for (uint32_t i = 0; i < max_candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
   if (chosen) *chosen = (uint32_t)best;
   *out = bufs[best].p;
+  return MSC_OK;
+}
+
+// device buffers for callers that hold no HIP headers of their own (the assignment vector, score rows, score matrices)
+extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
+  MSC_REQUIRE(ctx && out, "null argument");
+  *out = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  // MSC_ALLOC_CANDIDATES (default 6; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6600)
+  static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 6;
+  static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6600.f;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if (nbytes >= (64u << 20) && cand >= 1 && !capturing)
+    return alloc_placed(ctx, nbytes, (uint32_t)std::min(cand, 64), accept, out, nullptr, nullptr);
+  void *p = nullptr;
+  MSC_HIP(hipMalloc(&p, nbytes ? nbytes : 1));
+  const hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(MSC_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  *out = p;
+  return MSC_OK;
+}
+
+extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out,
+                                       float *rates_gbps, uint32_t *chosen) {
+  MSC_REQUIRE(ctx && out, "null argument");
+  MSC_REQUIRE(candidates >= 1 && candidates <= 64, "candidates %u outside 1..64", candidates);
+  *out = nullptr;
+  MSC_HIP(hipSetDevice(ctx->device));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(MSC_EINVAL, "msc_device_alloc_probed waits for the device: not on a capturing stream");
+  return alloc_placed(ctx, nbytes, candidates, 1e30f, out, rates_gbps, chosen);     // every candidate is probed, the best kept
+}
+extern "C" int msc_device_alloc_stats(msc_context *ctx, float *rates_gbps, uint32_t capacity, uint32_t *ntried, uint32_t *chosen) {
+  MSC_REQUIRE(ctx, "null context");
+  const uint32_t n = (uint32_t)ctx->last_alloc_rates.size();
+  if (rates_gbps)
+    for (uint32_t i = 0; i < capacity && i < n; i++) rates_gbps[i] = ctx->last_alloc_rates[i];
+  if (ntried) *ntried = n;
+  if (chosen) *chosen = ctx->last_alloc_chosen;
   return MSC_OK;
 }
 extern "C" int msc_device_free(msc_context *ctx, void *dev) {

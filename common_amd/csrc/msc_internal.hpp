@@ -247,6 +247,10 @@ struct msc_context {
   // through msc_device_free
   struct VmmAlloc { void *va; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
   std::vector<VmmAlloc> vmm;
+  // the candidates of the most recent placed allocation (msc_device_alloc >= 64 MiB, msc_device_alloc_probed): fill
+  // rates in GB/s and the index kept (msc_device_alloc_stats)
+  std::vector<float> last_alloc_rates;
+  uint32_t last_alloc_chosen = 0;
   // pinned, device-mapped mailbox for msc_value_op_single
   void *mailbox_host = nullptr;
   void *mailbox_dev = nullptr;

@@ -115,6 +115,12 @@ class Context(object):
         L.check(self.lib.msc_device_alloc(self._h, nbytes, C.byref(p)))
         return _alias_tensor(p.value, n, dtype, self.torch_device, owner=_DeviceBuffer(self, p.value)).reshape(*shape)
 
+    def alloc_stats(self):
+        """([GB/s fill rate of every candidate the most recent placed allocation tried], index kept)"""
+        rates, n, chosen = (C.c_float * 64)(), C.c_uint32(), C.c_uint32()
+        L.check(self.lib.msc_device_alloc_stats(self._h, rates, 64, C.byref(n), C.byref(chosen)))
+        return [float(rates[i]) for i in range(min(n.value, 64))], int(chosen.value)
+
     def alloc_probed(self, shape, dtype=torch.float32, candidates=8):
         """A zero-filled device tensor in the best-placed of `candidates` allocations (msc_device_alloc_probed; the
         write stream of a large score matrix runs 5.6 or 7.0 TB/s depending on where the driver put it).

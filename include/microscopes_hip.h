@@ -93,22 +93,26 @@ int msc_context_set_stream(msc_context *ctx, void *stream);
 int msc_context_synchronize(msc_context *ctx);
 
 /*
- * Plain device buffers (zero-filled), for hosts that keep no HIP headers of their
- * own: the assignment vector z, a row of scores.  upload / download are ordered on
- * the context's stream and complete before they return.
+ * Device buffers (zero-filled), for hosts that keep no HIP headers of their own: the assignment vector z, a row of
+ * scores, the [N, K] score matrix.  upload / download are ordered on the context's stream and complete before they
+ * return.
+ *
+ * From 64 MiB on a buffer is PLACED for the write stream of a score matrix: the same 1 GB stream takes 5.5 TB/s into
+ * most allocations and 7.0 TB/s into some, decided by where the driver put the pages (profiles/r02_placement_study.txt),
+ * and no allocator argument selects that.  A candidate is mapped from 32 MiB physical chunks through the virtual-memory
+ * API (such buffers land in the upper band more often than hipMalloc'ed ones), stream-filled a few times on the
+ * context's stream, and kept when it takes the stream at 6.6 TB/s or better; otherwise the next candidate is tried, up
+ * to six, and the fastest is kept (SYNCHRONOUS, about 1 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
+ * MSC_ALLOC_ACCEPT_GBPS in the environment change the bounds, MSC_ALLOC_CANDIDATES=0 is plain hipMalloc).
+ * msc_device_alloc_probed is the same with the bounds given by the caller: all `candidates` are probed and the fastest
+ * is returned; rates_gbps (nullable, `candidates` floats) receives every candidate's fill rate, *chosen (nullable) the
+ * index kept.  msc_device_alloc_stats reports the same for the context's most recent placed allocation.
+ * Free with msc_device_free.
  */
 int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out_dev);
-/*
- * A large, long-lived output buffer (the [N, K] score matrix) placed where the write stream runs fastest: the same
- * 1 GB stream takes 5.6 TB/s into most allocations and 7.0 TB/s into some, decided by where the driver put the pages
- * (profiles/r02_placement_study.txt), and no allocator argument selects that.  Up to `candidates` buffers are
- * allocated side by side (each mapped from 32 MiB physical chunks through the virtual-memory API; hipMalloc where
- * that is unavailable or the buffer is small -- both show both regimes), each is stream-filled a few times on the
- * context's stream, the fastest is returned and the rest are freed.  SYNCHRONOUS (about 1 ms per candidate and GB).  rates_gbps (nullable, `candidates` floats) receives
- * every candidate's fill rate, *chosen (nullable) the index kept.  Free with msc_device_free.
- */
 int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t candidates, void **out_dev,
                             float *rates_gbps, uint32_t *chosen);
+int msc_device_alloc_stats(msc_context *ctx, float *rates_gbps, uint32_t capacity, uint32_t *ntried, uint32_t *chosen);
 int msc_device_free(msc_context *ctx, void *dev);
 /*
  * Pinned host memory the device writes straight into (zero-copy): a row of scores the host reads after

@@ -153,8 +153,30 @@ def test_slice_scores_are_irms_per_entity_candidate_scores(gpu_ctx, family, shap
                 if offh[c] >= 0:
                     want[e] += sh[c, offh[c] + stride * np.arange(Ks[dim])]
         assert rel_err(got, want).max() <= 1e-6
-    with pytest.raises(common_amd.MicroscopesHipError):
-        view.slice_scores(scores[:, :2].contiguous(), view.slice_offsets(zt, Ks, 0), 0, Ks)   # score rows shorter than the blocks
+    off0 = view.slice_offsets(zt, Ks, 0)
+    with pytest.raises(ValueError):
+        view.slice_scores(scores[:, :2].contiguous(), off0, 0, Ks)   # score rows shorter than the blocks: refused on the host
+    # ... and below the wrapper: the C ABI refuses candidates that run past the row, and a row that holds the candidates
+    # but not every offset (off is caller data) is caught by the kernel -- skipped, reported, MSC_EDEVICE at the next call
+    import ctypes as C
+    lib, nd = gpu_ctx.lib, len(shape)
+    stride0 = int(np.prod(Ks[1:]))
+    out = torch.zeros((shape[0], Ks[0]), dtype=torch.float32, device=dev)
+    shp = (C.c_uint64 * nd)(*shape)
+
+    def raw(mat):
+        return lib.msc_relation_slice_scores(gpu_ctx._h, C.c_void_p(mat.data_ptr()), mat.stride(0), nd, shp, 0, None, None,
+                                             C.c_void_p(off0.data_ptr()), int(Ks[0]), stride0, shape[0],
+                                             C.c_void_p(out.data_ptr()), out.stride(0))
+    assert raw(scores[:, :2].contiguous()) == -1                     # MSC_EINVAL: (ncand - 1) * stride >= ld
+    narrow = scores[:, :(Ks[0] - 1) * stride0 + 1].contiguous()      # holds candidate ncand - 1 at offset 0 only
+    assert int(off0.max()) > 0
+    assert raw(narrow) == 0                                          # launched: the arguments alone are consistent
+    with pytest.raises(common_amd.MicroscopesHipError) as ei:
+        gpu_ctx.synchronize()
+    assert ei.value.code == -6 and "offset beyond the score row" in str(ei.value)
+    gpu_ctx.synchronize()                                            # reported once
+    assert bool(torch.isfinite(view.slice_scores(scores, off0, 0, Ks)).all())     # and the context works on
 
 
 def test_sparse_2d_relation_equals_the_dense_masked_one(gpu_ctx):
