@@ -675,6 +675,30 @@ static void plan_groups(msc_state *st) {
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
     else d.run_end = (i + 1 < d.grp_end && t[i + 1].kind != MSC_KIND_GENERIC) ? t[i + 1].run_end : i + 1;
   }
+  // The leave-one-out pass (k_loo_own_lds) stages what a row gathers per feature -- the lookup families' "value against
+  // the group minus one" tables, nich's twelve doubles per group -- for ALL kpad groups (a row's own group is any of
+  // them): consecutive features share the 64 KiB slot while their blocks fit; a feature whose block does not fit, or
+  // that is not of a staged kind, reads global memory inside its stage.
+  st->loo_staged = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    FeatDesc &d = t[i];
+    d.loo_off = d.loo_rows = 0;
+    uint32_t rows = 0;
+    if (d.kind != MSC_KIND_GENERIC && (d.loo_tab != nullptr || d.family == MSC_BBNC)) rows = d.run_clamp + 1;
+    else if (d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr && d.loo64 != nullptr) rows = 2 * kNlooStride;
+    if (rows != 0 && (uint64_t)rows * st->kpad <= kLooSlotFloats) d.loo_rows = rows;
+  }
+  for (uint32_t f0 = 0; f0 < n;) {
+    uint32_t used = 0, g = f0;
+    while (g < n && g - f0 < (uint32_t)kLooStageFeats && used + t[g].loo_rows * st->kpad <= kLooSlotFloats) {
+      t[g].loo_off = used;
+      used += t[g].loo_rows * st->kpad;
+      st->loo_staged += t[g].loo_rows != 0;
+      g++;
+    }
+    for (uint32_t i = f0; i < g; i++) t[i].loo_stage_end = g;
+    f0 = g;
+  }
 }
 
 static int upload_desc(msc_state *st) {
@@ -1300,7 +1324,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   hipStream_t s = st->ctx->stream;
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
-    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
+    if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
       return fail(MSC_EHIP, "k_loo_own launch failed");
   }
   uint32_t n_niw = 0;
@@ -1621,7 +1645,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   } else if (sweep_is_fused(st)) {
     if (!nich1) {                                       // (the single-nich kernel computes the own-group values itself)
       MSC_TRY(ensure_own(st, nrows));
-      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+      if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
     }
     uint32_t narrow_rows = 0;

@@ -333,59 +333,68 @@ MSC_DEV float nich_eval_log2_est(float x, float smu_hi, float smu_lo, float c0, 
 // Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:
 //   n = count - 1, m2 = (mean count - x) / n, v2 = ctv - (x - mean)(x - m2), then the posterior and the
 //   Student-t of the section header with (n, m2, v2).
-// It runs through per-group constants (k_prepare fills them; rows of FeatDesc::loo64): what depends on
-// the group alone -- reciprocals, the lgamma difference, logs -- is computed once per group, the row
-// keeps ~15 fma, one division, one log and one log1p.
-// NLOO_STATS: the group's own float fields (mean in the low word, count_times_variance in the high one), so that a row
-// reads one block per (feature, group) and nothing else
-enum { NLOO_TOTAL = 0, NLOO_INV_N, NLOO_HAS_V2, NLOO_KMU, NLOO_N_INV_KN, NLOO_NUSIG, NLOO_INV_NUN, NLOO_NKK,
-       NLOO_C0G, NLOO_C1, NLOO_K2G, NLOO_STATS, NLOO_ROWS };
+// It runs through per-group constants (k_prepare fills them; FeatDesc::loo64, kNlooStride doubles per group side by
+// side): what depends on the group alone and costs a division or an lgamma -- 1/n, 1/kappa_n, 1/nu_n, the constant
+// term -- is computed once per group; what is a multiplication away from those (n/kappa_n = 1 - kappa/kappa_n, ...) the
+// row derives itself.  Six doubles = 48 bytes = three 16-byte reads per (row, feature): the block was twelve doubles
+// until the rows' gathers of it turned out to be what the leave-one-out pass spends its time on (the LDS port at a
+// 96-byte stride: 16-way bank conflicts; profiles/r03_loo_own.txt).
+//   STATS    the group's own float fields (mean in the low word, count_times_variance in the high one)
+//   TOTAL    mean * count
+//   INV_N    1 / n (0 when the row is the group's only member); n > 1 <=> 0 < INV_N < 1
+//   IKN      1 / kappa_n,  kappa_n = kappa + n
+//   INV_NUN  1 / nu_n,     nu_n = nu + n
+//   C01      two floats: c0 = lgamma((nu_n + 1)/2) - lgamma(nu_n/2) + log(kfac / (pi nu_n)) / 2 (low word) and
+//            c1 = (nu_n + 1) / 2 (high word); kfac = kappa_n / (kappa_n + 1) = 1 / (1 + IKN)
+enum { NLOO_STATS = 0, NLOO_TOTAL, NLOO_INV_N, NLOO_IKN, NLOO_INV_NUN, NLOO_C01, NLOO_ROWS };
 MSC_DEV void nich_loo_prepare(const float *hp, uint32_t count, float mean_f, float ctv_f, double *out, size_t stride) {
   out[NLOO_STATS * stride] = __hiloint2double(__float_as_int(ctv_f), __float_as_int(mean_f));
-  const double mu = hp[0], kappa = hp[1], sigmasq = hp[2], nu = hp[3];
+  const double kappa = hp[1], nu = hp[3];
   const double n = (double)count - 1.0, kn = kappa + n, nun = nu + n, kfac = kn / (kn + 1.0);
   out[NLOO_TOTAL * stride] = (double)mean_f * (double)count;
   out[NLOO_INV_N * stride] = count <= 1 ? 0.0 : 1.0 / n;
-  out[NLOO_HAS_V2 * stride] = n > 1.0 ? 1.0 : 0.0;
-  out[NLOO_KMU * stride] = kappa * mu / kn;
-  out[NLOO_N_INV_KN * stride] = n / kn;
-  out[NLOO_NUSIG * stride] = nu * sigmasq / nun;
+  out[NLOO_IKN * stride] = 1.0 / kn;
   out[NLOO_INV_NUN * stride] = 1.0 / nun;
-  out[NLOO_NKK * stride] = n * kappa / (kn * nun);
-  out[NLOO_C0G * stride] = lgamma_pos(0.5 * nun + 0.5) - lgamma_pos(0.5 * nun) + 0.5 * log(kfac / (kPi * nun));
-  out[NLOO_C1 * stride] = 0.5 * nun + 0.5;
-  out[NLOO_K2G * stride] = kfac / nun;
+  const float c0 = (float)(lgamma_pos(0.5 * nun + 0.5) - lgamma_pos(0.5 * nun) + 0.5 * log(kfac / (kPi * nun)));
+  const float c1 = (float)(0.5 * nun + 0.5);
+  out[NLOO_C01 * stride] = __hiloint2double(__float_as_int(c1), __float_as_int(c0));
+}
+// the double part both forms share: the downdated group's posterior scale `sig` and the squared distance `dd2`
+MSC_DEV void nich_loo_core(const float *hp, const double *t, size_t stride, float xf, double &sig, double &dd2, double &ikn) {
+  const double stats = t[NLOO_STATS * stride];
+  const double x = xf, mean = __int_as_float(__double2loint(stats)), ctv = __int_as_float(__double2hiint(stats));
+  const double mu = hp[0], kappa = hp[1], sigmasq = hp[2], nu = hp[3];
+  const double inv_n = t[NLOO_INV_N * stride];
+  ikn = t[NLOO_IKN * stride];
+  const double m2 = (t[NLOO_TOTAL * stride] - x) * inv_n;
+  // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
+  // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
+  const double v2 = (inv_n > 0.0 && inv_n < 1.0) ? fmax(ctv - (x - mean) * (x - m2), 0.0) : 0.0;     // n > 1
+  const double n_ikn = 1.0 - kappa * ikn;                  // n / kappa_n
+  const double mun = (kappa * mu) * ikn + m2 * n_ikn;
+  const double d = mu - m2;
+  sig = (nu * sigmasq + v2 + (kappa * n_ikn) * d * d) * t[NLOO_INV_NUN * stride];
+  const double dd = x - mun;
+  dd2 = dd * dd * t[NLOO_INV_NUN * stride];               // (times kfac: the Student-t's (x - mu_n)^2 lambda / nu_n)
 }
 MSC_DEV double nich_loo_tab(const float *hp, const double *t, size_t stride, float xf) {
-  const double stats = t[NLOO_STATS * stride];
-  const double x = xf, mean = __int_as_float(__double2loint(stats)), ctv = __int_as_float(__double2hiint(stats)), mu = hp[0];
-  const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
-  // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
-  // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
-  const double v2 = fmax(t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2)), 0.0);
-  const double mun = t[NLOO_KMU * stride] + m2 * t[NLOO_N_INV_KN * stride];
-  const double d = mu - m2;
-  const double sig = t[NLOO_NUSIG * stride] + v2 * t[NLOO_INV_NUN * stride] + t[NLOO_NKK * stride] * d * d;
-  const double dd = x - mun;
-  return t[NLOO_C0G * stride] - 0.5 * log(sig) - t[NLOO_C1 * stride] * log1p(t[NLOO_K2G * stride] * dd * dd / sig);
+  double sig, dd2, ikn;
+  nich_loo_core(hp, t, stride, xf, sig, dd2, ikn);
+  const double c01 = t[NLOO_C01 * stride];
+  const double c0 = __int_as_float(__double2loint(c01)), c1 = __int_as_float(__double2hiint(c01));
+  return c0 - 0.5 * log(sig) - c1 * log1p(dd2 / ((1.0 + ikn) * sig));
 }
-// The transposed sweep kernel's form: the downdate and the posterior -- where the cancellations are -- in double as above,
-// the two logarithms and the division in float (log1p_acc: hardware log2 + the compensation term), which is how every
-// other entry of the row is evaluated.  ~14 double fma + ~15 float instructions instead of ~225 double ones.
+// The sweep kernels' and the leave-one-out pass's form: the downdate and the posterior -- where the cancellations are --
+// in double as above, the two logarithms and the divisions in float (log1p_acc: hardware log2 + the compensation term),
+// which is how every other entry of the row is evaluated.
 MSC_DEV float nich_loo_tab_sweep(const float *hp, const double *t, size_t stride, float xf) {
-  const double stats = t[NLOO_STATS * stride];
-  const double x = xf, mean = __int_as_float(__double2loint(stats)), ctv = __int_as_float(__double2hiint(stats)), mu = hp[0];
-  const double m2 = (t[NLOO_TOTAL * stride] - x) * t[NLOO_INV_N * stride];
-  // (a sum of squares: below zero it is the rounding of the float fields it is rebuilt from -- an outlier 1e6 away
-  // leaves count_times_variance ~1e12 with an ulp of 1e5 -- and a negative variance would turn the score into NaN)
-  const double v2 = fmax(t[NLOO_HAS_V2 * stride] * (ctv - (x - mean) * (x - m2)), 0.0);
-  const double mun = t[NLOO_KMU * stride] + m2 * t[NLOO_N_INV_KN * stride];
-  const double d = mu - m2;
-  const double sig = t[NLOO_NUSIG * stride] + v2 * t[NLOO_INV_NUN * stride] + t[NLOO_NKK * stride] * d * d;
-  const double dd = x - mun;
-  const float sigf = (float)sig, q = (float)(t[NLOO_K2G * stride] * dd * dd);
+  double sig, dd2, ikn;
+  nich_loo_core(hp, t, stride, xf, sig, dd2, ikn);
+  const double c01 = t[NLOO_C01 * stride];
+  const float c0 = __int_as_float(__double2loint(c01)), c1 = __int_as_float(__double2hiint(c01));
+  const float sigf = (float)sig, q = (float)dd2 * hw_rcp(1.0f + (float)ikn);      // kfac = 1 / (1 + 1/kappa_n)
   const float tt = q * hw_rcp(sigf);                     // (v_rcp_f32: 1 ulp, far inside what log1p of it keeps)
-  return (float)t[NLOO_C0G * stride] - 0.5f * (hw_log2(sigf) * kLn2f) - (float)t[NLOO_C1 * stride] * log1p_acc(tt);
+  return c0 - 0.5f * (hw_log2(sigf) * kLn2f) - c1 * log1p_acc(tt);
 }
 // gp leave-one-out: posterior (a - v, b - 1) of the group's own (a, b); a' + v = a, so
 //   score = [lgamma(a) - lgamma(a - v)] - log v! + (a - v) ln b' - a ln(1 + b')

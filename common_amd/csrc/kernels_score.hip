@@ -273,8 +273,60 @@ __global__ __launch_bounds__(256) void k_entity_op(const FeatDesc *__restrict__ 
 // sum over scalar features of score_value(group z[n] minus row n, row n).  One thread per row,
 // everything in double; niw features add theirs inside the niw kernel.
 // ---------------------------------------------------------------------------
+// one feature of one row against the row's own group, read from global memory: masked columns, counts beyond the
+// tables, nich, dm -- and every feature of the kernel that stages nothing.
 // HEAVY = false leaves out the branches with lgamma chains in them (gp / bnb counts beyond the table, dm): with them
 // inlined the kernel sits at 225 VGPRs, 2 waves per SIMD, for rows that never take them (launch_loo_own picks)
+template <bool HEAVY>
+MSC_DEV double loo_feature_global(const FeatDesc &fd, uint64_t row, int g, uint32_t kpad) {
+  if (fd.family != MSC_NIW && load_masked(fd, row, true)) return 0.0;
+  switch (fd.family) {
+    case MSC_BB:       // lookup families: the table k_prepare made of "this value against the group minus one of it"
+      return (double)fd.loo_tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
+    case MSC_BBNC:     // p does not move when a row leaves: the plain score's own table entry (a double log per row before)
+      return (double)fd.tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
+    case MSC_GP: {
+      const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+      if (v < fd.vcap) return (double)fd.loo_tab[(size_t)v * kpad + g];
+      if (HEAVY) return gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], v);
+      return 0.0;
+    }
+    case MSC_BNB: {
+      const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+      if (v < fd.vcap) return (double)fd.loo_tab[(size_t)v * kpad + g];
+      if (HEAVY) return bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
+      return 0.0;
+    }
+    case MSC_DM: {
+      // dim + 1 lookups in the leave-one-out tables k_dm_prepare fills (it was 2 (dim + 1) lgamma per row); rows
+      // whose total is beyond the tables take the formula
+      const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
+      const uint32_t tot = fd.dm_tot[row];
+      double s = 0.0;
+      if (tot < kGpMaxTable && fd.loo64 != nullptr && fd.dm_meta != nullptr) {
+        for (uint32_t i = 0; i <= fd.dim; i++) {
+          const uint32_t v = i < fd.dim ? (uint32_t)x[i] : tot;
+          if (v) s += fd.loo64[(size_t)(fd.dm_meta[2 * i] / 2 + v) * kpad + g];      // (entry 0 is exactly zero)
+        }
+      } else if (HEAVY) {
+        s = dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad, x, true);
+      }
+      return s;
+    }
+    case MSC_DD: {
+      int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+      v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
+      return (double)fd.loo_tab[(size_t)v * kpad + g];
+    }
+    case MSC_NICH:
+      // (downdate and posterior in double, the two logarithms and the division in float like every other entry of
+      // the row: family_math.hpp nich_loo_tab_sweep -- the all-double form was ~225 double instructions per feature,
+      // 0.18 of this kernel's 0.32 ms on C3)
+      return (double)nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)g * kNlooStride, 1, reinterpret_cast<const float *>(fd.col)[row]);
+    default: return 0.0;
+  }
+}
+
 template <bool HEAVY>
 __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K,
                                                   uint32_t kpad, uint64_t row0, uint64_t nrows,
@@ -301,7 +353,7 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
   // first.  For those a feature is value -> table entry, two dependent loads and nothing else, and with one row per
   // thread nobody hides them: four features at a time, without a branch between the loads (the value fetch and the
   // clamp of the tile kernels' lookup runs), so that four loads are in flight where one was.  Everything else --
-  // masked columns, counts beyond the tables, nich, dm -- goes through the switch below, feature by feature.
+  // masked columns, counts beyond the tables, nich, dm -- goes through loo_feature_global, feature by feature.
   auto run_word = [&](const FeatDesc &d) -> uint32_t {
     typedef const __attribute__((address_space(1))) unsigned char *g_u8;
     const bool u8 = d.kind == MSC_KIND_LOOKUP_U8;
@@ -334,54 +386,114 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
       continue;
     }
     const FeatDesc fd = feats[f++];
-    if (fd.family != MSC_NIW && load_masked(fd, row, true)) continue;
-    switch (fd.family) {
-      case MSC_BB:       // lookup families: the table k_prepare made of "this value against the group minus one of it"
-        s += (double)fd.loo_tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
-        break;
-      case MSC_BBNC:     // p does not move when a row leaves: the plain score's own table entry (a double log per row before)
-        s += (double)fd.tab[(reinterpret_cast<const uint8_t *>(fd.col)[row] != 0 ? kpad : 0u) + g];
-        break;
-      case MSC_GP: {
-        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-        if (v < fd.vcap) s += (double)fd.loo_tab[(size_t)v * kpad + g];
-        else if (HEAVY) s += gp_loo(fd.hp, fd.raw_u32[g], fd.raw_u32[kpad + g], v);
-      } break;
-      case MSC_BNB: {
-        const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-        if (v < fd.vcap) s += (double)fd.loo_tab[(size_t)v * kpad + g];
-        else if (HEAVY) s += bnb_score(fd.hp, (double)fd.raw_u32[g] - 1.0, (double)fd.raw_u32[kpad + g] - (double)v, (double)v);
-      } break;
-      case MSC_DM: {
-        // dim + 1 lookups in the leave-one-out tables k_dm_prepare fills (it was 2 (dim + 1) lgamma per row); rows
-        // whose total is beyond the tables take the formula
-        const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
-        const uint32_t tot = fd.dm_tot[row];
-        if (tot < kGpMaxTable && fd.loo64 != nullptr && fd.dm_meta != nullptr) {
-          for (uint32_t i = 0; i <= fd.dim; i++) {
-            const uint32_t v = i < fd.dim ? (uint32_t)x[i] : tot;
-            if (v) s += fd.loo64[(size_t)(fd.dm_meta[2 * i] / 2 + v) * kpad + g];      // (entry 0 is exactly zero)
-          }
-        } else if (HEAVY) {
-          s += dm_score_direct(fd.hp, fd.dim, fd.raw_u32 + g, kpad, x, true);
-        }
-      } break;
-      case MSC_DD: {
-        int v = reinterpret_cast<const int32_t *>(fd.col)[row];
-        v = v < 0 ? 0 : (v >= (int)fd.dim ? (int)fd.dim - 1 : v);
-        s += (double)fd.loo_tab[(size_t)v * kpad + g];
-      } break;
-      case MSC_NICH:
-        // (downdate and posterior in double, the two logarithms and the division in float like every other entry of
-        // the row: family_math.hpp nich_loo_tab_sweep -- the all-double form was ~225 double instructions per feature,
-        // 0.18 of this kernel's 0.32 ms on C3)
-        s += (double)nich_loo_tab_sweep(fd.hp, fd.loo64 + (size_t)g * kNlooStride, 1,
-                                        reinterpret_cast<const float *>(fd.col)[row]);
-        break;
-      default: break;
-    }
+    s += loo_feature_global<HEAVY>(fd, row, g, kpad);
   }
   own[n] = (float)s;
+}
+
+// ---------------------------------------------------------------------------
+// The same pass for many rows: what a row gathers per feature comes from LDS.  In k_loo_own every lane of a wave reads
+// its own group's entry -- 64 cache lines per wave instruction, two of them per nich feature and row (96 bytes of
+// constants) -- and the kernel ran at the rate the address unit splits such gathers, 0.25 ms for C3's 64 columns
+// (0.97 TB/s of 64-byte sectors for 4 + 4 useful bytes).  Here a workgroup of 512 threads takes 2048 rows (four per
+// thread, coalesced) through the stages of the leave-one-out plan (abi.cpp plan_groups: consecutive features whose
+// blocks -- the lookup families' leave-one-out tables, nich's twelve doubles per group, for all kpad groups -- share the
+// 64 KiB slot): the block copy is coalesced, the per-row reads are LDS reads at the lane's own address, and two
+// workgroups per CU cover each other's copies.  Same terms, same order of the double sum as k_loo_own: same bits.
+// ---------------------------------------------------------------------------
+constexpr int kLooRows = 4, kLooThreads = 512;      // (kLooStageFeats: msc_internal.hpp)
+template <bool HEAVY>
+__global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__restrict__ feats,
+                                                              int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
+                                                              const int32_t *__restrict__ z,
+                                                              const float *__restrict__ crp, float *__restrict__ own) {
+  extern __shared__ __attribute__((aligned(16))) float slot[];
+  const uint64_t base = (uint64_t)blockIdx.x * (kLooRows * kLooThreads) + threadIdx.x;
+  int g[kLooRows];
+  double s[kLooRows];
+  uint64_t row[kLooRows];
+#pragma unroll
+  for (int j = 0; j < kLooRows; j++) {
+    const uint64_t n = base + (uint64_t)j * kLooThreads;
+    const int gg = n < nrows ? z[n] : -1;
+    g[j] = (uint32_t)gg < K ? gg : -1;
+    row[j] = row0 + (n < nrows ? n : nrows - 1);          // (a row of the call's range for the loads of idle slots)
+    s[j] = 0.0;
+    if (crp && g[j] >= 0) {
+      const float lm1 = crp[kpad + g[j]];
+      s[j] = __builtin_isinf(lm1) ? (double)crp[2 * (size_t)kpad + 1] + (double)crp[2 * (size_t)kpad + 3]
+                                  : (double)lm1 + (double)crp[crp_lo_cntm1(kpad) + g[j]];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int f0 = 0;
+  while (f0 < nfeat) {
+    const int f1 = (int)feats[f0].loo_stage_end;           // (at most kLooStageFeats features: abi.cpp plan_groups)
+    __syncthreads();                                      // the slot's previous readers are done
+    // the blocks, 1 KiB per wave instruction straight into LDS (global_load_lds_dwordx4) ...
+    for (int f = f0; f < f1; f++) {
+      const FeatDesc &fd = feats[f];
+      if (fd.loo_rows == 0) continue;
+      const float *src = fd.family == MSC_NICH ? reinterpret_cast<const float *>(fd.loo64)
+                                                : (fd.family == MSC_BBNC ? fd.tab : fd.loo_tab);
+      const uint32_t nchunks = fd.loo_rows * (kpad / 256);  // (kpad is a multiple of 256)
+      float4 *dst = reinterpret_cast<float4 *>(slot + fd.loo_off);
+      for (uint32_t c = (uint32_t)wave; c < nchunks; c += kLooThreads / 64)
+        glds16(src + (size_t)c * 256 + 4 * lane, dst + (size_t)c * 64);
+    }
+    // ... and, in the same breath, the values of this thread's rows for every feature of the stage: one exposed memory
+    // latency per stage instead of one per feature (fetching them a stage AHEAD, under the evaluation of the stage
+    // before, measured slower: 148 -> 162 us on C3, 126 registers; so did what the kernel needs of a descriptor packed
+    // into a 48-byte head and the stage's heads read up front: a stage of sixteen bool columns 33 -> 18 us, C3's mix
+    // 148 -> 164-177 us, the heads live in scalar registers that the evaluation then spills).  No branch around a load: a
+    // slot past the stage's end reads the stage's last column again; a column of any type holds at least one dword per
+    // row but a bool column, which is read by the byte.
+    uint32_t w[kLooStageFeats][kLooRows];
+#pragma unroll
+    for (int fi = 0; fi < kLooStageFeats; fi++) {
+      const FeatDesc &fd = feats[f0 + fi < f1 ? f0 + fi : f1 - 1];
+      const bool u8 = fd.col_type == MSC_TYPE_B || fd.col_type == MSC_TYPE_I8 || fd.col_type == MSC_TYPE_U8;
+#pragma unroll
+      for (int j = 0; j < kLooRows; j++)
+        w[fi][j] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row[j]] : reinterpret_cast<const uint32_t *>(fd.col)[row[j]];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the blocks, and the values
+    __syncthreads();
+#pragma unroll
+    for (int fi = 0; fi < kLooStageFeats; fi++) {
+      if (f0 + fi >= f1) break;
+      const FeatDesc &fd = feats[f0 + fi];
+      if (fd.loo_rows == 0) {                             // not staged: from global memory
+#pragma unroll
+        for (int j = 0; j < kLooRows; j++)
+          if (g[j] >= 0) s[j] += loo_feature_global<HEAVY>(fd, row[j], g[j], kpad);
+        continue;
+      }
+      const float *blk = slot + fd.loo_off;
+      if (fd.family == MSC_NICH) {
+#pragma unroll
+        for (int j = 0; j < kLooRows; j++) {
+          const double *t = reinterpret_cast<const double *>(blk) + (size_t)(g[j] >= 0 ? g[j] : 0) * kNlooStride;
+          const float e = nich_loo_tab_sweep(fd.hp, t, 1, __uint_as_float(w[fi][j]));
+          if (g[j] >= 0) s[j] += (double)e;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kLooRows; j++) {
+          const int v = (int)w[fi][j];
+          const uint32_t idx = (uint32_t)(v < 0 ? 0 : (v > (int)fd.run_clamp ? (int)fd.run_clamp : v));
+          const float e = blk[(size_t)idx * kpad + (g[j] >= 0 ? g[j] : 0)];
+          if (g[j] >= 0) s[j] += (double)e;
+        }
+      }
+    }
+    f0 = f1;
+  }
+#pragma unroll
+  for (int j = 0; j < kLooRows; j++) {
+    const uint64_t n = base + (uint64_t)j * kLooThreads;
+    if (n < nrows) own[n] = g[j] >= 0 ? (float)s[j] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -793,9 +905,28 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
-                   uint64_t nrows, const int32_t *z, const float *crp, float *own) {
+int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, bool staged, const FeatDesc *feats_dev, int nfeat, uint32_t K,
+                   uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *crp, float *own) {
   (void)num_cus;
+  // staged: the plan has features whose leave-one-out blocks fit the LDS slot (abi.cpp plan_groups).  Worth the block
+  // copies from a few tens of thousands of rows on (a workgroup copies every block once for its 2048 rows)
+  static const int lds_mode = std::getenv("MSC_LOO_LDS") ? std::atoi(std::getenv("MSC_LOO_LDS")) : -1;   // 0 / 1: A/B knob
+  const bool use_lds = staged && (lds_mode < 0 ? nrows >= 32768 : lds_mode != 0);
+  if (use_lds) {
+    static unsigned long long attr_devices = 0;
+    if (first_use_on_device(attr_devices)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    }
+    const unsigned blocks = (unsigned)((nrows + kLooRows * kLooThreads - 1) / (kLooRows * kLooThreads));
+    if (heavy)
+      hipLaunchKernelGGL(k_loo_own_lds<true>, dim3(blocks), dim3(kLooThreads), kLooSlotFloats * 4, stream, feats_dev, nfeat, K,
+                         kpad, row0, nrows, z, crp, own);
+    else
+      hipLaunchKernelGGL(k_loo_own_lds<false>, dim3(blocks), dim3(kLooThreads), kLooSlotFloats * 4, stream, feats_dev, nfeat, K,
+                         kpad, row0, nrows, z, crp, own);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (heavy)
     hipLaunchKernelGGL(k_loo_own<true>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, feats_dev, nfeat,
                        K, kpad, row0, nrows, z, crp, own);

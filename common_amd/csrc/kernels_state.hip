@@ -32,183 +32,184 @@ __device__ __host__ inline AccShape acc_shape(int family, uint32_t dim_slice) {
   }
 }
 
+// One workgroup = one feature (blockIdx.x; nfeat = the group sizes of group_manager) x one slice of `per` rows
+// (blockIdx.y).  The grid is sized for ~8 workgroups per CU (launch_accumulate), so a slice is tens of thousands of
+// rows when there are many features: the histogram of a dd(32) column has 8192 (category, group) bins, and a workgroup
+// that sees 4096 rows flushes ~3300 of them with a global atomic apiece -- that flush, and 64 dependent
+// zero / barrier / load / barrier / flush rounds per workgroup with four rows per thread in each, was the old kernel's
+// time on C3 (0.34 ms for 212 MB).  Here a workgroup makes one round, keeps eight rows per thread in flight, and
+// flushes once per ~32k rows; workgroups of different features run side by side and hide each other's latencies.
 __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict__ feats, int nfeat,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
                                                       uint64_t nrows, const int32_t *__restrict__ z,
                                                       int sign, long long *__restrict__ cnt_acc,
-                                                      uint32_t dd_slice) {
+                                                      uint32_t dd_slice, uint64_t per) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint64_t per = (nrows + gridDim.x - 1) / gridDim.x;
-  const uint64_t lo = (uint64_t)blockIdx.x * per;
+  const uint64_t lo = (uint64_t)blockIdx.y * per;
   const uint64_t hi = lo + per < nrows ? lo + per : nrows;
+  if (lo >= hi) return;
   const long long sgn = sign;
+  constexpr int U = 8;                                   // rows a thread keeps in flight
+  const uint32_t nt = blockDim.x;
 
-  // gridDim.y == 1: the block walks the group sizes (group_manager counts) and then every feature over its slice
-  // of rows.  gridDim.y == nfeat + 1 (few rows, launch_accumulate): blockIdx.y = 0 takes the group sizes and
-  // blockIdx.y = 1 + f feature f, so that a small problem still spreads over the chip.
-  const bool spread = gridDim.y > 1;
-  if (!spread || blockIdx.y == 0) {
+  if ((int)blockIdx.x == nfeat) {
     uint32_t *c32 = reinterpret_cast<uint32_t *>(smem);
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) c32[i] = 0;
+    for (uint32_t i = threadIdx.x; i < K; i += nt) c32[i] = 0;
     __syncthreads();
-    for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-      const int g = z[n];
-      if (g >= 0 && (uint32_t)g < K) atomicAdd(&c32[g], 1u);
+    for (uint64_t base = lo; base < hi; base += (uint64_t)U * nt) {
+      int g[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
+        g[j] = n < hi ? z[n] : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < U; j++)
+        if ((uint32_t)g[j] < K) atomicAdd(&c32[g[j]], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < K; i += nt)
       if (c32[i]) atomicAdd(reinterpret_cast<unsigned long long *>(&cnt_acc[i]),
                             (unsigned long long)(sgn * (long long)c32[i]));
-    if (spread) return;
-    __syncthreads();
+    return;
   }
 
-  // A workgroup's slice is at most four rows per thread in the usual launch (launch_accumulate): their groups are read
-  // once, and an unmasked scalar column's four values go out together before the first LDS atomic -- a column was
-  // four dependent (group, value) load pairs per thread behind three barriers, and the waves mostly waited
-  const bool few = hi - lo <= 4ull * blockDim.x;
-  int zr[4];
-  uint64_t rr[4];
+  const FeatDesc fd = feats[blockIdx.x];
+  // dd and dm walk their categories in slices that fit the LDS budget (dm bins are 8 bytes wide)
+  const bool sliced = fd.family == MSC_DD || fd.family == MSC_DM;
+  const uint32_t slice = fd.family == MSC_DM ? (dd_slice > 1 ? dd_slice / 2 : 1) : dd_slice;
+  const uint32_t nslices = sliced ? (fd.dim + slice - 1) / slice : 1;
+  for (uint32_t sl = 0; sl < nslices; sl++) {
+    const uint32_t c_lo = sl * slice;
+    const uint32_t c_n = sliced ? (fd.dim - c_lo < slice ? fd.dim - c_lo : slice) : 0;
+    const AccShape sh = acc_shape(fd.family, c_n);
+    double *f64 = reinterpret_cast<double *>(smem);
+    unsigned long long *u64 = reinterpret_cast<unsigned long long *>(f64 + (size_t)K * sh.nf64);
+    uint32_t *u32 = reinterpret_cast<uint32_t *>(u64 + (size_t)K * sh.nu64);
+    for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += nt) f64[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += nt) u64[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += nt) u32[i] = 0u;
+    __syncthreads();
+    const bool scalar_col = fd.family == MSC_BB || fd.family == MSC_BBNC || fd.family == MSC_GP || fd.family == MSC_BNB ||
+                            fd.family == MSC_DD || fd.family == MSC_NICH;
+    if (scalar_col && fd.mask == nullptr) {
+      // an unmasked scalar column: U (group, value) pairs per thread go out together before the first LDS atomic
+      const bool u8 = fd.family == MSC_BB || fd.family == MSC_BBNC;
+      for (uint64_t base = lo; base < hi; base += (uint64_t)U * nt) {
+        int g[U];
+        uint32_t w[U];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint64_t n = lo + threadIdx.x + (uint64_t)j * blockDim.x;
-    rr[j] = row0 + n;
-    zr[j] = (few && n < hi) ? z[n] : -1;
-    if ((uint32_t)zr[j] >= K) zr[j] = -1;
-  }
-  const int f_lo = spread ? (int)blockIdx.y - 1 : 0, f_hi = spread ? f_lo + 1 : nfeat;
-  for (int f = f_lo; f < f_hi; f++) {
-    const FeatDesc fd = feats[f];
-    // dd and dm walk their categories in slices that fit the LDS budget (dm bins are 8 bytes wide)
-    const bool sliced = fd.family == MSC_DD || fd.family == MSC_DM;
-    const uint32_t slice = fd.family == MSC_DM ? (dd_slice > 1 ? dd_slice / 2 : 1) : dd_slice;
-    const uint32_t nslices = sliced ? (fd.dim + slice - 1) / slice : 1;
-    for (uint32_t sl = 0; sl < nslices; sl++) {
-      const uint32_t c_lo = sl * slice;
-      const uint32_t c_n = sliced ? (fd.dim - c_lo < slice ? fd.dim - c_lo : slice) : 0;
-      const AccShape sh = acc_shape(fd.family, c_n);
-      double *f64 = reinterpret_cast<double *>(smem);
-      unsigned long long *u64 = reinterpret_cast<unsigned long long *>(f64 + (size_t)K * sh.nf64);
-      uint32_t *u32 = reinterpret_cast<uint32_t *>(u64 + (size_t)K * sh.nu64);
-      for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += blockDim.x) f64[i] = 0.0;
-      for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) u64[i] = 0ull;
-      for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += blockDim.x) u32[i] = 0u;
-      __syncthreads();
-      const bool scalar_col = fd.family == MSC_BB || fd.family == MSC_BBNC || fd.family == MSC_GP || fd.family == MSC_BNB ||
-                              fd.family == MSC_DD || fd.family == MSC_NICH;
-      if (few && scalar_col && fd.mask == nullptr) {
-        const bool u8 = fd.family == MSC_BB || fd.family == MSC_BBNC;
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {                               // (a bool column: the aligned dword around the byte)
-          w[j] = 0u;
-          if (zr[j] >= 0) {
-            const uint64_t at = (reinterpret_cast<uint64_t>(fd.col) + (u8 ? rr[j] : rr[j] * 4)) & ~(uint64_t)3;
-            w[j] = *reinterpret_cast<const uint32_t *>(at);
-          }
+        for (int j = 0; j < U; j++) {
+          const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
+          g[j] = n < hi ? z[n] : -1;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int g = zr[j];
-          if (g < 0) continue;
-          const uint32_t raw = u8 ? (w[j] >> (((reinterpret_cast<uint64_t>(fd.col) + rr[j]) & 3u) * 8u)) & 0xffu : w[j];
+        for (int j = 0; j < U; j++) {
+          const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
+          const uint64_t row = row0 + (n < hi ? n : lo);           // (a row of the slice whatever this thread's share is)
+          w[j] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row] : reinterpret_cast<const uint32_t *>(fd.col)[row];
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          if ((uint32_t)g[j] >= K) continue;
+          const uint32_t gg = (uint32_t)g[j], raw = w[j];
           switch (fd.family) {
             case MSC_BBNC:
-            case MSC_BB: atomicAdd(&u32[(raw != 0 ? 0 : K) + g], 1u); break;
+            case MSC_BB: atomicAdd(&u32[(raw != 0 ? 0 : K) + gg], 1u); break;
             case MSC_GP:
-              atomicAdd(&u32[g], 1u);
-              atomicAdd(&u64[g], (unsigned long long)raw);
-              atomicAdd(&f64[g], log_factorial(raw));        // ln Gamma(v + 1)
+              atomicAdd(&u32[gg], 1u);
+              atomicAdd(&u64[gg], (unsigned long long)raw);
+              atomicAdd(&f64[gg], log_factorial(raw));        // ln Gamma(v + 1)
               break;
             case MSC_BNB:
-              atomicAdd(&u32[g], 1u);
-              atomicAdd(&u64[g], (unsigned long long)raw);
+              atomicAdd(&u32[gg], 1u);
+              atomicAdd(&u64[gg], (unsigned long long)raw);
               break;
             case MSC_DD: {
               const int v = (int)raw;
-              if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + g], 1u);
+              if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + gg], 1u);
             } break;
             default: {                                             // nich
               const double x = __uint_as_float(raw);
-              atomicAdd(&u32[g], 1u);
-              atomicAdd(&f64[g], x);
-              atomicAdd(&f64[K + g], x * x);
+              atomicAdd(&u32[gg], 1u);
+              atomicAdd(&f64[gg], x);
+              atomicAdd(&f64[K + gg], x * x);
             } break;
           }
         }
-      } else
-      for (uint64_t n = lo + threadIdx.x; n < hi; n += blockDim.x) {
-        const int g = z[n];
-        if (g < 0 || (uint32_t)g >= K) continue;
-        const uint64_t row = row0 + n;
-        if (fd.mask != nullptr) {                                    // masked value: not part of the group
-          bool m = false;
-          if (fd.family == MSC_DM) for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
-          else m = fd.mask[row] != 0;
-          if (m) continue;
-        }
-        switch (fd.family) {
-          case MSC_BBNC:
-          case MSC_BB: {
-            const bool v = reinterpret_cast<const uint8_t *>(fd.col)[row] != 0;
-            atomicAdd(&u32[(v ? 0 : K) + g], 1u);
-          } break;
-          case MSC_GP: {
-            const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-            atomicAdd(&u32[g], 1u);
-            atomicAdd(&u64[g], (unsigned long long)v);
-            atomicAdd(&f64[g], log_factorial(v));        // ln Gamma(v + 1)
-          } break;
-          case MSC_BNB: {
-            const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
-            atomicAdd(&u32[g], 1u);
-            atomicAdd(&u64[g], (unsigned long long)v);
-          } break;
-          case MSC_DM: {
-            const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
-            for (uint32_t i = 0; i < c_n; i++) {
-              const uint32_t v = (uint32_t)x[c_lo + i];
-              if (v) atomicAdd(&u64[(size_t)i * K + g], (unsigned long long)v);
-            }
-            if (sl == 0) atomicAdd(&f64[g], dm_row_ratio(fd.dim, x));
-          } break;
-          case MSC_DD: {
-            const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
-            if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + g], 1u);
-          } break;
-          case MSC_NICH: {
-            const double x = reinterpret_cast<const float *>(fd.col)[row];
-            atomicAdd(&u32[g], 1u);
-            atomicAdd(&f64[g], x);
-            atomicAdd(&f64[K + g], x * x);
-          } break;
-          default: break;
-        }
       }
-      __syncthreads();
-      // flush: row r of the pass maps to a row of the feature's additive tables
-      for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += blockDim.x) {
-        const uint32_t r = i / K, k = i - r * K;
-        if (!u32[i]) continue;
-        uint32_t dst_row = r;
-        if (fd.family == MSC_DD) dst_row = c_lo + r;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
-                  (unsigned long long)(sgn * (long long)u32[i]));
+    } else
+    for (uint64_t n = lo + threadIdx.x; n < hi; n += nt) {
+      const int g = z[n];
+      if (g < 0 || (uint32_t)g >= K) continue;
+      const uint64_t row = row0 + n;
+      if (fd.mask != nullptr) {                                    // masked value: not part of the group
+        bool m = false;
+        if (fd.family == MSC_DM) for (uint32_t e = 0; e < fd.dim; e++) m |= fd.mask[row * fd.dim + e] != 0;
+        else m = fd.mask[row] != 0;
+        if (m) continue;
       }
-      for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += blockDim.x) {
-        const uint32_t r = i / K, k = i - r * K;
-        if (!u64[i]) continue;
-        // gp, bnb: u64 row 0 is `sum`, additive row 1; dm: category c_lo + r
-        const uint32_t dst_row = fd.family == MSC_DM ? c_lo + r : 1 + r;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
-                  (unsigned long long)(sgn * (long long)u64[i]));
+      switch (fd.family) {
+        case MSC_BBNC:
+        case MSC_BB: {
+          const bool v = reinterpret_cast<const uint8_t *>(fd.col)[row] != 0;
+          atomicAdd(&u32[(v ? 0 : K) + g], 1u);
+        } break;
+        case MSC_GP: {
+          const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+          atomicAdd(&u32[g], 1u);
+          atomicAdd(&u64[g], (unsigned long long)v);
+          atomicAdd(&f64[g], log_factorial(v));        // ln Gamma(v + 1)
+        } break;
+        case MSC_BNB: {
+          const uint32_t v = reinterpret_cast<const uint32_t *>(fd.col)[row];
+          atomicAdd(&u32[g], 1u);
+          atomicAdd(&u64[g], (unsigned long long)v);
+        } break;
+        case MSC_DM: {
+          const int32_t *x = reinterpret_cast<const int32_t *>(fd.col) + row * fd.dim;
+          for (uint32_t i = 0; i < c_n; i++) {
+            const uint32_t v = (uint32_t)x[c_lo + i];
+            if (v) atomicAdd(&u64[(size_t)i * K + g], (unsigned long long)v);
+          }
+          if (sl == 0) atomicAdd(&f64[g], dm_row_ratio(fd.dim, x));
+        } break;
+        case MSC_DD: {
+          const int v = reinterpret_cast<const int32_t *>(fd.col)[row];
+          if (v >= (int)c_lo && v < (int)(c_lo + c_n)) atomicAdd(&u32[(size_t)(v - c_lo) * K + g], 1u);
+        } break;
+        case MSC_NICH: {
+          const double x = reinterpret_cast<const float *>(fd.col)[row];
+          atomicAdd(&u32[g], 1u);
+          atomicAdd(&f64[g], x);
+          atomicAdd(&f64[K + g], x * x);
+        } break;
+        default: break;
       }
-      for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += blockDim.x) {
-        const uint32_t r = i / K, k = i - r * K;
-        if (f64[i] != 0.0) atomicAdd(&fd.acc_f64[(size_t)r * kpad + k], (double)sign * f64[i]);
-      }
-      __syncthreads();
     }
+    __syncthreads();
+    // flush: row r of the pass maps to a row of the feature's additive tables
+    for (uint32_t i = threadIdx.x; i < K * sh.nu32; i += nt) {
+      const uint32_t r = i / K, k = i - r * K;
+      if (!u32[i]) continue;
+      uint32_t dst_row = r;
+      if (fd.family == MSC_DD) dst_row = c_lo + r;
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
+                (unsigned long long)(sgn * (long long)u32[i]));
+    }
+    for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += nt) {
+      const uint32_t r = i / K, k = i - r * K;
+      if (!u64[i]) continue;
+      // gp, bnb: u64 row 0 is `sum`, additive row 1; dm: category c_lo + r
+      const uint32_t dst_row = fd.family == MSC_DM ? c_lo + r : 1 + r;
+      atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
+                (unsigned long long)(sgn * (long long)u64[i]));
+    }
+    for (uint32_t i = threadIdx.x; i < K * sh.nf64; i += nt) {
+      const uint32_t r = i / K, k = i - r * K;
+      if (f64[i] != 0.0) atomicAdd(&fd.acc_f64[(size_t)r * kpad + k], (double)sign * f64[i]);
+    }
+    __syncthreads();
   }
 }
 
@@ -617,19 +618,25 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
   if (first_use_on_device(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  uint64_t blocks = (nrows + 4095) / 4096;          // >= 4 rows per thread
-  if (blocks < (uint64_t)num_cus) {                 // too few rows to fill the chip that way: down to 1 row per thread
-    const uint64_t per = std::max<uint64_t>(1024, (nrows + num_cus - 1) / num_cus);
-    blocks = (nrows + per - 1) / per;
+  // a workgroup per (feature, slice of rows): ~8 workgroups per CU in all, a slice never shorter than 4096 rows (fewer
+  // when that would leave most of the chip idle) -- C3: 65 x 31 workgroups of 32k rows, C2: 2 x 245 of 4096.
+  // MSC_ACC_WGS_PER_CU: tuning knob
+  static const int wgs_per_cu = std::getenv("MSC_ACC_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MSC_ACC_WGS_PER_CU"))) : 8;
+  const uint64_t nf1 = (uint64_t)nfeat + 1;
+  uint64_t slices = std::max<uint64_t>(1, ((uint64_t)num_cus * wgs_per_cu + nf1 - 1) / nf1);
+  uint64_t per = std::max<uint64_t>((nrows + slices - 1) / slices, 4096);
+  if ((nrows + per - 1) / per * nf1 < (uint64_t)num_cus)                  // few rows: spread them, down to 1024 per workgroup
+    per = std::max<uint64_t>(1024, (nrows * nf1 + num_cus - 1) / num_cus);
+  slices = std::max<uint64_t>(1, (nrows + per - 1) / per);
+  if (slices > 65535) {
+    slices = 65535;
+    per = (nrows + slices - 1) / slices;
   }
-  const uint64_t cap = (uint64_t)num_cus * 2;
-  if (blocks > cap) blocks = cap;
-  if (blocks == 0) blocks = 1;
-  // features side by side only while the whole grid is one round of workgroups; beyond that walking them in the
-  // block measured faster (C3: 0.41 ms against 0.94 ms)
-  const unsigned gy = blocks * ((uint64_t)nfeat + 1) <= 2 * (uint64_t)num_cus ? (unsigned)nfeat + 1 : 1u;
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)blocks, gy), dim3(1024), lds, stream, feats_dev, nfeat, K,
-                     kpad, row0, nrows, z, sign, cnt_acc, dd_slice);
+  // small histograms: 256-thread workgroups, several per CU; large ones (many groups) keep 1024 threads to zero and
+  // flush their bins
+  const unsigned threads = lds <= 40u * 1024u ? 256u : 1024u;
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)nf1, (unsigned)slices), dim3(threads), lds, stream, feats_dev, nfeat, K,
+                     kpad, row0, nrows, z, sign, cnt_acc, dd_slice, per);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

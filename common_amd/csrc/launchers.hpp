@@ -48,7 +48,7 @@ int launch_entity_op(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, u
                      uint32_t group, int sign, long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, int32_t *z_slot);
 int launch_set_i32(hipStream_t stream, int32_t *dst, int32_t value);
 int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
-int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
+int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, bool staged, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
                         uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, float *out, uint64_t ld);

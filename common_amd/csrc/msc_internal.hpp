@@ -119,7 +119,16 @@ struct FeatDesc {
   double *loo64;              // nich: per-group constants of the leave-one-out pass, [kpad][kNlooStride] (family_math.hpp)
   float *loo_tab;             // bb, gp, bnb, dd: score of value v against the group with one such value removed,
                               // [v][kpad] (k_prepare); the leave-one-out pass is a lookup for these families
+  // the leave-one-out pass's own stage plan (abi.cpp plan_groups; k_loo_own_lds): consecutive features of the tile plan
+  // whose leave-one-out blocks share the kernel's LDS slot
+  uint32_t loo_off;           // first float of this feature's block inside the slot
+  uint32_t loo_rows;          // rows of kpad floats staged (lookup kinds: run_clamp + 1 table rows; nich: 12 = 6 doubles
+                              // per group, group-major); 0 = not staged: the feature reads global memory
+  uint32_t loo_stage_end;     // one past the last feature of this feature's stage
+  uint32_t pad1;
 };
+constexpr uint32_t kLooSlotFloats = 16384;   // 64 KiB: two workgroups of k_loo_own_lds per CU
+constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
 enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 
 // families whose score is a lookup of the row's count in an exact per-group table
@@ -138,9 +147,9 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
     default: return 0;
   }
 }
-// (nich: kNlooStride doubles per group, group-major -- a row's leave-one-out pass reads ONE group's eleven constants: side
-// by side they are two cache lines, a table row apiece they were eleven)
-constexpr uint32_t kNlooStride = 12;
+// (nich: kNlooStride doubles per group, group-major -- a row's leave-one-out pass reads ONE group's six constants: side
+// by side they are 48 bytes, one cache line mostly; family_math.hpp NLOO_*)
+constexpr uint32_t kNlooStride = 6;
 inline uint32_t loo_rows(int family) { return family == MSC_NICH ? kNlooStride : 0u; }
 inline uint32_t loo_tab_rows(int family, uint32_t dim) {
   return family == MSC_BB ? 2u : (family == MSC_GP || family == MSC_BNB) ? kGpMaxTable : family == MSC_DD ? dim : 0u;
@@ -331,6 +340,7 @@ struct msc_state {
   float *scratch = nullptr;       // score chunk for the generic sweep path
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
+  uint32_t loo_staged = 0;        // plan_groups: features whose leave-one-out block k_loo_own_lds stages in LDS
   float *rows_table = nullptr;    // k_sweep_nich1_rows: per-group constants as scalar operands (single nich, K > 1024)
   size_t own_cap = 0;
   uint32_t *colmax_dev = nullptr;
