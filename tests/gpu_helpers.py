@@ -7,6 +7,34 @@ from oracle import oracle as orc
 TOL = 1e-6  # north_star: float log-scores within 1e-6 relative of the double evaluation
 
 
+_AUDIT = {}
+
+
+def audit(name, err, gate):
+    """every gate that is not the plain TOL goes through here: the largest error seen per gate is kept and, with
+    MSC_TOL_AUDIT=<file> in the environment, written out when the session ends (profiles/r03_tolerance_audit.json is
+    such a run) -- a gate is a budget with a reason, and this is the evidence it is held against"""
+    err = float(err)
+    rec = _AUDIT.setdefault(name, {"max_err": 0.0, "gate": float(gate), "checks": 0})
+    rec["max_err"] = max(rec["max_err"], err)
+    rec["gate"] = max(rec["gate"], float(gate))
+    rec["checks"] += 1
+    assert err <= gate, (name, err, gate)
+
+
+def _dump_audit():
+    import json
+    import os
+    path = os.environ.get("MSC_TOL_AUDIT")
+    if path and _AUDIT:
+        with open(path, "w") as fh:
+            json.dump(_AUDIT, fh, indent=1, sort_keys=True)
+
+
+import atexit  # noqa: E402
+atexit.register(_dump_audit)
+
+
 def rel_err(got, want):
     """|got - want| / max(1, |want|): relative for |score| >= 1, absolute below."""
     got = np.asarray(got, dtype=np.float64)
