@@ -414,6 +414,16 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
       double qp[JB];
 #pragma unroll
       for (int jb = 0; jb < JB; jb++) qp[jb] = 0.0;
+      // Beyond dim 32 the group's operand stream is NB (NB + 1) / 2 chunks of 2 KiB; left to itself the compiler hoists
+      // every chunk's load to the top of the group (80 registers of operands at dim 64, 288 at dim 128) and the kernel
+      // runs one wave per SIMD.  PIPE: chunk c + 1 is fetched when chunk c starts to multiply and a scheduling
+      // barrier after every chunk keeps it at that -- two chunks of operands live, whatever the dimension.
+      constexpr bool PIPE = NB > 2;
+      double2 n01 = {0.0, 0.0}, n23 = {0.0, 0.0};
+      if (PIPE) {
+        n01 = *reinterpret_cast<const double2 *>(Wk);
+        n23 = *reinterpret_cast<const double2 *>(Wk + 2);
+      }
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         const double2 b01 = *reinterpret_cast<const double2 *>(Bk + b * 256), b23 = *reinterpret_cast<const double2 *>(Bk + b * 256 + 2);
@@ -422,8 +432,21 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
         for (int jb = 0; jb < JB; jb++) acc[jb] = f64x4{-b01.x, -b01.y, -b23.x, -b23.y};   // W x - W mu
 #pragma unroll
         for (int s4 = 0; s4 <= b; s4++) {
-          const double *wc = Wk + (b * (b + 1) / 2 + s4) * 256;
-          const double2 a01 = *reinterpret_cast<const double2 *>(wc), a23 = *reinterpret_cast<const double2 *>(wc + 2);
+          constexpr int kLast = NCH - 1;
+          const int ch = b * (b + 1) / 2 + s4;
+          const double *wc = Wk + ch * 256;
+          double2 a01, a23;
+          if (PIPE) {
+            a01 = n01;
+            a23 = n23;
+            if (ch < kLast) {
+              n01 = *reinterpret_cast<const double2 *>(wc + 256);
+              n23 = *reinterpret_cast<const double2 *>(wc + 256 + 2);
+            }
+          } else {
+            a01 = *reinterpret_cast<const double2 *>(wc);
+            a23 = *reinterpret_cast<const double2 *>(wc + 2);
+          }
           const double a[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
               acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], (double)xv, acc[jb], 0, 0, 0);
             }
           }
+          if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int jb = 0; jb < JB; jb++)
@@ -782,7 +806,16 @@ int launch_niw_score_data(hipStream_t stream, const FeatDesc *feats_dev, uint32_
 template <int NB, bool LOO, bool ACCUM>
 static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc *feats_dev, uint32_t f, uint32_t K, uint32_t kpad,
                             uint64_t row0, uint64_t nrows, const int32_t *z, double *qown, float *out, uint64_t ld) {
-  hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), grid, dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  // Row blocks of 16 per wave: four up to dim 32 (C4: 179 + 64 registers, two waves per SIMD, 0.88 of the f64 matrix
+  // peak), two beyond -- with four the wave's features, sums and epilogue take 290-512 registers and the kernel runs one
+  // wave per SIMD: dim 64 4.94 ms; with two (and the operand stream pipelined, PIPE in the kernel) 3.06 ms, three
+  // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).  MSC_NIW_JB = 2 | 4 forces one (tuning knob).
+  static const int forced = std::getenv("MSC_NIW_JB") ? std::atoi(std::getenv("MSC_NIW_JB")) : 0;
+  const int jb = forced == 2 || forced == 4 ? forced : (NB > 2 ? 2 : 4);
+  if (jb == 2)
+    hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), dim3(grid.x * 2), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else
+    hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), grid, dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
 }
 template <bool LOO, bool ACCUM>
 static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, uint32_t dim, const FeatDesc *feats_dev,
