@@ -376,6 +376,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     warmup_run = max(a.warmup, 200)
     for _ in range(warmup_run):
         st.score_value(view, out=out)
+    launched = 1 + warmup_run + (7 * 8 if a.tune else 0)        # launches of the headline kernel so far (for the trace summary)
 
     def region(buf, steps):
         """HIP events over the timed region, on the stream the library launches on: ONE pair around the launches (a
@@ -397,6 +398,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         # a 3 ms region is a handful of clock ticks of the driver's sampling: the line reports a region of >= 200 steps
         # (and what the short one read, for the record)
         short_region = {"steps": a.steps, "ms_per_step": dt / a.steps * 1e3, "kernel_avg_ms": kern_avg_ms}
+        launched += a.steps
         a.steps = max(200, int(a.min_region_ms / (dt / a.steps * 1e3)) + 1)
         dt, kern_avg_ms = region(out, a.steps)
     # (per-launch spread, outside the timed region)
@@ -442,6 +444,8 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                      "traffic": traffic if (N, K) == (1_000_000, 256) else None,
                      "traffic_source": traffic_src,
                      "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
+                     "timed_region_launches": [launched, launched + a.steps],      # of this kernel, in launch order
+
                      "kernel_min_ms_single_launch_events": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes,
                      "out_va": "%#x" % out.data_ptr()},
     }

@@ -42,6 +42,18 @@ def main():
     # the timed loop): its average is the one bench.py's HIP events must agree with
     traces = glob.glob(os.path.join(ktdir, "**", "*_kernel_trace.csv"), recursive=True)
     timed_steps = int(os.environ.get("MSC_TIMED_STEPS", "500"))
+    # bench.py says which launches of its headline kernel were the timed region (roofline.timed_region_launches); its line
+    # is in the log beside the trace (tools/profile_round.sh: kt.log)
+    region, headline = None, None
+    log = os.path.join(out, "kt.log")
+    if os.path.exists(log):
+        for ln in open(log):
+            if ln.startswith("{"):
+                try:
+                    roof = json.loads(ln).get("roofline", {})
+                    region, headline = roof.get("timed_region_launches"), roof.get("kernel")
+                except ValueError:
+                    pass
     if traces:
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(traces[0])):
@@ -55,6 +67,10 @@ def main():
                 last = d[-timed_steps:]
                 fh.write("%-60s launches %5d avg %10.1f | last %4d: avg %10.1f min %9d max %9d\n"
                          % (k[:60], len(d), sum(d) / len(d), len(last), sum(last) / len(last), min(last), max(last)))
+                if region and headline and headline in k and len(d) >= region[1]:
+                    r = d[region[0]:region[1]]
+                    fh.write("    bench.py's timed region = launches [%d, %d) of this kernel: avg %10.1f min %9d max %9d\n"
+                             % (region[0], region[1], sum(r) / len(r), min(r), max(r)))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sys.argv[3:]:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
