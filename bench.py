@@ -144,7 +144,13 @@ def spawn_ranks(a):
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+    # the ranks' stdout is relayed: the JSON line to our stdout, anything else a library prints there (gloo's connection
+    # notices) to stderr -- the driver reads ONE line
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    for ln in p.stdout:
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return p.wait()
 
 
 def main():
