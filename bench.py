@@ -183,7 +183,13 @@ def main():
                   "launch them" % (a.gpus, world, a.gpus, a.gpus), file=sys.stderr)
         sys.exit(2)
     one_rank = None
+    stdout_fd = None
     if world > 1 or force_c5:
+        # the collective library announces itself on STDOUT when its communicator is created (RCCL: five lines of
+        # versions; gloo: its connection notices): file descriptor 1 points at stderr until the JSON line is due
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knob for a 1-GPU box: MSC_BENCH_BACKEND=gloo puts every rank on cuda:0
         backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
@@ -212,9 +218,14 @@ def main():
         line = run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_rank)
     else:
         line = run_c2(a, torch, dist, common_amd, ctx, sync_all)
+    if stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1 or force_c5:
+        os.dup2(2, 1)                                       # (whatever the teardown prints is not the line)
         dist.barrier()
         dist.destroy_process_group()
 
