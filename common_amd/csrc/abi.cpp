@@ -1667,11 +1667,13 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;
-    // 256 MiB of scores per chunk: measured on K = 300 .. 5000 (32 / 64 / 128 / 256 / 512 MiB: 1.88 / 1.55 / 1.28 /
-    // 1.13 / 1.05 ms for 1M rows x 300 groups), fewer and larger launches beat keeping the chunk cache-resident,
-    // and a state with niw features wants >= 4 waves per SIMD on its MFMA kernel anyway
+    // Up to 4 GiB of scores per chunk (288 GB of HBM: the scratch is not what runs out): fewer and larger launches beat
+    // keeping the chunk cache-resident (single nich, 1M rows x 300 groups, 32 / 64 / 128 / 256 / 512 MiB: 1.88 / 1.55 /
+    // 1.28 / 1.13 / 1.05 ms), a state with niw features wants >= 4 waves per SIMD on its MFMA kernel, and the
+    // leave-one-out pass takes its staged kernel only when the rows fill the chip -- C3's columns at K = 512, 1M rows:
+    // 5.39 ms a sweep step with 256 MiB chunks (eight of them), 4.95 with 1 GiB, 4.63 with the whole 2 GiB at once
     static const uint64_t forced_mib = std::getenv("MSC_SWEEP_CHUNK_MIB") ? std::strtoull(std::getenv("MSC_SWEEP_CHUNK_MIB"), nullptr, 10) : 0;
-    uint64_t chunk = ((forced_mib ? forced_mib : 256ull) << 20) / (ld * sizeof(float));
+    uint64_t chunk = ((forced_mib ? forced_mib : 4096ull) << 20) / (ld * sizeof(float));
     if (chunk == 0) chunk = 1;
     if (chunk > nrows) chunk = nrows;
     if (st->scratch_floats < chunk * ld) {

@@ -907,11 +907,13 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
 
 int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, bool staged, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                    uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *crp, float *own) {
-  (void)num_cus;
-  // staged: the plan has features whose leave-one-out blocks fit the LDS slot (abi.cpp plan_groups).  Worth the block
-  // copies from a few tens of thousands of rows on (a workgroup copies every block once for its 2048 rows)
-  static const int lds_mode = std::getenv("MSC_LOO_LDS") ? std::atoi(std::getenv("MSC_LOO_LDS")) : -1;   // 0 / 1: A/B knob
-  const bool use_lds = staged && (lds_mode < 0 ? nrows >= 32768 : lds_mode != 0);
+  // staged: the plan has features whose leave-one-out blocks fit the LDS slot (abi.cpp plan_groups).  A workgroup of the
+  // staged kernel takes as long for its 2048 rows as the plan has stages (~8 us each) however many workgroups run, so it
+  // pays once the rows fill the chip -- one workgroup per CU; below that the gather kernel's time falls with the rows
+  // (a 131k-row chunk of the materialising sweep: 64 workgroups, 0.33 ms staged against 0.06 ms gathered)
+  const char *knob = std::getenv("MSC_LOO_LDS");            // 0 / 1: A/B knob, read per call (the tests pin either kernel)
+  const int lds_mode = knob ? std::atoi(knob) : -1;
+  const bool use_lds = staged && (lds_mode < 0 ? nrows >= (uint64_t)kLooRows * kLooThreads * (uint64_t)num_cus : lds_mode != 0);
   if (use_lds) {
     static unsigned long long attr_devices = 0;
     if (first_use_on_device(attr_devices)) {

@@ -324,3 +324,36 @@ def test_wave_role_kernels_on_random_feature_lists(gpu_ctx, seed):
         assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
         assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True),
                            st.score_value(view, z=zt, crp_prior=True)[row0:row0 + n])
+
+
+@pytest.mark.parametrize("K", [60, 256, 400])
+def test_both_leave_one_out_kernels_give_a_row_the_same_bits(gpu_ctx, monkeypatch, K):
+    """k_loo_own (a gather per entry) and k_loo_own_lds (the plan's stages through LDS; taken from one workgroup per CU
+    on) feed the same `own` value into the score and sweep kernels: same terms, same order of the double sum, so the
+    leave-one-out + prior scores must be equal bit for bit -- a shard of any size reproduces the unsharded pass -- and
+    within the gate of the oracle.  Mixed features incl. a masked column and a dd wider than the staged rows."""
+    import common_amd
+    rng = np.random.default_rng(K)
+    N = 30_000
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BB, 0), (orc.DD, 40), (orc.BNB, 0),
+             (orc.NICH, 0), (orc.BBNC, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[::17] = -1
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z[z >= 0], minlength=K).astype(np.uint32))
+    st.set_alpha(1.3)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    monkeypatch.setenv("MSC_LOO_LDS", "0")
+    gathered = st.score_value(view, z=zt, crp_prior=True).clone()
+    monkeypatch.setenv("MSC_LOO_LDS", "1")
+    staged = st.score_value(view, z=zt, crp_prior=True).clone()
+    assert torch.equal(gathered, staged)
+    rows = rng.choice(N, 300, replace=False)
+    want = oracle_scores(feats, fs, z=z, rows=rows) + crp_prior_matrix(np.bincount(z[z >= 0], minlength=K), 1.3, z[rows])
+    lik = oracle_scores(feats, fs, z=z, rows=rows)
+    got = staged.cpu().numpy()[rows]
+    assert (np.abs(got - want) / np.maximum(1.0, np.maximum(np.abs(want), np.abs(lik)))).max() <= TOL
