@@ -395,13 +395,13 @@ __global__ __launch_bounds__(256) void k_loo_own(const FeatDesc *__restrict__ fe
 // The same pass for many rows: what a row gathers per feature comes from LDS.  In k_loo_own every lane of a wave reads
 // its own group's entry -- 64 cache lines per wave instruction, two of them per nich feature and row (96 bytes of
 // constants) -- and the kernel ran at the rate the address unit splits such gathers, 0.25 ms for C3's 64 columns
-// (0.97 TB/s of 64-byte sectors for 4 + 4 useful bytes).  Here a workgroup of 512 threads takes 2048 rows (four per
+// (0.97 TB/s of 64-byte sectors for 4 + 4 useful bytes).  Here a workgroup of 1024 threads takes 4096 rows (four per
 // thread, coalesced) through the stages of the leave-one-out plan (abi.cpp plan_groups: consecutive features whose
-// blocks -- the lookup families' leave-one-out tables, nich's twelve doubles per group, for all kpad groups -- share the
-// 64 KiB slot): the block copy is coalesced, the per-row reads are LDS reads at the lane's own address, and two
-// workgroups per CU cover each other's copies.  Same terms, same order of the double sum as k_loo_own: same bits.
+// blocks -- the lookup families' leave-one-out tables, nich's six doubles per group, for all kpad groups -- share the
+// 128 KiB slot): the block copy is coalesced, the per-row reads are LDS reads at the lane's own address.  (Two workgroups
+// of 512 threads with 64 KiB each, covering each other's copies: 149 us on C3 against 140 -- twice the stages.)  Same terms, same order of the double sum as k_loo_own: same bits.
 // ---------------------------------------------------------------------------
-constexpr int kLooRows = 4, kLooThreads = 512;      // (kLooStageFeats: msc_internal.hpp)
+constexpr int kLooRows = 4, kLooThreads = 1024;      // (kLooStageFeats: msc_internal.hpp)
 template <bool HEAVY>
 __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__restrict__ feats,
                                                               int nfeat, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
@@ -908,17 +908,18 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
 int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, bool staged, const FeatDesc *feats_dev, int nfeat, uint32_t K,
                    uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, const float *crp, float *own) {
   // staged: the plan has features whose leave-one-out blocks fit the LDS slot (abi.cpp plan_groups).  A workgroup of the
-  // staged kernel takes as long for its 2048 rows as the plan has stages (~8 us each) however many workgroups run, so it
-  // pays once the rows fill the chip -- one workgroup per CU; below that the gather kernel's time falls with the rows
-  // (a 131k-row chunk of the materialising sweep: 64 workgroups, 0.33 ms staged against 0.06 ms gathered)
+  // staged kernel takes as long for its 4096 rows as the plan has stages (~10 us each) however many workgroups run, so it
+  // pays once the rows (nearly) fill the chip -- C3, 1M rows: 140 us staged, 196 us gathered; below about three quarters
+  // of a workgroup per CU the gather kernel's time, which falls with the rows, is the shorter one (a 131k-row chunk:
+  // 0.33 ms staged against 0.03 ms gathered)
   const char *knob = std::getenv("MSC_LOO_LDS");            // 0 / 1: A/B knob, read per call (the tests pin either kernel)
   const int lds_mode = knob ? std::atoi(knob) : -1;
-  const bool use_lds = staged && (lds_mode < 0 ? nrows >= (uint64_t)kLooRows * kLooThreads * (uint64_t)num_cus : lds_mode != 0);
+  const bool use_lds = staged && (lds_mode < 0 ? nrows >= (uint64_t)kLooRows * kLooThreads * (uint64_t)num_cus * 3 / 4 : lds_mode != 0);
   if (use_lds) {
     static unsigned long long attr_devices = 0;
     if (first_use_on_device(attr_devices)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLooSlotFloats * 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_loo_own_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLooSlotFloats * 4);
     }
     const unsigned blocks = (unsigned)((nrows + kLooRows * kLooThreads - 1) / (kLooRows * kLooThreads));
     if (heavy)

@@ -127,7 +127,7 @@ struct FeatDesc {
   uint32_t loo_stage_end;     // one past the last feature of this feature's stage
   uint32_t pad1;
 };
-constexpr uint32_t kLooSlotFloats = 16384;   // 64 KiB: two workgroups of k_loo_own_lds per CU
+constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
 enum { MSC_KIND_GENERIC = 0, MSC_KIND_LOOKUP_U8 = 1, MSC_KIND_LOOKUP_U32 = 2, MSC_KIND_LOOKUP_I32 = 3 };
 
