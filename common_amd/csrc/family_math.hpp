@@ -308,6 +308,18 @@ MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1l
   log1p_parts(a * a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
 }
+// The tile kernels' second phase sums the nich features of a row WITHOUT a separate addition per evaluation: the
+// accumulator starts at the sum of the features' c0 (a constant of the group: nich_c0_sum) and every evaluation is the two
+// fused multiply-adds below on it -- 9 plain + 2 transcendental instructions where `acc += nich_eval(...)` is 10 + 2, and
+// the nich phase runs at the issue rate of exactly that mix.  Same mathematics, another
+// association of the float sum: every tile kernel uses this form for its plain (unmasked) nich features.
+MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c1ln2, float c1, float s) {
+#pragma clang fp contract(off)
+  const float a = fmaf(x, s, -smu_hi) - smu_lo;
+  float l2, r;
+  log1p_parts(a * a, l2, r);
+  return fmaf(-c1, r, fmaf(-c1ln2, l2, acc));
+}
 // The sweep kernels' form, in log2 units: c0' - c1 log2(1 + t), with log2(1 + t) = log2(u) + log2e (t - (u - 1)) / u
 // assembled first -- the same accuracy (the product with c1 rounds at the term's own size either way) with one
 // per-group constant fewer to keep in registers than nich_eval's two factors.

@@ -360,10 +360,23 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
 
 // second phase: the unmasked nich features (the host puts them last, abi.cpp plan_groups), group by group,
 // in a loop that holds nothing else
+// the sum of c0 over the second phase's features, for this lane's four groups: what the phase's accumulators start from
+// (family_math.hpp nich_accum); read from the tables in L2, once per chunk
+MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb) {
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int f = f0; f < nfeat; f++) add4(s, ld4(feats[f].tab + (size_t)NICH_C0 * kpad + kb));
+  return s;
+}
+// (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
 template <int R, int W>
 MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t ktile,
                                   int lane, int wave, uint64_t myrow, bool has_row, float4 *__restrict__ lds,
                                   float4 (&acc)[R]) {
+  {
+    const float4 c0s = nich_c0_sum(feats, f0, nfeat, kpad, ktile * kGroupTile + lane * 4);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = c0s;
+  }
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].grp_end;
     stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
@@ -373,15 +386,15 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
       const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
       const float xv = xv_next;                          // (fetched one feature ahead, as in the lookup runs)
       if (f + 1 < f1) xv_next = has_row ? reinterpret_cast<const float *>(feats[f + 1].col)[myrow] : 0.f;
-      const float4 mh = buf[NICH_MU_HI * 64], ml = buf[NICH_MU_LO * 64], c0 = buf[NICH_C0 * 64],
+      const float4 mh = buf[NICH_MU_HI * 64], ml = buf[NICH_MU_LO * 64],
                    c1l = buf[NICH_C1LN2 * 64], c1 = buf[NICH_C1 * 64], c2 = buf[NICH_C2 * 64];
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const float x = lane_bcast(xv, r);
-        acc[r].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-        acc[r].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-        acc[r].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-        acc[r].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
+        acc[r].x = nich_accum(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+        acc[r].y = nich_accum(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+        acc[r].z = nich_accum(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+        acc[r].w = nich_accum(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
       }
     }
     f0 = f1;
@@ -507,12 +520,11 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nspli
   score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, row_safe, lds, acc);
   if (nsplit < nfeat) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (!SPLIT || nsplit == 0) {
+    static_assert(SPLIT, "the second phase is always summed on its own (score_tile_nich_tail sets its accumulators)");
+    if (nsplit == 0) {                                    // (the caller passed zeros and adds the prior afterwards)
       score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
     } else {
       float4 accn[R];
-#pragma unroll
-      for (int r = 0; r < R; r++) accn[r] = make_float4(0, 0, 0, 0);
       score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, accn);
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], accn[r]);
