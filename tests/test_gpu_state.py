@@ -314,3 +314,73 @@ def test_entity_op_keeps_every_table_current(gpu_ctx):
         audit("state.entity_op_scores." + name, (np.abs(sc - total) / np.maximum(mag, np.abs(total))).max(), TOL)
     with pytest.raises(common_amd.MicroscopesHipError):
         st.entity_op(view, 0, K, join=True)                       # no such group
+
+
+def test_entity_op_preconditions_are_checked_on_the_device(gpu_ctx):
+    """msc_entity_op's preconditions (the reference asserts them in group_manager::add_value / remove_value,
+    group_manager.hpp:218-248): a leave needs a non-empty group that the row is in, a join an unassigned row.  The kernel
+    that notices skips the update it concerns and reports through the device's error word: the next synchronising or
+    launching call returns MSC_EDEVICE (-6), once; and the call is refused outright between msc_sweep_step_begin and
+    msc_state_commit_reduce."""
+    import common_amd
+    rng = np.random.default_rng(3)
+    N, K = 64, 5
+    specs = [(orc.BB, 0), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    zt = torch.full((N,), -1, dtype=torch.int32, device=gpu_ctx.torch_device)
+    st.entity_op(view, 0, 2, join=True, z=zt)
+    st.entity_op(view, 1, 2, join=True, z=zt)
+    gpu_ctx.synchronize()                                         # nothing to report
+    assert st.get_group_counts()[2] == 2 and zt[:2].tolist() == [2, 2]
+
+    def expect_device_error(what):
+        with pytest.raises(common_amd.MicroscopesHipError) as ei:
+            gpu_ctx.synchronize()
+        assert ei.value.code == -6 and "msc_entity_op" in str(ei.value), what
+        gpu_ctx.synchronize()                                     # reported once
+
+    st.entity_op(view, 5, 3, join=False, z=zt)                    # row 5 is not in group 3 (which is empty)
+    expect_device_error("leave from an empty group")
+    st.entity_op(view, 0, 4, join=False, z=zt)                    # row 0 is in group 2, not 4
+    expect_device_error("leave from another group")
+    st.entity_op(view, 1, 3, join=True, z=zt)                     # row 1 is already assigned
+    expect_device_error("join of an assigned row")
+    # the group sizes and the assignment vector were left alone by the refused moves
+    assert st.get_group_counts().tolist() == [0, 0, 2, 0, 0] and zt[:2].tolist() == [2, 2]
+    # the tables of a state that saw a refused move are to be rebuilt; after that everything works on
+    st.accumulate(view, zt)
+    st.entity_op(view, 0, 2, join=False, z=zt)
+    gpu_ctx.synchronize()
+    assert st.get_group_counts()[2] == 1 and int(zt[0]) == -1
+    # between the sharded step's two halves the additive tables hold uncommitted sums: refused on the host
+    st.set_alpha(1.0)
+    z2 = torch.zeros(N, dtype=torch.int32, device=gpu_ctx.torch_device)
+    st.accumulate(view, z2)
+    st.sweep_step_begin(view, z2, seed=1, sweep=0)
+    with pytest.raises(common_amd.MicroscopesHipError):
+        st.entity_op(view, 0, 0, join=False, z=z2)
+    st.commit_reduce()
+    st.entity_op(view, 0, int(z2[0]), join=False, z=z2)
+    gpu_ctx.synchronize()
+
+
+def test_default_allocator_places_large_buffers(gpu_ctx):
+    """msc_device_alloc from 64 MiB on: a probed, chunk-mapped buffer (msc_device_alloc_stats says what was tried), zero
+    filled, usable as a score matrix, freed with the tensor; below that a plain allocation"""
+    import common_amd
+    t = gpu_ctx.alloc((300_000, 64), torch.float32)               # 76.8 MB
+    rates, kept = gpu_ctx.alloc_stats()
+    assert 1 <= len(rates) <= 6 and 0 <= kept < len(rates) and all(r > 100.0 for r in rates)
+    assert rates[kept] == max(rates) and float(t.abs().sum()) == 0.0
+    small = gpu_ctx.alloc((1000,), torch.float32)
+    assert float(small.sum()) == 0.0
+    st = common_amd.State(gpu_ctx, [(orc.NICH, 0)], 64)
+    x = torch.randn(300_000, device=gpu_ctx.torch_device)
+    view = common_amd.DataView.from_tensors(gpu_ctx, [x])
+    st.score_value(view, out=t)
+    assert bool(torch.isfinite(t).all()) and float(t.abs().sum()) > 0.0
+    with pytest.raises(RuntimeError):
+        gpu_ctx.close()                                           # live buffers: refused
+    del t, small
