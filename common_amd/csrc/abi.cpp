@@ -639,15 +639,24 @@ static void plan_groups(msc_state *st) {
   for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
   st->tile_split = (uint32_t)t.size();
   for (const FeatDesc &d : st->desc_host) if (nich_tail(d)) t.push_back(d);
+  // masked lookup columns: the tile plan reads the copy with the mask folded in (bind_view) and sees no mask -- a masked
+  // value selects the table's zero row, which the feature stages with the others (one more row: `extra`)
+  std::vector<uint32_t> extra(t.size(), 0u);
+  for (size_t i = 0; i < t.size(); i++)
+    if (t[i].mask != nullptr && t[i].col_sentinel != nullptr) {
+      t[i].col = t[i].col_sentinel;
+      t[i].mask = nullptr;
+      extra[i] = 1;
+    }
   const uint32_t n = st->nfeat, split = st->tile_split;
   uint32_t f = 0;
   while (f < n) {
     const uint32_t limit = f < split ? split : n;
     uint32_t used = 0, g = f;
-    while (g < limit && used + rows_of(t[g]) <= (uint32_t)kGrpRows) {
+    while (g < limit && used + rows_of(t[g]) + extra[g] <= (uint32_t)kGrpRows) {
       t[g].grp_off = used;
-      t[g].grp_rows = rows_of(t[g]);
-      used += rows_of(t[g]);
+      t[g].grp_rows = rows_of(t[g]) + extra[g];
+      used += t[g].grp_rows;
       g++;
     }
     for (uint32_t i = f; i < g; i++) t[i].grp_end = g;
@@ -659,9 +668,10 @@ static void plan_groups(msc_state *st) {
     FeatDesc &d = t[i];
     d.kind = MSC_KIND_GENERIC;
     if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
-    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = 1;
-    else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap) d.kind = MSC_KIND_LOOKUP_U32, d.run_clamp = d.grp_rows - 1;
-    else if (d.family == MSC_DD && d.grp_rows >= d.dim) d.kind = MSC_KIND_LOOKUP_I32, d.run_clamp = d.dim - 1;
+    // (run_clamp: the largest row a value may select -- with the mask folded in that is the zero row)
+    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = 1 + extra[i];
+    else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap + extra[i]) d.kind = MSC_KIND_LOOKUP_U32, d.run_clamp = d.grp_rows - 1;
+    else if (d.family == MSC_DD && d.grp_rows >= d.dim + extra[i]) d.kind = MSC_KIND_LOOKUP_I32, d.run_clamp = d.dim - 1 + extra[i];
   }
   bool has_dm = false;
   st->tile_roles_ok = split > 0 && split < n;
@@ -1076,6 +1086,27 @@ static int column_as(const msc_dataview *view, uint32_t c, int want, bool make, 
   return MSC_OK;
 }
 
+// A masked lookup column with the mask folded in (FeatDesc::col_sentinel): masked rows hold `sentinel`.  `col` is the
+// column as the model's value type (column_as); made once per (column, element type, sentinel), kept with the view.
+static int sentinel_column(const msc_dataview *view, uint32_t c, const void *col, bool bytes, uint32_t sentinel, const void **out) {
+  *out = nullptr;
+  if (view->sentinels.size() < view->cols.size()) view->sentinels.resize(view->cols.size());
+  const std::pair<int, uint32_t> key(bytes ? 1 : 4, sentinel);
+  for (const auto &e : view->sentinels[c])
+    if (e.first == key) {
+      *out = e.second;
+      return MSC_OK;
+    }
+  void *dst = nullptr;
+  MSC_HIP(hipMalloc(&dst, std::max<size_t>(1, (size_t)view->nrows * (bytes ? 1 : 4))));
+  view->owned_lazy.push_back(dst);
+  if (launch_mask_sentinel(view->ctx->stream, col, static_cast<const uint8_t *>(view->masks[c]), view->nrows, bytes, sentinel, dst))
+    return fail(MSC_EHIP, "k_mask_sentinel launch failed");
+  view->sentinels[c].emplace_back(key, dst);
+  *out = dst;
+  return MSC_OK;
+}
+
 static int bind_dm_column(msc_state *st, uint32_t f, const msc_dataview *view, uint32_t c) {
   msc_feature_host &h = st->feats[f];
   FeatDesc &d = st->desc_host[f];
@@ -1190,6 +1221,22 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
       }
     }
     if (h.family == MSC_DM) MSC_TRY(bind_dm_column(st, f, view, c));
+    // a masked column of a lookup family, for the tile kernels: the mask folded in as the index of the family's zero
+    // table row, while that row is among those a feature group stages (plan_groups)
+    st->desc_host[f].col_sentinel = nullptr;
+    if (view->masks[c] != nullptr) {
+      uint32_t sentinel = 0;
+      bool ok = false, bytes = false;
+      switch (h.family) {
+        case MSC_BB:
+        case MSC_BBNC: sentinel = 2, ok = true, bytes = true; break;
+        case MSC_DD: sentinel = h.dim, ok = h.dim + 1 <= 64; break;
+        case MSC_GP:
+        case MSC_BNB: sentinel = st->desc_host[f].vcap, ok = sentinel + 1 <= 64; break;
+        default: break;
+      }
+      if (ok) MSC_TRY(sentinel_column(view, c, eff, bytes, sentinel, &st->desc_host[f].col_sentinel));
+    }
   }
   st->bound_view = view;
   st->bound_serial = view->serial;

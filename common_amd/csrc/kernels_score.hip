@@ -34,11 +34,15 @@ namespace msc {
 MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32_t z, uint32_t nz) {
   if (z != 0 && fd.family != MSC_GP && fd.family != MSC_BNB && fd.family != MSC_DD) return;
   switch (fd.family) {
+    // (every lookup family keeps one table row of zeros right after its last entry: what a masked value of a column with
+    // the mask folded in selects, FeatDesc::col_sentinel)
     case MSC_BB: {
       float s0, s1;
       bb_prepare(fd.hp, fd.raw_u32[k], fd.raw_u32[kpad + k], s0, s1);
       fd.tab[k] = s0;
       fd.tab[kpad + k] = s1;
+      fd.tab[2 * (size_t)kpad + k] = 0.f;
+      if (fd.loo_tab != nullptr) fd.loo_tab[2 * (size_t)kpad + k] = 0.f;
       if (fd.loo_tab != nullptr) {          // (an entry is only read for a row that is in the group with that value)
         const uint32_t h = fd.raw_u32[k], t = fd.raw_u32[kpad + k];
         fd.loo_tab[k] = t ? (float)bb_loo(fd.hp, h, t, false) : 0.f;
@@ -50,10 +54,15 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32
       bbnc_prepare(fd.raw_f32[k], s0, s1);
       fd.tab[k] = s0;
       fd.tab[kpad + k] = s1;
+      fd.tab[2 * (size_t)kpad + k] = 0.f;
     } break;
     case MSC_GP: {
       const uint32_t cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
-      if (z == 0) gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
+      if (z == 0) {
+        gp_prepare_consts(fd.hp, cnt, sum, fd.tab[(size_t)GP_NSE_HI * kpad + k], fd.tab[(size_t)GP_NSE_LO * kpad + k]);
+        fd.tab[(size_t)(GP_T0 + fd.vcap) * kpad + k] = 0.f;
+        if (fd.loo_tab != nullptr) fd.loo_tab[(size_t)fd.vcap * kpad + k] = 0.f;
+      }
       for (uint32_t v = z; v < fd.vcap; v += nz)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = gp_prepare_table(fd.hp, cnt, sum, v);
       if (fd.loo_tab != nullptr)
@@ -62,6 +71,10 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32
     } break;
     case MSC_BNB: {
       const double cnt = fd.raw_u32[k], sum = fd.raw_u32[kpad + k];
+      if (z == 0) {
+        fd.tab[(size_t)(GP_T0 + fd.vcap) * kpad + k] = 0.f;
+        if (fd.loo_tab != nullptr) fd.loo_tab[(size_t)fd.vcap * kpad + k] = 0.f;
+      }
       for (uint32_t v = z; v < fd.vcap; v += nz)
         fd.tab[(size_t)(GP_T0 + v) * kpad + k] = (float)bnb_score(fd.hp, cnt, sum, (double)v);
       if (fd.loo_tab != nullptr)
@@ -70,6 +83,10 @@ MSC_DEV void prepare_group(const FeatDesc &fd, uint32_t k, uint32_t kpad, uint32
     } break;
     case MSC_DD: {
       const uint32_t csum = fd.raw_u32[k];
+      if (z == 0) {
+        fd.tab[(size_t)fd.dim * kpad + k] = 0.f;
+        if (fd.loo_tab != nullptr) fd.loo_tab[(size_t)fd.dim * kpad + k] = 0.f;
+      }
       for (uint32_t i = z; i < fd.dim; i += nz)
         fd.tab[(size_t)i * kpad + k] =
             dd_prepare_entry(fd.hp[i], fd.raw_u32[(size_t)(1 + i) * kpad + k], fd.aux, csum);

@@ -430,6 +430,25 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ reco
   }
 }
 
+// a masked lookup column with the mask folded in: masked rows hold `sentinel` (the index of the family's zero table row)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mask_sentinel(const T *__restrict__ col, const uint8_t *__restrict__ mask, uint64_t n,
+                                                        T sentinel, T *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = mask[i] != 0 ? sentinel : col[i];
+}
+int launch_mask_sentinel(hipStream_t stream, const void *col, const uint8_t *mask, uint64_t n, bool bytes, uint32_t sentinel, void *out) {
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (bytes)
+    hipLaunchKernelGGL(k_mask_sentinel<uint8_t>, grid, dim3(256), 0, stream, static_cast<const uint8_t *>(col), mask, n, (uint8_t)sentinel,
+                       static_cast<uint8_t *>(out));
+  else
+    hipLaunchKernelGGL(k_mask_sentinel<uint32_t>, grid, dim3(256), 0, stream, static_cast<const uint32_t *>(col), mask, n, sentinel,
+                       static_cast<uint32_t *>(out));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // maximum of a uint32 column (sizes the gp tables)
 __global__ __launch_bounds__(256) void k_col_max_u32(const uint32_t *__restrict__ col, uint64_t n,
                                                       uint32_t *__restrict__ out) {

@@ -136,6 +136,7 @@ int launch_relation_slice_scores(hipStream_t stream, const float *scores, uint64
 int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t dim, uint32_t *colmax_dev,
                     uint32_t *rowtot_dev);
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);
+int launch_mask_sentinel(hipStream_t stream, const void *col, const uint8_t *mask, uint64_t n, bool bytes, uint32_t sentinel, void *out);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
                   uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);
 

@@ -126,6 +126,11 @@ struct FeatDesc {
                               // per group, group-major); 0 = not staged: the feature reads global memory
   uint32_t loo_stage_end;     // one past the last feature of this feature's stage
   uint32_t pad1;
+  // a masked lookup column (bb, bbnc, gp, bnb, dd) as the tile kernels want it: a copy in which a masked row holds the
+  // index of the family's ZERO table row (bb 2, dd dim, gp / bnb vcap) -- abi.cpp bind_view makes it, plan_groups puts it
+  // in the tile plan's copy of the descriptor (mask = null there), so a masked value is one more table row to the
+  // lookup loops and nothing else; null when the column has no mask or the family no such row
+  const void *col_sentinel;
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -151,8 +156,9 @@ inline uint32_t tab_rows(int family, uint32_t dim) {
 // by side they are 48 bytes, one cache line mostly; family_math.hpp NLOO_*)
 constexpr uint32_t kNlooStride = 6;
 inline uint32_t loo_rows(int family) { return family == MSC_NICH ? kNlooStride : 0u; }
+// (+ 1: the zero row a masked value selects, FeatDesc::col_sentinel)
 inline uint32_t loo_tab_rows(int family, uint32_t dim) {
-  return family == MSC_BB ? 2u : (family == MSC_GP || family == MSC_BNB) ? kGpMaxTable : family == MSC_DD ? dim : 0u;
+  return family == MSC_BB ? 3u : (family == MSC_GP || family == MSC_BNB) ? kGpMaxTable + 1u : family == MSC_DD ? dim + 1u : 0u;
 }
 inline uint32_t raw_u32_rows(int family, uint32_t dim) {
   switch (family) {
@@ -289,6 +295,9 @@ struct msc_dataview {
   // copies of a column converted to another primitive type with runtime_cast semantics, made the first time a state
   // binds the column to a model whose value type differs (abi.cpp column_as): per column, (type, device copy)
   mutable std::vector<std::vector<std::pair<int, const void *>>> converted;
+  // masked lookup columns with the mask folded in as a sentinel value (abi.cpp sentinel_column): per column,
+  // ((element type, sentinel), device copy)
+  mutable std::vector<std::vector<std::pair<std::pair<int, uint32_t>, const void *>>> sentinels;
 };
 
 struct msc_feature_host {

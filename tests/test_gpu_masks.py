@@ -90,3 +90,79 @@ def test_fully_masked_row_scores_zero_and_samples_from_the_prior(gpu_ctx, monkey
     emp = np.bincount(zt.cpu().numpy(), minlength=K) / N
     pc = np.where(counts > 0, counts, 2.0 / 2)            # pseudocounts: alpha / 2 empty groups
     assert np.abs(emp - pc / pc.sum()).max() < 0.015
+
+
+@pytest.mark.parametrize("K,masked_cols", [(90, {0, 1, 3}), (300, {0, 3}), (120, {0, 2, 7})])
+def test_masked_lookup_columns_keep_the_tile_kernels_fast_path(gpu_ctx, K, masked_cols):
+    """Masked bb / gp / dd columns reach the tile kernels with the mask folded in (a masked row holds the index of the
+    family's zero table row: abi.cpp bind_view / plan_groups), so such a state keeps the lookup runs and the role-split
+    kernels; a masked nich column (third case, column 2) still takes the generic path.  40k rows against the oracle,
+    against short slices (other launch shapes: same bits), plain and leave-one-out + prior, and -- K <= 256 -- as a fused
+    sweep against the same sweep in three shards; accumulate sees the original column and mask."""
+    import common_amd
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.BB, 0), (orc.DD, 40), (orc.NICH, 0), (orc.GP, 0),
+             (orc.NICH, 0), (orc.BBNC, 0)]
+    N = 40_000
+    rng = np.random.default_rng(K)
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    masks = [(rng.random(N) < 0.2) if i in masked_cols else np.zeros(N, dtype=bool) for i in range(len(feats))]
+    dev = gpu_ctx.torch_device
+    cols = [torch.from_numpy(np.ascontiguousarray(f["values"])).to(dev) for f in feats]
+    mts = [torch.from_numpy(masks[i].astype(np.uint8)).to(dev) if i in masked_cols else None for i in range(len(feats))]
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols, mts)
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    fs = []
+    for f, m in zip(feats, masks):
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        init = None
+        if f["family"] == orc.BBNC:
+            init = np.zeros(K, dtype=orc.ss_dtype(orc.BBNC, 0, "f64"))
+            init["p"] = np.random.default_rng(K).uniform(0.05, 0.95, K).astype(np.float32)
+        ss32 = orc.narrow_ss(f["family"], F.accumulate(K, f["values"], np.where(m, -1, z).astype(np.int32), ss_init=init), f["dim"])
+        fs.append((F, orc.widen_ss(f["family"], ss32, f["dim"]), ss32))
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(0.9)
+    zt = torch.from_numpy(z).to(dev)
+    rows = np.random.default_rng(1).choice(N, 300, replace=False)
+
+    def twin(zz):
+        total, mag = None, None
+        for f, m, (F, ss64, _) in zip(feats, masks, fs):
+            sc = F.score_matrix(ss64, f["values"][rows], None if zz is None else np.where(m, -1, zz).astype(np.int32)[rows])
+            sc[m[rows]] = 0.0
+            total = sc if total is None else total + sc
+            mag = np.maximum(1.0, np.abs(sc)) if mag is None else mag + np.maximum(1.0, np.abs(sc))
+        return total, mag
+    plain = st.score_value(view)
+    want, mag = twin(None)
+    assert (np.abs(plain.cpu().numpy()[rows] - want) / mag).max() <= TOL
+    loo = st.score_value(view, z=zt)
+    want, mag = twin(z)
+    assert (np.abs(loo.cpu().numpy()[rows] - want) / mag).max() <= TOL
+    full = st.score_value(view, z=zt, crp_prior=True)
+    for row0, n in ((0, 129), (N - 77, 77), (N // 2 + 3, 500)):
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True),
+                           full[row0:row0 + n])
+    if K <= 256:                                           # the fused mixed sweep: whole against three shards
+        whole = zt.clone()
+        st.sweep_assign(view, whole, seed=5, sweep=1)
+        parts = zt.clone()
+        for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+            zs = parts[lo:lo + n].contiguous()
+            st.sweep_assign(view, zs, seed=5, sweep=1, row0=lo, nrows=n, row_id0=lo)
+            parts[lo:lo + n] = zs
+        assert torch.equal(whole, parts)
+        assert (whole.cpu().numpy() != z).mean() > 0.05
+    # the suff-stats a device-side accumulate builds (original column + mask) are the masked rows left out
+    st2 = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, (F, _, ss32) in enumerate(fs):
+        st2.set_hp(i, F.hp)
+    st2.accumulate(view, zt)
+    for i, (F, _, ss32) in enumerate(fs):
+        rec = st2.get_ss(i)
+        for name in rec.dtype.names:
+            if np.issubdtype(rec.dtype[name].base, np.integer):
+                assert np.array_equal(rec[name], ss32[name]), (i, name)
