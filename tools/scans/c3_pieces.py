@@ -13,7 +13,7 @@ import common_amd  # noqa: E402
 from tools.bench_configs import make_columns, timed  # noqa: E402
 
 Ks = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [256]
-masked = "--masked" in sys.argv
+masked = "--masked" in sys.argv or "--masked-nich" in sys.argv
 ctx = common_amd.Context(0)
 N = 1_000_000
 spec = [(common_amd.BB, 0), (common_amd.GP, 0), (common_amd.DD, 32), (common_amd.NICH, 0)] * 16
@@ -27,6 +27,8 @@ for K in Ks:
     if masked:                                  # one masked bb column: the first phase is no longer lookup runs only
         masks = [None] * len(cols)
         masks[0] = (torch.rand(N, device=ctx.torch_device) < 0.05).to(torch.uint8).contiguous()
+        if "--masked-nich" in sys.argv:         # ... and a masked nich column
+            masks[3] = (torch.rand(N, device=ctx.torch_device) < 0.05).to(torch.uint8).contiguous()
     view = common_amd.DataView.from_tensors(ctx, cols, masks)
     st = common_amd.State(ctx, spec, K)
     st.set_alpha(1.0)
