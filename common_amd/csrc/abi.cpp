@@ -680,6 +680,20 @@ static void plan_groups(msc_state *st) {
     if (i < split && t[i].kind == MSC_KIND_GENERIC) st->tile_roles_ok = false;
   }
   if (has_dm) st->tile_roles_ok = false;
+  // the narrow kernel for a partly filled last tile (k_score_tail): lookup runs only in the first phase (what it
+  // implements), whatever the second holds of plain nich features
+  st->tile_narrow_tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
+  for (uint32_t i = 0; i < split; i++) st->tile_narrow_tail_ok &= t[i].kind != MSC_KIND_GENERIC;
+  for (uint32_t i = split; i < n; i++) st->tile_narrow_tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
+  // (its slot holds a feature group with every block padded to the rows one instruction copies: four at most)
+  st->tile_narrow_tail_rows = 0;
+  for (uint32_t f0 = 0; f0 < n;) {
+    uint32_t rows = 0, g = f0;
+    for (; g < t[f0].grp_end; g++) rows += (t[g].grp_rows + 3u) / 4u * 4u;
+    st->tile_narrow_tail_rows = std::max(st->tile_narrow_tail_rows, rows);
+    f0 = g > f0 ? g : f0 + 1;
+  }
+  if (st->tile_narrow_tail_rows > 512) st->tile_narrow_tail_ok = false;      // (Q = 2: 512 rows x 32 float4 = 256 KiB: beyond the LDS)
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
@@ -1391,7 +1405,8 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
     auto launch = [&](int shape) {
-      return launch_score(s, st->ctx->num_cus, path, shape, descs, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
+      return launch_score(s, st->ctx->num_cus, path, (st->tile_narrow_tail_ok && path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM) ? (int)st->tile_narrow_tail_rows : 0, shape, descs,
+                          (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
                           nrows, z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out);
     };
     // The single-nich pass is bound by the HBM write stream; its launch shape (rows per visit, visits per wave =
@@ -1461,7 +1476,7 @@ extern "C" int msc_score_tune(msc_state *st, const msc_dataview *view, const uin
   if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
     return fail(MSC_EINVAL, "msc_score_tune waits for the device: not on a capturing stream");
   auto launch = [&](int shape) {
-    return launch_score(s, st->ctx->num_cus, MSC_PATH_NICH1, shape, st->desc_dev, 1, (int)st->tile_split, st->K, st->kpad, row0,
+    return launch_score(s, st->ctx->num_cus, MSC_PATH_NICH1, 0, shape, st->desc_dev, 1, (int)st->tile_split, st->K, st->kpad, row0,
                         nrows, nullptr, nullptr, nullptr, out_dev, ld_out);
   };
   hipEvent_t e0, e1;

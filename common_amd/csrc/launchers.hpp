@@ -60,7 +60,9 @@ enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TIL
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
-int launch_score(hipStream_t stream, int num_cus, int path, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
+// narrow_tail: score a partly filled last tile (<= 128 groups) with k_score_tail (abi.cpp: the plan's first phase is lookup
+// runs only)
+int launch_score(hipStream_t stream, int num_cus, int path, int narrow_tail /* 0: no; else the table rows its slot must hold */, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
 

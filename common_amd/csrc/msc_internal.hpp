@@ -349,6 +349,8 @@ struct msc_state {
   float *scratch = nullptr;       // score chunk for the generic sweep path
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
+  bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail
+  uint32_t tile_narrow_tail_rows = 0; // ... whose LDS slot must hold this many table rows
   uint32_t loo_staged = 0;        // plan_groups: features whose leave-one-out block k_loo_own_lds stages in LDS
   float *rows_table = nullptr;    // k_sweep_nich1_rows: per-group constants as scalar operands (single nich, K > 1024)
   size_t own_cap = 0;
