@@ -1726,6 +1726,34 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0;
   }
+  // 256 < K <= 320 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
+  // included) into 64 floats per row, then the fused kernel over the tile draws over both -- nothing materialised but
+  // that.  Whatever the row count, so that a shard draws from the same bits as the whole.
+  if (rc == -2 && !nich1 && !has_dm && st->tile_roles_ok && st->tile_narrow_tail_ok && tile_roles_enabled() && st->K > 256 &&
+      st->K <= 320 && std::getenv("MSC_NO_FUSED_TAIL") == nullptr) {
+    bool plain = true;
+    for (uint32_t f = 0; f < st->nfeat; f++) plain &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
+    if (plain) {
+      MSC_TRY(ensure_own(st, nrows));
+      if (launch_loo_own(s, cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
+        return fail(MSC_EHIP, "k_loo_own launch failed");
+      const size_t need = ((size_t)nrows + 16) * 64;
+      if (st->tail_floats < need) {
+        void *p = nullptr;
+        MSC_HIP(hipMalloc(&p, need * sizeof(float)));
+        st->owned.push_back(p);
+        st->tail_scores = static_cast<float *>(p);
+        st->tail_floats = need;
+      }
+      // (the kernel stores at out + row * ld + k: handing it tail_scores - 256 puts group 256 + j at column j)
+      if (launch_score_tail(s, cus, (int)st->tile_narrow_tail_rows, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
+                            kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, 64) == 0) {
+        rc = launch_sweep_roles_tail(s, cus, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
+                                     z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);
+        if (zeroed) *zeroed = rc == 0;
+      }
+    }
+  }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
     const uint64_t ld = st->kpad;

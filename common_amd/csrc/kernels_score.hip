@@ -1133,6 +1133,27 @@ __global__ __launch_bounds__(kTailWaves * 64, 4) void k_score_tail(const FeatDes
   }
 }
 
+// -> 0: launched; 1: the tail is not one for this kernel (the caller's tile kernels take it)
+int launch_score_tail(hipStream_t stream, int num_cus, int slot_rows, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                      uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
+                      float *out, uint64_t ld) {
+  // (up to 64 groups: there the narrow kernel takes 1.05 ms for C3's columns where a tile pass takes 1.65-2.0; with
+  // 65..128 groups -- two rows per instruction -- it measured 2.4 ms and the tile kernels keep the tile)
+  const uint32_t tail_groups = K - k0;
+  constexpr int Q = 4;
+  const size_t lds = (size_t)slot_rows * (64 / Q) * sizeof(float4);
+  if (slot_rows <= 0 || K <= k0 || tail_groups > 64 || lds > 128u * 1024u) return 1;
+  static unsigned long long attr_devices = 0;
+  if (first_use_on_device(attr_devices))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  const uint64_t rows_wg = (uint64_t)kTailWaves * kTailBundles * Q;
+  const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
+  const unsigned tgx = (unsigned)std::min<uint64_t>(tchunks ? tchunks : 1, (uint64_t)num_cus * 8);
+  hipLaunchKernelGGL(k_score_tail<4>, dim3(tgx), dim3(kTailWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0, row0,
+                     nrows, z, own, crp, out, ld);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 template <bool LOO, bool CRP>
 static void launch_score_t(hipStream_t stream, int num_cus, int path, int narrow_tail, int nich1_shape, const FeatDesc *feats_dev,
                            int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
@@ -1172,29 +1193,8 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int narrow
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
     // the last tile alone on the narrow kernel when it is partly filled and the plan allows (path flag from abi.cpp)
-    const uint32_t tail_groups = K - (ktiles - 1) * kGroupTile;
-    const int Q = tail_groups <= 64 ? 4 : 2;
-    const size_t lds = (size_t)narrow_tail * (64 / Q) * sizeof(float4);
-    // (up to 64 groups: there the narrow kernel takes 1.05 ms for C3's columns where a tile pass takes 1.65-2.0; with
-    // 65..128 groups -- two rows per instruction -- it measured 2.4 ms and the tile kernels keep the tile)
-    const bool tail = narrow_tail > 0 && ktiles > 1 && tail_groups <= 64 && lds <= 128u * 1024u;
-    if (tail) {
-      static unsigned long long attr_devices = 0;
-      if (first_use_on_device(attr_devices)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      }
-      const uint64_t rows_wg = (uint64_t)kTailWaves * kTailBundles * Q;
-      const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
-      const unsigned tgx = (unsigned)std::min<uint64_t>(tchunks ? tchunks : 1, (uint64_t)num_cus * 8);
-      const uint32_t k0 = (ktiles - 1) * kGroupTile;
-      if (Q == 4)
-        hipLaunchKernelGGL(k_score_tail<4>, dim3(tgx), dim3(kTailWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0, row0,
-                           nrows, z, own, crp, out, ld);
-      else
-        hipLaunchKernelGGL(k_score_tail<2>, dim3(tgx), dim3(kTailWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0, row0,
-                           nrows, z, own, crp, out, ld);
-    }
+    const bool tail = ktiles > 1 && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
+                                                      (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
     const dim3 grid((unsigned)gx, tail ? ktiles - 1 : ktiles);
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,

@@ -152,6 +152,49 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
   return k < (int)K ? k : (int)K - 1;
 }
 
+// The same draw over a full 256-group tile (4 entries per lane) FOLLOWED by a tail of up to 64 groups (4 per lane on lanes
+// 0..15; -inf elsewhere and beyond K): one maximum, two running sums, the dart thrown at their total, the tile searched
+// first -- the CDF order of sample_discrete (k ascending).
+MSC_DEV int sample_tile_and_tail(const float (&sm)[4], const float (&st)[4], float u01, int lane, uint32_t K) {
+  float m = fmaxf(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
+  m = wave_max(m);
+  float pm[4], pt[4], summ = 0.f, sumt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    pm[j] = __builtin_amdgcn_exp2f((sm[j] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
+    pt[j] = __builtin_amdgcn_exp2f((st[j] - m) * 1.44269504088896340736f);
+    summ += pm[j];
+    sumt += pt[j];
+  }
+  const float inclm = wave_incl_scan(summ, lane), totm = lane_bcast(inclm, 63);
+  const float inclt = wave_incl_scan(sumt, lane), tott = lane_bcast(inclt, 63);
+  const float dart = u01 * (totm + tott);
+  float c = inclm - summ;
+  int nmiss = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    c += pm[j];
+    nmiss += c < dart ? 1 : 0;
+  }
+  unsigned long long hit = __builtin_amdgcn_ballot_w64(nmiss < 4);
+  if (hit != 0ull) {
+    const int l = (int)__builtin_ctzll(hit);
+    return 4 * l + lane_bcast(nmiss, l);                 // (< 256 <= K)
+  }
+  c = totm + (inclt - sumt);
+  nmiss = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    c += pt[j];
+    nmiss += c < dart ? 1 : 0;
+  }
+  hit = __builtin_amdgcn_ballot_w64(nmiss < 4 && lane < 16);
+  if (hit == 0ull) return (int)K - 1;
+  const int l = (int)__builtin_ctzll(hit);
+  const int k = kGroupTile + 4 * l + lane_bcast(nmiss, l);
+  return k < (int)K ? k : (int)K - 1;
+}
+
 // the whole grid shares the zeroing of the additive tables (nothing in a sweep kernel reads them)
 MSC_DEV void zero_spans(const ZeroSpans &zs) {
   const size_t n = zs.na + zs.nb;
@@ -1021,11 +1064,17 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // each, the table slot and a barrier of their own) and the nich phase (waves 8-15, the same rows, constants from L2) --
 // kernels_score.hip k_score_tile_roles, where the why is written down.  The lookup waves take the sums over and draw.
 // ---------------------------------------------------------------------------
+// TAIL: 256 < K <= 320 -- the groups beyond the tile were scored by k_score_tail (leave-one-out value and prior included)
+// into `tail`, 64 floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
+// nich sums are read (the region is the wave's own until every lookup wave has passed the next chunk's first barrier)
+// and draws over tile + tail.  An instantiation of its own: the K <= 256 kernel keeps its registers.
+template <bool TAIL>
 __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                                uint64_t row_id0, int32_t *__restrict__ z,
                                                                const float *__restrict__ own, const float *__restrict__ crp,
-                                                               const uint64_t *__restrict__ rng, ZeroSpans zero) {
+                                                               const uint64_t *__restrict__ rng, ZeroSpans zero,
+                                                               const float *__restrict__ tail) {
   constexpr int R = 16;
   const uint64_t seed = rng[0], sweep = rng[1];
   zero_spans(zero);
@@ -1097,6 +1146,17 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], theirs[r * 64]);
     }
+    float4 *mytail = lds + (size_t)pair * R * 64;
+    if (TAIL) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the nich sums are read: the region is free)
+#pragma unroll
+      for (int i = 0; i < R / 4; i++) {                    // four rows of 64 floats per instruction
+        uint64_t tr = rb + (uint64_t)(4 * i + (lane >> 4));
+        tr = tr < nrows ? tr : nrows - 1;
+        glds16(tail + tr * 64 + 4 * (lane & 15), mytail + (size_t)i * 64);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
 #pragma unroll
@@ -1105,10 +1165,20 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       const int g = lane_bcast(gz, r);
       if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
       float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+      int pick;
+      if (TAIL) {
+        const float4 t4 = mytail[(size_t)r * 16 + (lane & 15)];
+        float st[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (kb + j >= K) sc[j] = -INFINITY;
-      const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        for (int j = 0; j < 4; j++)
+          if (lane >= 16 || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
+        pick = sample_tile_and_tail(sc, st, lane_bcast(u01, r), lane, K);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kb + j >= K) sc[j] = -INFINITY;
+        pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+      }
       if (lane == r) znew = pick;
     }
     if (lane < nr) z[rb + lane] = znew;
@@ -1555,14 +1625,27 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
     hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (roles_ok && tile_roles_enabled())
-    hipLaunchKernelGGL(k_sweep_tile_roles, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
-                       row_id0, z, own, crp, rng, zero);
+    hipLaunchKernelGGL(k_sweep_tile_roles<false>, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+                       row_id0, z, own, crp, rng, zero, static_cast<const float *>(nullptr));
   else if (R == 16)
     hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else
     hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 256 < K <= 320, whatever the row count (so that a shard draws from the same bits as the whole): the role-split kernel
+// over the full tile, the tail's scores from `tail` (k_score_tail wrote them)
+int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                            uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
+                            const float *crp, const uint64_t *rng, ZeroSpans zero, const float *tail) {
+  uint64_t gx = (nrows + 127) / 128;
+  const uint64_t cap = (uint64_t)num_cus * 4;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_sweep_tile_roles<true>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
+                     row0, nrows, row_id0, z, own, crp, rng, zero, tail);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -62,6 +62,10 @@ constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 // narrow_tail: score a partly filled last tile (<= 128 groups) with k_score_tail (abi.cpp: the plan's first phase is lookup
 // runs only)
+// the narrow kernel alone: groups [k0, K) of every row (k_score_tail; slot_rows as launch_score's narrow_tail)
+int launch_score_tail(hipStream_t stream, int num_cus, int slot_rows, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                      uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
+                      float *out, uint64_t ld);
 int launch_score(hipStream_t stream, int num_cus, int path, int narrow_tail /* 0: no; else the table rows its slot must hold */, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
@@ -82,6 +86,9 @@ bool tile_roles_enabled();
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero);
+int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                            uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
+                            const float *crp, const uint64_t *rng, ZeroSpans zero, const float *tail);
 int sweep_niw1_max_groups(uint32_t dim);
 // single nich feature beyond 1024 groups (lane <-> row, groups as scalar operands); `table`: device scratch of
 // sweep_nich1_rows_table_floats(kpad) floats, rewritten by every call
