@@ -495,3 +495,38 @@ def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
         parts[lo:lo + n] = zs
     assert torch.equal(whole, parts)
     assert (whole.cpu().numpy() != z).mean() > 0.05
+
+
+@pytest.mark.parametrize("K,empty", [(257, 0), (300, 3), (320, 40)])
+def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty):
+    """256 < K <= 320 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
+    (k_score_tail: 64 floats per row, leave-one-out value and prior included) and the role-split sweep kernel draws over
+    tile + tail (k_sweep_tile_roles<true>, sample_tile_and_tail) -- whatever the row count.  Against the oracle's sweep
+    (every disagreeing draw on a CDF step), rows whose own group lies in the tail and empty tail groups included; and the
+    same sweep in three shards draws the same assignments."""
+    import common_amd
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 9), (orc.NICH, 0), (orc.BB, 0), (orc.BNB, 0)]
+    got, want, scores, z = _run(gpu_ctx, specs, 3000, K, seed=40 + K, sweep_idx=2, alpha=0.8, empty=empty)
+    assert (z >= 256).any() or K - empty <= 256
+    _check_agreement(got, want, scores, 40 + K, 2, 0.995)
+    assert (got >= 256).any()                                   # draws do land in the tail
+    # shards: the same state, 20k rows, whole against three parts
+    rng = np.random.default_rng(K)
+    N = 20_000
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    zz = rng.integers(0, K - empty, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, zz)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(zz, minlength=K).astype(np.uint32))
+    st.set_alpha(0.8)
+    whole = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, whole, seed=9, sweep=1)
+    parts = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=9, sweep=1, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
+    assert (whole.cpu().numpy() != zz).mean() > 0.05
