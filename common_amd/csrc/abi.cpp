@@ -264,7 +264,7 @@ static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MSC_EHIP, "hipEventCreate failed");
   int rc = MSC_OK;
-  const int reps = nbytes >= (256u << 20) ? 3 : 8;
+  const int reps = nbytes >= (256u << 20) ? 5 : 8;
   const bool want_vmm = !no_vmm && nbytes >= (64u << 20);                      // small buffers: not worth 32 MiB chunks
   for (uint32_t i = 0; i < max_candidates; i++) {
     if (i > 0) {                                                               // never take the device's last memory for a probe
@@ -329,9 +329,13 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
   MSC_REQUIRE(ctx && out, "null argument");
   *out = nullptr;
   MSC_HIP(hipSetDevice(ctx->device));
-  // MSC_ALLOC_CANDIDATES (default 6; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6600)
-  static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 6;
-  static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6600.f;
+  // MSC_ALLOC_CANDIDATES (default 24; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6500: a
+  // candidate that fills at 6.5 TB/s takes the C2 pass at 0.87 of the HBM roof, one at 6.2 at 0.80-0.83).  Candidates
+  // held side by side walk through physical memory, and where the fast stretches lie differs from box to box: one box
+  // offered one within six candidates in ten processes of ten, another none within twelve in one process of twelve
+  // (profiles/r03_alloc_distribution.jsonl)
+  static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 24;
+  static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6500.f;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if (nbytes >= (64u << 20) && cand >= 1 && !capturing)

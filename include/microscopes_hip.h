@@ -101,8 +101,8 @@ int msc_context_synchronize(msc_context *ctx);
  * most allocations and 7.0 TB/s into some, decided by where the driver put the pages (profiles/r02_placement_study.txt),
  * and no allocator argument selects that.  A candidate is mapped from 32 MiB physical chunks through the virtual-memory
  * API (such buffers land in the upper band more often than hipMalloc'ed ones), stream-filled a few times on the
- * context's stream, and kept when it takes the stream at 6.6 TB/s or better; otherwise the next candidate is tried, up
- * to six, and the fastest is kept (SYNCHRONOUS, about 1 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
+ * context's stream, and kept when it takes the stream at 6.5 TB/s or better; otherwise the next candidate is tried, up
+ * to 24 (while the device has room), and the fastest is kept (SYNCHRONOUS, 2-3 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
  * MSC_ALLOC_ACCEPT_GBPS in the environment change the bounds, MSC_ALLOC_CANDIDATES=0 is plain hipMalloc).
  * msc_device_alloc_probed is the same with the bounds given by the caller: all `candidates` are probed and the fastest
  * is returned; rates_gbps (nullable, `candidates` floats) receives every candidate's fill rate, *chosen (nullable) the

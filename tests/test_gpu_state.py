@@ -372,7 +372,7 @@ def test_default_allocator_places_large_buffers(gpu_ctx):
     import common_amd
     t = gpu_ctx.alloc((300_000, 64), torch.float32)               # 76.8 MB
     rates, kept = gpu_ctx.alloc_stats()
-    assert 1 <= len(rates) <= 6 and 0 <= kept < len(rates) and all(r > 100.0 for r in rates)
+    assert 1 <= len(rates) <= 24 and 0 <= kept < len(rates) and all(r > 100.0 for r in rates)
     assert rates[kept] == max(rates) and float(t.abs().sum()) == 0.0
     small = gpu_ctx.alloc((1000,), torch.float32)
     assert float(small.sum()) == 0.0
