@@ -56,3 +56,69 @@ def score_through_virtual_api(_base desc, bytes hp, values, probe_value):
     cdef float sv = g.get().score_value(h.get()[0], value_accessor(&praw[0], NULL, t), rng)
     cdef float sd = g.get().score_data(h.get()[0], rng)
     return float(sv), float(sd), <bytes>g.get().get_ss()
+
+
+# ---- a downstream state object built from descriptors + a dataview (what mixturemodel's state.__cinit__ does) ----
+from libcpp.utility cimport pair
+from libcpp.string cimport string
+from libc.stddef cimport size_t
+from libc.stdint cimport uint64_t
+
+from common_amd.cy._dataview cimport abstract_dataview
+from common_amd.cy._dataview_h cimport dataview, row_major_dataview
+
+cdef extern from "microscopes_amd/mixture_state.hpp" namespace "microscopes::hip":
+    cdef cppclass mixture_state:
+        mixture_state(const vector[shared_ptr[model]] &, const row_major_dataview &, size_t) except +
+        size_t nentities() except +
+        size_t ngroups() except +
+        vector[size_t] groups() except +
+        vector[ssize_t] assignments() except +
+        string get_suffstats(size_t, size_t) except +
+        void set_cluster_hp(const string &) except +
+        size_t create_group(rng_t &) except +
+        void assign_all(const vector[size_t] &, rng_t &) except +
+        size_t remove_value(size_t, rng_t &) except +
+        void add_value(size_t, size_t, rng_t &) except +
+        pair[vector[size_t], vector[float]] score_value(size_t, rng_t &) except +
+        void gibbs_sweep(uint64_t, uint64_t, rng_t &) except +
+
+
+def view_size(abstract_dataview view):
+    """what a cdef consumer sees behind `_thisptr` (no device work)"""
+    cdef dataview *v = view._thisptr.get()
+    return int(v.size()), int(v.types().size())
+
+
+def mixture_walk(list descs, abstract_dataview view, labels, size_t max_groups, size_t probe_eid, bytes crp_hp,
+                 int sweeps=0):
+    """descriptors' shared_ptr[model]s + the dataview's C++ object -> hip::mixture_state; assign_all(labels); one more
+    (empty) group; remove one entity and score it against every group; put it back; optionally run batched sweeps.
+    -> dict(groups, bags[c][gid], score ids / values, assignments after the optional sweeps)"""
+    cdef vector[shared_ptr[model]] ms
+    for d in descs:
+        ms.push_back((<_base> d).get())
+    cdef row_major_dataview *rv = <row_major_dataview *> view._thisptr.get()
+    cdef vector[size_t] lab = [int(x) for x in labels]
+    cdef rng_t rng = rng_t(5)
+    cdef mixture_state *st = new mixture_state(ms, rv[0], max_groups)
+    cdef pair[vector[size_t], vector[float]] sc
+    cdef size_t gid, c, s
+    try:
+        st.set_cluster_hp(crp_hp)
+        st.assign_all(lab, rng)
+        empty = st.create_group(rng)
+        groups = [int(g) for g in st.groups()]
+        assign0 = [int(a) for a in st.assignments()]
+        bags = [{g: <bytes> st.get_suffstats(c, g) for g in groups} for c in range(ms.size())]
+        gid = st.remove_value(probe_eid, rng)
+        sc = st.score_value(probe_eid, rng)
+        bags_without = [{g: <bytes> st.get_suffstats(c, g) for g in groups} for c in range(ms.size())]
+        st.add_value(gid, probe_eid, rng)
+        for s in range(sweeps):
+            st.gibbs_sweep(1234, s, rng)
+        return {"groups": groups, "assignments": assign0, "bags": bags, "bags_without": bags_without,
+                "probe_gid": int(gid), "empty_gid": int(empty), "score_ids": [int(x) for x in sc.first], "scores": [float(x) for x in sc.second],
+                "after": [int(a) for a in st.assignments()], "ngroups_after": int(st.ngroups())}
+    finally:
+        del st

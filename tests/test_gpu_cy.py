@@ -65,3 +65,65 @@ def test_virtual_api_through_the_cython_handle_matches_the_oracle(probe, name, d
     assert rel_err(sv, F.score_value(rec, 0, pv[0])) <= TOL, name
     want_sd = F.score_data(rec, 0)
     audit("cy.score_data." + name, abs(sd - want_sd) / max(1.0, abs(want_sd)), TOL)
+
+
+def test_downstream_state_from_descriptors_and_a_cython_dataview(probe):
+    """What mixturemodel's state.__cinit__ does: shared_ptr[model]s out of the descriptors + the C++ dataview out of
+    `numpy_dataview._thisptr` -> hip::mixture_state (columns uploaded and converted at bind time); assign_all, one
+    remove_value / score_value / add_value move and batched sweeps, checked against the oracle's sequential double path."""
+    from common_amd.cy.build import build_module
+    build_module(os.path.join(ROOT, "common_amd", "cy", "_dataview.pyx"))
+    from common_amd.cy import _dataview
+    rng = np.random.default_rng(77)
+    N, K, alpha = 300, 5, 1.7
+    descs = [models.bb, models.gp, models.nich, models.dd(5)]
+    fams = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 5)]
+    feats = [make_feature(fam, N, K, rng, dim) for fam, dim in fams]
+    y = np.zeros(N, dtype=[("f%d" % i, d.py_desc().get_np_dtype()) for i, d in enumerate(descs)])
+    for i, f in enumerate(feats):
+        y["f%d" % i] = f["values"]
+    labels = rng.integers(0, K, N) * 10 + 3                        # arbitrary labels: groups are made in order of appearance
+    eid = 41
+    out = probe.mixture_walk([d.c_desc() for d in descs], _dataview.numpy_dataview(y), labels, 16, eid,
+                             wire.dumps("crp", {"alpha": alpha}), sweeps=3)
+    first = {}
+    for lab in labels:
+        first.setdefault(int(lab), len(first))
+    want_assign = [first[int(lab)] for lab in labels]
+    assert out["assignments"] == want_assign and out["groups"] == sorted(set(want_assign) | {out["empty_gid"]})
+    assert out["probe_gid"] == want_assign[eid] and out["empty_gid"] == len(first)
+    G = len(first) + 1
+    want, budget = np.zeros(G), np.zeros(G)
+    sizes = np.bincount([a for e, a in enumerate(want_assign) if e != eid], minlength=G)
+    for c, (d, (fam, dim)) in enumerate(zip(descs, fams)):
+        hp = wire.loads(d.name() + ".shared", d.c_desc().default_hp_bytes())
+        F = orc.Family(fam, hp, dim, "f64")
+        full, without = F.new_groups(G), F.new_groups(G)
+        for e in range(N):
+            F.add_value(full, want_assign[e], y["f%d" % c][e])
+            if e != eid:
+                F.add_value(without, want_assign[e], y["f%d" % c][e])
+        for which, recs in (("bags", full), ("bags_without", without)):
+            for g in range(G):
+                ss = wire.loads(d.name() + ".group", out[which][c][g])
+                for k in recs.dtype.names:
+                    if k not in ss:
+                        continue
+                    got = np.asarray(ss[k]).reshape(recs[k][g].shape)
+                    if np.issubdtype(recs.dtype[k].base, np.integer):
+                        assert np.array_equal(got, recs[k][g]), (which, c, g, k)
+                    else:
+                        # a float field rebuilt from <= N values in one pass (sums in double on the device, stored
+                        # as float): a few float roundings of its largest value, not N of them
+                        audit("cy.mixture_state.float_field." + d.name() + "." + k,
+                              rel_err(got, recs[k][g]).max() / (8 * 2.0 ** -24), 1.0)
+        sc = np.array([F.score_value(without, g, y["f%d" % c][eid]) for g in range(G)])
+        want += sc
+        budget += np.maximum(1.0, np.abs(sc))                      # the gate: 1e-6 x sum over features of max(1, |score_f|)
+    prior = np.log(np.where(sizes > 0, sizes, alpha / 1.0))       # (one empty group on offer)
+    assert out["score_ids"] == out["groups"]
+    got = np.asarray(out["scores"])
+    for g in range(G):
+        audit("cy.mixture_state.score_value",
+              abs(got[g] - (want[g] + prior[g])) / (budget[g] + max(1.0, abs(prior[g]))), TOL)
+    assert len(out["after"]) == N and min(out["after"]) >= 0 and 1 <= out["ngroups_after"] <= 16
