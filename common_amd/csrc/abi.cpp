@@ -698,6 +698,12 @@ static void plan_groups(msc_state *st) {
     f0 = g > f0 ? g : f0 + 1;
   }
   if (st->tile_narrow_tail_rows > 512) st->tile_narrow_tail_ok = false;      // (Q = 2: 512 rows x 32 float4 = 256 KiB: beyond the LDS)
+  st->tail_max_rows = st->tail_pack_rows = 0;
+  if (st->tile_narrow_tail_ok)
+    for (uint32_t i = 0; i < split; i++) {
+      st->tail_max_rows = std::max(st->tail_max_rows, t[i].run_clamp + 1);
+      st->tail_pack_rows += t[i].run_clamp + 1;
+    }
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
@@ -1323,6 +1329,25 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
   return MSC_OK;
 }
 
+// what the narrow kernels of a partly filled last tile need (launchers.hpp); the packed-table scratch grows on demand
+static int tail_plan(msc_state *st, TailPlan &tp) {
+  tp = TailPlan();
+  if (!st->tile_narrow_tail_ok) return MSC_OK;
+  const size_t need = (size_t)st->tail_pack_rows * 64;
+  if (st->tail_pack_floats < need) {
+    void *p = nullptr;
+    MSC_HIP(hipMalloc(&p, need * sizeof(float)));
+    st->owned.push_back(p);
+    st->tail_pack = static_cast<float *>(p);
+    st->tail_pack_floats = need;
+  }
+  tp.slot_rows = (int)st->tile_narrow_tail_rows;
+  tp.max_rows = st->tail_max_rows;
+  tp.pack_rows = st->tail_pack_rows;
+  tp.pack = st->tail_pack;
+  return MSC_OK;
+}
+
 static bool gp_beyond_table(const msc_state *st, uint32_t f) {
   if (!st->bound_view) return false;
   const uint32_t c = st->bound_cols[f];
@@ -1408,8 +1433,11 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
+    TailPlan tail;
+    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->kpad > (uint32_t)kGroupTile && st->K - (st->kpad - kGroupTile) <= 64)
+      MSC_TRY(tail_plan(st, tail));
     auto launch = [&](int shape) {
-      return launch_score(s, st->ctx->num_cus, path, (st->tile_narrow_tail_ok && path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM) ? (int)st->tile_narrow_tail_rows : 0, shape, descs,
+      return launch_score(s, st->ctx->num_cus, path, tail, shape, descs,
                           (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
                           nrows, z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out);
     };
@@ -1480,7 +1508,7 @@ extern "C" int msc_score_tune(msc_state *st, const msc_dataview *view, const uin
   if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
     return fail(MSC_EINVAL, "msc_score_tune waits for the device: not on a capturing stream");
   auto launch = [&](int shape) {
-    return launch_score(s, st->ctx->num_cus, MSC_PATH_NICH1, 0, shape, st->desc_dev, 1, (int)st->tile_split, st->K, st->kpad, row0,
+    return launch_score(s, st->ctx->num_cus, MSC_PATH_NICH1, TailPlan(), shape, st->desc_dev, 1, (int)st->tile_split, st->K, st->kpad, row0,
                         nrows, nullptr, nullptr, nullptr, out_dev, ld_out);
   };
   hipEvent_t e0, e1;
@@ -1750,7 +1778,9 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
         st->tail_floats = need;
       }
       // (the kernel stores at out + row * ld + k: handing it tail_scores - 256 puts group 256 + j at column j)
-      if (launch_score_tail(s, cus, (int)st->tile_narrow_tail_rows, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
+      TailPlan tail;
+      MSC_TRY(tail_plan(st, tail));
+      if (launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
                             kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, 64) == 0) {
         rc = launch_sweep_roles_tail(s, cus, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
                                      z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);

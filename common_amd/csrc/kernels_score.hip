@@ -1133,16 +1133,222 @@ __global__ __launch_bounds__(kTailWaves * 64, 4) void k_score_tail(const FeatDes
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_score_tail_rows: the same tail, LANE <-> ROW.  The lanes-are-groups kernel above leaves a third of its lanes idle on
+// 44 groups, broadcasts every row value through a shuffle and restages its tables per 256 rows, one plan group after the
+// other; here a lane owns a row, its value arrives with a coalesced load and is used as it stands, the tail's groups
+// stream past: a lookup feature is one LDS read per group at a constant offset from the row's table row (tables of the
+// tail's groups alone, packed [table row][64 groups] by k_tail_pack once per pass, staged with a 65-float row stride --
+// rows that differ in their value hit different banks), a nich feature takes its six constants per group as SCALAR
+// operands (s_load from the feature's table: no register, no LDS).  Sums in plan order from the prior's low half, the
+// prior's high half last, the leave-one-out value in place of the row's own group: bit for bit what k_score_tail
+// computes.  TGP = the tail's groups rounded up to 16 (a lane's sums stay in registers across the whole plan).
+// ---------------------------------------------------------------------------
+constexpr int kTailRowsWaves = 8;                     // 512 rows per workgroup visit
+constexpr uint32_t kTailStride = 65;                   // floats per staged table row (64 groups + 1)
+
+__global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ feats, uint32_t kpad, uint32_t k0,
+                                                    float *__restrict__ pack) {
+  const int f = blockIdx.x;
+  uint32_t off = 0;
+  for (int i = 0; i < f; i++) off += feats[i].run_clamp + 1;
+  const FeatDesc &fd = feats[f];
+  const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u, rows = fd.run_clamp + 1;
+  for (uint32_t e = threadIdx.x; e < rows * 64u; e += 256u) {
+    const uint32_t r = e >> 6, g = e & 63u;
+    pack[(size_t)(off + r) * 64 + g] = fd.tab[(size_t)(first_row + r) * kpad + k0 + g];      // (k0 + 63 < kpad)
+  }
+}
+
+template <int TGP>
+__global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
+    const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
+    uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own, const float *__restrict__ crp,
+    float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];              // cap_rows x kTailStride
+  // the prior of the tail's groups as a row starts from it / ends with it: [0] low halves, [1] the same for a row that is
+  // its group's only member, [2] / [3] the high halves likewise -- a lane picks its pair of rows by address
+  __shared__ __attribute__((aligned(16))) float pr[4][64];
+  __shared__ __attribute__((aligned(16))) float c0s[64];                  // the nich features' c0 summed per group (plan order)
+  float *const mhl = tl + (size_t)cap_rows * kTailStride;                 // [nich feature][64]: s*mu (hi) -- see the second phase
+  typedef const __attribute__((address_space(4))) FeatDesc *scalar_fd;    // (constant address space: scalar loads)
+  typedef const __attribute__((address_space(4))) float *scalar_f;
+  const scalar_fd feats = (scalar_fd)feats_g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loo = z != nullptr, pri = crp != nullptr;
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const uint64_t rows_per_wg = (uint64_t)kTailRowsWaves * 64;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  if (threadIdx.x < 64) {
+    float hi = 0.f, lo = 0.f, le0 = 0.f, le1 = 0.f, e0 = 0.f, e1 = 0.f;
+    if (pri) {
+      hi = crp[k0 + threadIdx.x];                          // (k0 + 63 < kpad)
+      lo = crp[crp_lo_cnt(kpad) + k0 + threadIdx.x];
+      le0 = crp[2 * (size_t)kpad];
+      le1 = crp[2 * (size_t)kpad + 1];
+      e0 = crp[2 * (size_t)kpad + 2];
+      e1 = crp[2 * (size_t)kpad + 3];
+    }
+    // (without a prior: sums start from +0 and end with "+ -0", which leaves every float as it is -- no branch per group)
+    const bool empty = __builtin_isinf(hi);
+    pr[0][threadIdx.x] = !pri ? 0.f : empty ? e0 : lo;
+    pr[1][threadIdx.x] = !pri ? 0.f : empty ? e1 : lo;
+    pr[2][threadIdx.x] = !pri ? -0.f : empty ? le0 : hi;
+    pr[3][threadIdx.x] = !pri ? -0.f : empty ? le1 : hi;
+    float c0 = 0.f;
+    for (int f = nsplit; f < nfeat; f++) {
+      c0 += feats_g[f].tab[(size_t)NICH_C0 * kpad + k0 + threadIdx.x];
+      mhl[(size_t)(f - nsplit) * 64 + threadIdx.x] = feats_g[f].tab[(size_t)NICH_MU_HI * kpad + k0 + threadIdx.x];
+    }
+    c0s[threadIdx.x] = c0;
+  }
+  __syncthreads();
+  auto load_value = [&](int f, uint64_t rr) -> uint32_t {                 // the row's value of feature f, raw
+    const int fi = f < nfeat ? f : nfeat - 1;
+    const int ct = feats[fi].col_type;
+    const void *col = feats[fi].col;
+    const bool u8 = ct == MSC_TYPE_B || ct == MSC_TYPE_I8 || ct == MSC_TYPE_U8;
+    return u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(col)[rr] : reinterpret_cast<const uint32_t *>(col)[rr];
+  };
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t r = chunk * rows_per_wg + (uint64_t)wave * 64 + lane;     // relative to row0
+    const bool has_row = r < nrows;
+    const uint64_t rr = row0 + (has_row ? r : 0);
+    int gown = (loo && has_row) ? z[r] : -1;
+    if ((uint32_t)gown >= K) gown = -1;
+    const bool single = pri && gown >= 0 && __builtin_isinf(crp[kpad + gown]);   // the row is its group's only member
+    const float ownv = gown >= 0 ? own[r] : 0.f;
+    const float *prl = pr[single ? 1 : 0];
+    float acc[TGP];
+    // the prior is a (hi, lo) pair per group: the sums start from lo, hi is added after the last feature (k_score_tile)
+#pragma unroll
+    for (int g = 0; g < TGP; g++) acc[g] = prl[g];
+    // ---- first phase: lookup features, as many consecutive ones per stage as the slot holds ----
+    uint32_t srow = 0, off = 0;
+    int stage_end = 0;
+    for (int fb = 0; fb < nsplit; fb += 8) {
+      // eight features' values of the row go out together: one memory round trip per batch (the other waves of the SIMD work meanwhile)
+      uint32_t w0 = load_value(fb, rr), w1 = load_value(fb + 1, rr), w2 = load_value(fb + 2, rr), w3 = load_value(fb + 3, rr),
+               w4 = load_value(fb + 4, rr), w5 = load_value(fb + 5, rr), w6 = load_value(fb + 6, rr), w7 = load_value(fb + 7, rr);
+#pragma unroll 1
+      for (int i = 0; i < 8; i++) {
+        const int f = fb + i;
+        if (f >= nsplit) break;
+        if (f == stage_end) {
+          srow += off;
+          off = 0;
+          uint32_t rows = 0;
+          while (stage_end < nsplit) {
+            const uint32_t rw = feats[stage_end].run_clamp + 1;
+            if (rows + rw > cap_rows && rows > 0) break;       // (the launcher sizes the slot for the largest table)
+            rows += rw;
+            stage_end++;
+          }
+          __syncthreads();                               // the slot's previous readers are done
+          for (uint32_t e = threadIdx.x * 4u; e < rows * 64u; e += kTailRowsWaves * 64u * 4u) {
+            const float4 v = *reinterpret_cast<const float4 *>(pack + (size_t)srow * 64 + e);
+            float *d = tl + (size_t)(e >> 6) * kTailStride + (e & 63u);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+          }
+          __syncthreads();
+        }
+        const uint32_t rc = feats[f].run_clamp;
+        const int v = (int)w0;
+        const uint32_t idx = v < 0 ? 0u : ((uint32_t)v > rc ? rc : (uint32_t)v);
+        const float *b = tl + (size_t)(off + idx) * kTailStride;
+#pragma unroll
+        for (int g = 0; g < TGP; g++) acc[g] += b[g];
+        off += rc + 1;
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;    // (the batch's values pass through w0: no indexed register)
+      }
+    }
+    // ---- second phase: plain nich features.  The accumulator takes the features' summed c0 once and every evaluation is
+    // nich_accum's two fused multiply-adds on it (as in the tile kernels' second phase); the groups' constants are SCALAR
+    // operands but for s*mu (hi), which an instruction needs beside s (one scalar operand an instruction on this chip):
+    // that one comes from LDS, a broadcast read.  9 plain + 2 transcendental instructions an evaluation, no copy.
+    if (nsplit < nfeat) {
+#pragma unroll
+      for (int g = 0; g < TGP; g++) acc[g] += c0s[g];
+    }
+    for (int fb = nsplit; fb < nfeat; fb += 8) {
+      uint32_t w0 = load_value(fb, rr), w1 = load_value(fb + 1, rr), w2 = load_value(fb + 2, rr), w3 = load_value(fb + 3, rr),
+               w4 = load_value(fb + 4, rr), w5 = load_value(fb + 5, rr), w6 = load_value(fb + 6, rr), w7 = load_value(fb + 7, rr);
+#pragma unroll 1
+      for (int i = 0; i < 8; i++) {
+        const int f = fb + i;
+        if (f >= nfeat) break;
+        const float x = __uint_as_float(w0);
+        const scalar_f tab = (scalar_f)(feats[f].tab) + k0;
+        const float *mhf = mhl + (size_t)(f - nsplit) * 64;
+#pragma unroll
+        for (int gb = 0; gb < TGP; gb += 8) {
+          // eight groups' constants at a time, 32 scalar registers (volatile: left to itself the compiler merges the
+          // loads of sixteen groups, holds hundreds of registers' worth at once and spills them through vector lanes)
+          typedef float f32x8 __attribute__((ext_vector_type(8)));
+          typedef const volatile __attribute__((address_space(4))) f32x8 *scalar_f8;
+          const f32x8 ml = *(scalar_f8)(tab + (size_t)NICH_MU_LO * kpad + gb), c1l = *(scalar_f8)(tab + (size_t)NICH_C1LN2 * kpad + gb),
+                      c1 = *(scalar_f8)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_f8)(tab + (size_t)NICH_C2 * kpad + gb);
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[gb + j] = nich_accum(acc[gb + j], x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
+        }
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
+      }
+    }
+    const float *prh = pr[single ? 3 : 2];
+#pragma unroll
+    for (int q = 0; q < TGP / 4; q++) {
+      float sv[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int g = 4 * q + c;
+        sv[c] = gown == (int)(k0 + g) ? ownv : acc[g] + prh[g];
+      }
+      if (has_row) store_row<false>(out, ld, r, k0 + 4 * q, K, make_float4(sv[0], sv[1], sv[2], sv[3]), vec_ok);
+    }
+  }
+}
+
+template <int TGP>
+static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                               uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
+                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows) {
+  static unsigned long long attr_devices = 0;
+  if (first_use_on_device(attr_devices))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL(k_score_tail_rows<TGP>, dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+                     row0, nrows, z, own, crp, out, ld, pack, cap_rows);
+}
+
 // -> 0: launched; 1: the tail is not one for this kernel (the caller's tile kernels take it)
-int launch_score_tail(hipStream_t stream, int num_cus, int slot_rows, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                       float *out, uint64_t ld) {
-  // (up to 64 groups: there the narrow kernel takes 1.05 ms for C3's columns where a tile pass takes 1.65-2.0; with
-  // 65..128 groups -- two rows per instruction -- it measured 2.4 ms and the tile kernels keep the tile)
+  // (up to 64 groups: beyond, the tile kernels keep the tile)
   const uint32_t tail_groups = K - k0;
+  if (tp.slot_rows <= 0 || K <= k0 || tail_groups > 64) return 1;
+  const bool old_kernel = std::getenv("MSC_TAIL_OLD") != nullptr;
+  if (!old_kernel && (tp.pack != nullptr || tp.pack_rows == 0 || nsplit == 0) && tp.max_rows <= 200) {
+    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
+    const size_t lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
+    if (lds > 64u * 1024u) return 1;                       // (more than 48 nich columns: the tile kernels keep the tile)
+    if (nrows == 0) return 0;
+    // lane <-> row: the tail's lookup tables packed once (k_tail_pack), then 512 rows per workgroup visit
+    if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, k0, tp.pack);
+    const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
+    const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
+    const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
+    const uint32_t tgp = (tail_groups + 15u) / 16u * 16u;
+#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows)
+    if (tgp == 16) MSC_TAIL_ROWS(16);
+    else if (tgp == 32) MSC_TAIL_ROWS(32);
+    else if (tgp == 48) MSC_TAIL_ROWS(48);
+    else MSC_TAIL_ROWS(64);
+#undef MSC_TAIL_ROWS
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   constexpr int Q = 4;
-  const size_t lds = (size_t)slot_rows * (64 / Q) * sizeof(float4);
-  if (slot_rows <= 0 || K <= k0 || tail_groups > 64 || lds > 128u * 1024u) return 1;
+  const size_t lds = (size_t)tp.slot_rows * (64 / Q) * sizeof(float4);
+  if (lds > 128u * 1024u) return 1;
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -1155,7 +1361,7 @@ int launch_score_tail(hipStream_t stream, int num_cus, int slot_rows, const Feat
 }
 
 template <bool LOO, bool CRP>
-static void launch_score_t(hipStream_t stream, int num_cus, int path, int narrow_tail, int nich1_shape, const FeatDesc *feats_dev,
+static void launch_score_t(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev,
                            int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                            const int32_t *z, const float *own, const float *crp, float *out, uint64_t ld) {
   const uint32_t ktiles = kpad / kGroupTile;
@@ -1218,7 +1424,7 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, int narrow
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)
-int launch_score(hipStream_t stream, int num_cus, int path, int narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld) {
   const bool loo = z != nullptr, pri = crp != nullptr;

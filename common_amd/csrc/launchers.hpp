@@ -60,13 +60,19 @@ enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TIL
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
-// narrow_tail: score a partly filled last tile (<= 128 groups) with k_score_tail (abi.cpp: the plan's first phase is lookup
-// runs only)
-// the narrow kernel alone: groups [k0, K) of every row (k_score_tail; slot_rows as launch_score's narrow_tail)
-int launch_score_tail(hipStream_t stream, int num_cus, int slot_rows, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+// narrow_tail: score a partly filled last tile (<= 64 groups) with the narrow kernel (abi.cpp: the plan's first phase is
+// lookup runs only).  slot_rows 0: no; else what its kernels need to know about the plan's lookup tables.
+struct TailPlan {
+  int slot_rows = 0;          // k_score_tail: the table rows its LDS slot must hold (the largest plan group, blocks padded to 4)
+  uint32_t max_rows = 0;      // k_score_tail_rows: the largest lookup table (rows a value may select)
+  uint32_t pack_rows = 0;     // ... all lookup tables together
+  float *pack = nullptr;      // ... scratch of pack_rows x 64 floats (the tail groups' tables, k_tail_pack), owned by the state
+};
+// the narrow kernel alone: groups [k0, K) of every row
+int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                       float *out, uint64_t ld);
-int launch_score(hipStream_t stream, int num_cus, int path, int narrow_tail /* 0: no; else the table rows its slot must hold */, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
 
