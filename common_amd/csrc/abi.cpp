@@ -684,20 +684,11 @@ static void plan_groups(msc_state *st) {
     if (i < split && t[i].kind == MSC_KIND_GENERIC) st->tile_roles_ok = false;
   }
   if (has_dm) st->tile_roles_ok = false;
-  // the narrow kernel for a partly filled last tile (k_score_tail): lookup runs only in the first phase (what it
+  // the narrow kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase (what it
   // implements), whatever the second holds of plain nich features
   st->tile_narrow_tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
   for (uint32_t i = 0; i < split; i++) st->tile_narrow_tail_ok &= t[i].kind != MSC_KIND_GENERIC;
   for (uint32_t i = split; i < n; i++) st->tile_narrow_tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
-  // (its slot holds a feature group with every block padded to the rows one instruction copies: four at most)
-  st->tile_narrow_tail_rows = 0;
-  for (uint32_t f0 = 0; f0 < n;) {
-    uint32_t rows = 0, g = f0;
-    for (; g < t[f0].grp_end; g++) rows += (t[g].grp_rows + 3u) / 4u * 4u;
-    st->tile_narrow_tail_rows = std::max(st->tile_narrow_tail_rows, rows);
-    f0 = g > f0 ? g : f0 + 1;
-  }
-  if (st->tile_narrow_tail_rows > 512) st->tile_narrow_tail_ok = false;      // (Q = 2: 512 rows x 32 float4 = 256 KiB: beyond the LDS)
   st->tail_max_rows = st->tail_pack_rows = 0;
   if (st->tile_narrow_tail_ok)
     for (uint32_t i = 0; i < split; i++) {
@@ -1341,7 +1332,7 @@ static int tail_plan(msc_state *st, TailPlan &tp) {
     st->tail_pack = static_cast<float *>(p);
     st->tail_pack_floats = need;
   }
-  tp.slot_rows = (int)st->tile_narrow_tail_rows;
+  tp.ok = true;
   tp.max_rows = st->tail_max_rows;
   tp.pack_rows = st->tail_pack_rows;
   tp.pack = st->tail_pack;

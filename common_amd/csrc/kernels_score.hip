@@ -990,159 +990,20 @@ int tile_rows_per_wave() {
 const Nich1Shape kNich1Shapes[kNich1NumShapes] = {{4, 2}, {4, 1}, {4, 4}, {4, 6}, {4, 3}, {4, 8}, {4, 5}, {4, 12}};
 
 // ---------------------------------------------------------------------------
-// k_score_tail: the LAST, partly filled 256-group tile of a tile state, when it holds at most 128 groups.  A pass of the
+// k_score_tail_rows: the LAST, partly filled 256-group tile of a tile state, when it holds at most 64 groups.  A pass of the
 // tile kernels costs what a full tile costs however few groups it holds -- the nich half is vector issue, 56 cycles per
 // wave evaluation whatever the lanes carry -- so a CRP state that has just grown past 256 groups paid twice (K = 300 on
-// C3's columns: 3.6 ms a scoring pass against 1.9 at K = 256).  Here the lanes of a wave are (row slot q, group quad l):
-// Q = 4 rows x 16 lanes x 4 groups (tail <= 64 groups) or Q = 2 rows x 32 lanes (<= 128), so one instruction serves Q rows
-// and the tile's cost falls with its width.  Same plan (abi.cpp plan_groups: the state's feature groups, lookup runs in
-// the first phase, plain nich features in the second), tables staged in LDS with rows as wide as the tail, sums in plan
-// order; leave-one-out value and CRP prior as in k_score_tile.  Every row count takes this kernel for the tail of an
-// eligible state (launch_score), so a shard reproduces the whole.
-//   block = 8 waves x 32 rows; a wave's rows in bundles of Q; lane r < 32 fetches the values of row r.
-// ---------------------------------------------------------------------------
-constexpr int kTailBundles = 8, kTailWaves = 8;        // a wave takes 8 bundles of Q rows
-template <int Q>
-__global__ __launch_bounds__(kTailWaves * 64, 4) void k_score_tail(const FeatDesc *__restrict__ feats, int nfeat, int nsplit, uint32_t K,
-                                                                 uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows,
-                                                                 const int32_t *__restrict__ z, const float *__restrict__ own,
-                                                                 const float *__restrict__ crp, float *__restrict__ out, uint64_t ld) {
-  constexpr int LPR = 64 / Q;                              // lanes per row: 16 (64 groups) or 32 (128 groups)
-  constexpr int NB = kTailBundles, kTailRows = NB * Q;     // rows per wave: 32 or 16
-  extern __shared__ __attribute__((aligned(16))) float4 tslot[];      // the plan's largest feature group, blocks padded to Q rows, LPR float4 a row
-  __shared__ uint32_t wbuf[kTailWaves][8][64];              // a wave's row values of eight features (below)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane / LPR, l = lane % LPR;
-  const uint32_t kb = k0 + 4 * l;                          // this lane's four groups
-  const bool loo = z != nullptr, pri = crp != nullptr;
-  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const uint64_t rows_per_wg = (uint64_t)kTailWaves * kTailRows;
-  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
-  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * kTailRows;     // relative to row0
-    const bool has_row = lane < kTailRows && rb + lane < nrows;
-    const uint64_t myrow = row0 + (has_row ? rb + lane : 0);                   // (lane r: row r of the wave's block)
-    // per bundle: this lane's row, its group, whether removing it empties the group
-    float4 acc[NB];
-    float4 logcnt = make_float4(0, 0, 0, 0), lo4 = logcnt;
-    float le0 = 0.f, le1 = 0.f, e0 = 0.f, e1 = 0.f;
-    if (pri) {
-      logcnt = ld4(crp + kb);
-      lo4 = ld4(crp + crp_lo_cnt(kpad) + kb);
-      le0 = crp[2 * (size_t)kpad];
-      le1 = crp[2 * (size_t)kpad + 1];
-      e0 = crp[2 * (size_t)kpad + 2];
-      e1 = crp[2 * (size_t)kpad + 3];
-    }
-    unsigned single = 0u;                                  // bit j: the row of bundle j is its group's only member
-#pragma unroll
-    for (int j = 0; j < NB; j++) {
-      const uint64_t r = rb + (uint64_t)j * Q + q;
-      int g = (loo && r < nrows) ? z[r] : -1;
-      if ((uint32_t)g >= K) g = -1;
-      const bool sg = pri && g >= 0 && __builtin_isinf(crp[kpad + g]);
-      single |= sg ? (1u << j) : 0u;
-      // the prior is a (hi, lo) pair per group: the sums start from lo, hi is added after the last feature (k_score_tile)
-      acc[j] = pri ? crp_prior4_lo(logcnt, lo4, sg ? e1 : e0) : make_float4(0, 0, 0, 0);
-    }
-    int f0 = 0;
-    while (f0 < nfeat) {
-      const int f1 = (int)feats[f0].grp_end;
-      __syncthreads();                                     // the slot's previous readers are done
-      {                                                    // stage the group's tables, tail columns only: Q rows per instruction
-        uint32_t off = 0;
-        for (int f = f0; f < f1; f++) {
-          const FeatDesc &fd = feats[f];
-          const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
-          const uint32_t ninstr = (fd.grp_rows + Q - 1) / Q;
-          for (uint32_t i = (uint32_t)wave; i < ninstr; i += kTailWaves)        // (rows past the block: the table's slack rows)
-            glds16(fd.tab + (size_t)(first_row + i * Q + q) * kpad + kb, tslot + (size_t)(off + i * Q) * LPR);
-          off += ninstr * Q;
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // the features of the group eight at a time: their row values go out together (one memory round trip per eight
-      // features; one per feature left the kernel waiting on loads: 1.22 ms for C3's tail of 44 groups), then the
-      // lookups / evaluations.  No branch around a load: a slot past the group's end reads its last column again.
-      uint32_t off = 0;
-      for (int fb = f0; fb < f1; fb += 8) {
-        {
-          uint32_t w[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const FeatDesc &fd = feats[fb + i < f1 ? fb + i : f1 - 1];
-            const bool u8 = fd.col_type == MSC_TYPE_B || fd.col_type == MSC_TYPE_I8 || fd.col_type == MSC_TYPE_U8;
-            const uint64_t rr = has_row ? myrow : row0;
-            w[i] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[rr] : reinterpret_cast<const uint32_t *>(fd.col)[rr];
-          }
-          // (parked in LDS: the loop below is not unrolled -- unrolled, its eight bodies interleave and take 185-256 registers)
-#pragma unroll
-          for (int i = 0; i < 8; i++) wbuf[wave][i][lane] = w[i];
-        }
-#pragma unroll 1
-        for (int i = 0; i < 8; i++) {
-          const int f = fb + i;
-          if (f >= f1) break;
-          const FeatDesc &fd = feats[f];
-          const uint32_t wi = wbuf[wave][i][lane];
-          const float4 *blk = tslot + (size_t)off * LPR + l;
-          off += (fd.grp_rows + Q - 1) / Q * Q;
-          if (f < nsplit) {
-            if (fd.kind == MSC_KIND_GENERIC) continue;     // (launch_score takes this kernel for lookup-only first phases)
-            const int v = (int)wi;
-            const int idxv = v < 0 ? 0 : (v > (int)fd.run_clamp ? (int)fd.run_clamp : v);
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-              const int ib = __shfl(idxv, j * Q + q, 64);
-              add4(acc[j], blk[(size_t)ib * LPR]);
-            }
-          } else {
-            const float4 mh = blk[NICH_MU_HI * LPR], ml = blk[NICH_MU_LO * LPR], c0 = blk[NICH_C0 * LPR], c1l = blk[NICH_C1LN2 * LPR],
-                         c1 = blk[NICH_C1 * LPR], c2 = blk[NICH_C2 * LPR];
-            const float xv = __uint_as_float(wi);
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-              const float x = __shfl(xv, j * Q + q, 64);
-              acc[j].x += nich_eval(x, mh.x, ml.x, c0.x, c1l.x, c1.x, c2.x);
-              acc[j].y += nich_eval(x, mh.y, ml.y, c0.y, c1l.y, c1.y, c2.y);
-              acc[j].z += nich_eval(x, mh.z, ml.z, c0.z, c1l.z, c1.z, c2.z);
-              acc[j].w += nich_eval(x, mh.w, ml.w, c0.w, c1l.w, c1.w, c2.w);
-            }
-          }
-        }
-      }
-      f0 = f1;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; j++) {
-      const uint64_t r = rb + (uint64_t)j * Q + q;
-      float4 s = acc[j];
-      if (pri) add4(s, crp_prior4(logcnt, ((single >> j) & 1u) ? le1 : le0));
-      const int g = (loo && r < nrows) ? z[r] : -1;           // (read again rather than kept across the features)
-      if (g >= 0 && (uint32_t)g < K && (uint32_t)g >= kb && (uint32_t)g < kb + 4) {
-        const float v = own[r];
-        const uint32_t c = (uint32_t)g - kb;
-        s.x = c == 0 ? v : s.x;
-        s.y = c == 1 ? v : s.y;
-        s.z = c == 2 ? v : s.z;
-        s.w = c == 3 ? v : s.w;
-      }
-      if (r < nrows) store_row<false>(out, ld, r, kb, K, s, vec_ok);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_score_tail_rows: the same tail, LANE <-> ROW.  The lanes-are-groups kernel above leaves a third of its lanes idle on
-// 44 groups, broadcasts every row value through a shuffle and restages its tables per 256 rows, one plan group after the
-// other; here a lane owns a row, its value arrives with a coalesced load and is used as it stands, the tail's groups
-// stream past: a lookup feature is one LDS read per group at a constant offset from the row's table row (tables of the
-// tail's groups alone, packed [table row][64 groups] by k_tail_pack once per pass, staged with a 65-float row stride --
-// rows that differ in their value hit different banks), a nich feature takes its six constants per group as SCALAR
-// operands (s_load from the feature's table: no register, no LDS).  Sums in plan order from the prior's low half, the
-// prior's high half last, the leave-one-out value in place of the row's own group: bit for bit what k_score_tail
-// computes.  TGP = the tail's groups rounded up to 16 (a lane's sums stay in registers across the whole plan).
+// C3's columns: 3.6 ms a scoring pass against 1.9 at K = 256).  Here LANE <-> ROW: a lane owns a row, its values arrive
+// with coalesced loads and are used as they stand (no broadcast), and the tail's groups stream past: a lookup feature is
+// one LDS read per group at a constant offset from the row's table row (tables of the tail's groups alone, packed
+// [table row][64 groups] by k_tail_pack once per pass, staged with a 65-float row stride -- rows that differ in their
+// value hit different banks), a nich feature takes its constants per group as SCALAR operands (s_load from the feature's
+// table: no register, no LDS).  Same plan as the tile kernels (abi.cpp plan_groups: lookup features in the first phase,
+// plain nich features in the second), sums in plan order from the prior's low half, the prior's high half last, the
+// leave-one-out value in place of the row's own group.  TGP = the tail's groups rounded up to 16 (a lane's sums stay in
+// registers across the whole plan).  Every row count takes this kernel for the tail of an eligible state (launch_score),
+// so a shard reproduces the whole.  (Round 3's first version had the lanes as (row slot, group quad) with the row values
+// broadcast by shuffles: 1.08 ms for C3's tail of 44 groups; this one 0.46 ms -- tools/microbench/README.md.)
 // ---------------------------------------------------------------------------
 constexpr int kTailRowsWaves = 8;                     // 512 rows per workgroup visit
 constexpr uint32_t kTailStride = 65;                   // floats per staged table row (64 groups + 1)
@@ -1325,38 +1186,23 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
                       float *out, uint64_t ld) {
   // (up to 64 groups: beyond, the tile kernels keep the tile)
   const uint32_t tail_groups = K - k0;
-  if (tp.slot_rows <= 0 || K <= k0 || tail_groups > 64) return 1;
-  const bool old_kernel = std::getenv("MSC_TAIL_OLD") != nullptr;
-  if (!old_kernel && (tp.pack != nullptr || tp.pack_rows == 0 || nsplit == 0) && tp.max_rows <= 200) {
-    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
-    const size_t lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
-    if (lds > 64u * 1024u) return 1;                       // (more than 48 nich columns: the tile kernels keep the tile)
-    if (nrows == 0) return 0;
-    // lane <-> row: the tail's lookup tables packed once (k_tail_pack), then 512 rows per workgroup visit
-    if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, k0, tp.pack);
-    const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
-    const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
-    const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
-    const uint32_t tgp = (tail_groups + 15u) / 16u * 16u;
-#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows)
-    if (tgp == 16) MSC_TAIL_ROWS(16);
-    else if (tgp == 32) MSC_TAIL_ROWS(32);
-    else if (tgp == 48) MSC_TAIL_ROWS(48);
-    else MSC_TAIL_ROWS(64);
-#undef MSC_TAIL_ROWS
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-  }
-  constexpr int Q = 4;
-  const size_t lds = (size_t)tp.slot_rows * (64 / Q) * sizeof(float4);
-  if (lds > 128u * 1024u) return 1;
-  static unsigned long long attr_devices = 0;
-  if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  const uint64_t rows_wg = (uint64_t)kTailWaves * kTailBundles * Q;
+  if (!tp.ok || K <= k0 || tail_groups > 64 || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return 1;
+  // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
+  const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
+  const size_t lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
+  if (lds > 64u * 1024u) return 1;                       // (more than 48 nich columns: the tile kernels keep the tile)
+  if (nrows == 0) return 0;
+  if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, k0, tp.pack);
+  const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
   const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
-  const unsigned tgx = (unsigned)std::min<uint64_t>(tchunks ? tchunks : 1, (uint64_t)num_cus * 8);
-  hipLaunchKernelGGL(k_score_tail<4>, dim3(tgx), dim3(kTailWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0, row0,
-                     nrows, z, own, crp, out, ld);
+  const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
+  const uint32_t tgp = (tail_groups + 15u) / 16u * 16u;
+#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows)
+  if (tgp == 16) MSC_TAIL_ROWS(16);
+  else if (tgp == 32) MSC_TAIL_ROWS(32);
+  else if (tgp == 48) MSC_TAIL_ROWS(48);
+  else MSC_TAIL_ROWS(64);
+#undef MSC_TAIL_ROWS
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // each, the table slot and a barrier of their own) and the nich phase (waves 8-15, the same rows, constants from L2) --
 // kernels_score.hip k_score_tile_roles, where the why is written down.  The lookup waves take the sums over and draw.
 // ---------------------------------------------------------------------------
-// TAIL: 256 < K <= 320 -- the groups beyond the tile were scored by k_score_tail (leave-one-out value and prior included)
+// TAIL: 256 < K <= 320 -- the groups beyond the tile were scored by k_score_tail_rows (leave-one-out value and prior included)
 // into `tail`, 64 floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
 // nich sums are read (the region is the wave's own until every lookup wave has passed the next chunk's first barrier)
 // and draws over tile + tail.  An instantiation of its own: the K <= 256 kernel keeps its registers.
@@ -1637,7 +1637,7 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
 }
 
 // 256 < K <= 320, whatever the row count (so that a shard draws from the same bits as the whole): the role-split kernel
-// over the full tile, the tail's scores from `tail` (k_score_tail wrote them)
+// over the full tile, the tail's scores from `tail` (k_score_tail_rows wrote them)
 int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                             uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
                             const float *crp, const uint64_t *rng, ZeroSpans zero, const float *tail) {

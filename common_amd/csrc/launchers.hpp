@@ -60,13 +60,13 @@ enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TIL
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
-// narrow_tail: score a partly filled last tile (<= 64 groups) with the narrow kernel (abi.cpp: the plan's first phase is
-// lookup runs only).  slot_rows 0: no; else what its kernels need to know about the plan's lookup tables.
+// narrow_tail: score a partly filled last tile (<= 64 groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
+// first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {
-  int slot_rows = 0;          // k_score_tail: the table rows its LDS slot must hold (the largest plan group, blocks padded to 4)
-  uint32_t max_rows = 0;      // k_score_tail_rows: the largest lookup table (rows a value may select)
-  uint32_t pack_rows = 0;     // ... all lookup tables together
-  float *pack = nullptr;      // ... scratch of pack_rows x 64 floats (the tail groups' tables, k_tail_pack), owned by the state
+  bool ok = false;
+  uint32_t max_rows = 0;      // the largest lookup table (rows a value may select)
+  uint32_t pack_rows = 0;     // all lookup tables together
+  float *pack = nullptr;      // scratch of pack_rows x 64 floats (the tail groups' tables, k_tail_pack), owned by the state
 };
 // the narrow kernel alone: groups [k0, K) of every row
 int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,

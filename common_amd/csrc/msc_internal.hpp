@@ -347,12 +347,11 @@ struct msc_state {
   std::vector<uint32_t> bound_cols;
   std::vector<void *> owned;
   float *scratch = nullptr;       // score chunk for the generic sweep path
-  float *tail_scores = nullptr;   // 64 floats per row: the groups beyond the first tile (k_score_tail -> k_sweep_tile_roles<true>)
+  float *tail_scores = nullptr;   // 64 floats per row: the groups beyond the first tile (k_score_tail_rows -> k_sweep_tile_roles<true>)
   size_t tail_floats = 0;
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
-  bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail
-  uint32_t tile_narrow_tail_rows = 0; // ... whose LDS slot must hold this many table rows
+  bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail_rows
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;   // the lookup tables of the tile plan's first phase: the largest, all together
   float *tail_pack = nullptr;         // k_tail_pack's output: tail_pack_rows x 64 floats (grown on demand)
   size_t tail_pack_floats = 0;

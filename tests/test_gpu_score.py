@@ -222,6 +222,54 @@ def test_leave_one_out_on_the_large_tiling(gpu_ctx, N, K):
     assert torch.equal(got[other], plain[other])           # everything but the own entries: the same bits
 
 
+TAIL_PLANS = {
+    "mixed": [(orc.BB, 0), (orc.GP, 0), (orc.DD, 7), (orc.NICH, 0), (orc.NICH, 0), (orc.DD, 33), (orc.BBNC, 0)],
+    "lookups_only": [(orc.BB, 0), (orc.DD, 12), (orc.GP, 0)],
+    "nich_only": [(orc.NICH, 0), (orc.NICH, 0), (orc.NICH, 0)],
+    "many_stages": [(orc.DD, 60)] * 9 + [(orc.NICH, 0)] * 9,      # 540 table rows: three stages of the kernel's slot; two value batches
+}
+
+
+@pytest.mark.parametrize("plan", sorted(TAIL_PLANS))
+@pytest.mark.parametrize("K", [257, 270, 285, 300, 320])
+def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
+    """256 < K <= 320: the groups beyond the first tile come from k_score_tail_rows (lane <-> row; 1 / 14 / 29 / 44 / 64
+    groups: every register tiling of it), whatever the plan holds: lookup features and nich features, one kind only, more
+    table rows than one stage of its slot.  Plain and leave-one-out + prior against the oracle on sampled rows; rows whose
+    own group lies in the tail, a singleton tail group, an empty tail group and an unassigned row included; a row range
+    (row0 > 0, a count that is no multiple of the kernel's 512-row visits) gives the same bits as the whole."""
+    import common_amd
+    N = 3000
+    rng = np.random.default_rng(K + len(plan))
+    specs = TAIL_PLANS[plan]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[z == K - 1] = 0                                      # the last group: empty
+    if K > 258:
+        z[z == K - 2] = 1
+        z[1234] = K - 2                                    # a tail group with exactly one member
+    z[77] = -1
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    counts = np.bincount(z[z >= 0], minlength=K)
+    st.set_group_counts(counts.astype(np.uint32))
+    st.set_alpha(1.4)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    in_tail = np.flatnonzero(z >= 256)[:40]
+    rows = np.unique(np.concatenate([[1234, 77, 0, N - 1], in_tail, rng.choice(N, 120, replace=False)]))
+    rt = torch.from_numpy(rows).to(gpu_ctx.torch_device)
+    plain = st.score_value(view)
+    assert rel_err(plain[rt].cpu().numpy(), oracle_scores(feats, fs, rows=rows)).max() <= TOL
+    got = st.score_value(view, z=zt, crp_prior=True)
+    want = oracle_scores(feats, fs, z=z, rows=rows) + crp_prior_matrix(counts, 1.4, z[rows])
+    assert rel_err(got[rt].cpu().numpy(), want).max() <= TOL
+    part = torch.full((1531, K), -7.0, dtype=torch.float32, device=gpu_ctx.torch_device)
+    st.score_value(view, out=part, z=zt[700:700 + 1531].contiguous(), crp_prior=True, row0=700, nrows=1531)
+    assert torch.equal(part, got[700:700 + 1531])
+
+
 @pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 16, 17, 20, 24, 31, 32, 33, 48, 64, 100, 128])
 @pytest.mark.parametrize("K", [3, 70, 130])
 def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
