@@ -1425,7 +1425,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
     TailPlan tail;
-    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->kpad > (uint32_t)kGroupTile && st->K - (st->kpad - kGroupTile) <= 64)
+    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->kpad > (uint32_t)kGroupTile && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
     auto launch = [&](int shape) {
       return launch_score(s, st->ctx->num_cus, path, tail, shape, descs,
@@ -1749,18 +1749,19 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0;
   }
-  // 256 < K <= 320 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
-  // included) into 64 floats per row, then the fused kernel over the tile draws over both -- nothing materialised but
-  // that.  Whatever the row count, so that a shard draws from the same bits as the whole.
+  // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
+  // included) into 64 or 128 floats per row, then the fused kernel over the tile draws over both -- nothing materialised
+  // but that.  Whatever the row count, so that a shard draws from the same bits as the whole.
   if (rc == -2 && !nich1 && !has_dm && st->tile_roles_ok && st->tile_narrow_tail_ok && tile_roles_enabled() && st->K > 256 &&
-      st->K <= 320 && std::getenv("MSC_NO_FUSED_TAIL") == nullptr) {
+      st->K <= (uint32_t)kGroupTile + kTailMaxGroups && std::getenv("MSC_NO_FUSED_TAIL") == nullptr) {
+    const uint64_t tail_ld = st->K <= (uint32_t)kGroupTile + 64 ? 64 : 128;
     bool plain = true;
     for (uint32_t f = 0; f < st->nfeat; f++) plain &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
     if (plain) {
       MSC_TRY(ensure_own(st, nrows));
       if (launch_loo_own(s, cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
-      const size_t need = ((size_t)nrows + 16) * 64;
+      const size_t need = ((size_t)nrows + 16) * tail_ld;
       if (st->tail_floats < need) {
         void *p = nullptr;
         MSC_HIP(hipMalloc(&p, need * sizeof(float)));
@@ -1772,7 +1773,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       TailPlan tail;
       MSC_TRY(tail_plan(st, tail));
       if (launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
-                            kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, 64) == 0) {
+                            kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld) == 0) {
         rc = launch_sweep_roles_tail(s, cus, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
                                      z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);
         if (zeroed) *zeroed = rc == 0;

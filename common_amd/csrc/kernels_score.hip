@@ -1025,7 +1025,8 @@ template <int TGP>
 __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
     uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own, const float *__restrict__ crp,
-    float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows) {
+    float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows, uint32_t kend) {
+  // (groups [k0, kend) are this launch's; K is the table's: an id outside [0, K) is an unassigned row)
   extern __shared__ __attribute__((aligned(16))) float tl[];              // cap_rows x kTailStride
   // the prior of the tail's groups as a row starts from it / ends with it: [0] low halves, [1] the same for a row that is
   // its group's only member, [2] / [3] the high halves likewise -- a lane picks its pair of rows by address
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
         const int g = 4 * q + c;
         sv[c] = gown == (int)(k0 + g) ? ownv : acc[g] + prh[g];
       }
-      if (has_row) store_row<false>(out, ld, r, k0 + 4 * q, K, make_float4(sv[0], sv[1], sv[2], sv[3]), vec_ok);
+      if (has_row) store_row<false>(out, ld, r, k0 + 4 * q, kend, make_float4(sv[0], sv[1], sv[2], sv[3]), vec_ok);
     }
   }
 }
@@ -1172,37 +1173,40 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
 template <int TGP>
 static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
-                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows) {
+                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend) {
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   hipLaunchKernelGGL(k_score_tail_rows<TGP>, dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
-                     row0, nrows, z, own, crp, out, ld, pack, cap_rows);
+                     row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend);
 }
 
 // -> 0: launched; 1: the tail is not one for this kernel (the caller's tile kernels take it)
 int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                       float *out, uint64_t ld) {
-  // (up to 64 groups: beyond, the tile kernels keep the tile)
-  const uint32_t tail_groups = K - k0;
-  if (!tp.ok || K <= k0 || tail_groups > 64 || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return 1;
+  // up to kTailMaxGroups groups, 64 a launch (a lane's sums are its registers); beyond, the tile kernels keep the tile: three
+  // launches would cost what a tile pass costs
+  if (!tp.ok || K <= k0 || K - k0 > kTailMaxGroups || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return 1;
   // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
   const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
   const size_t lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
   if (lds > 64u * 1024u) return 1;                       // (more than 48 nich columns: the tile kernels keep the tile)
   if (nrows == 0) return 0;
-  if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, k0, tp.pack);
   const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
   const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
   const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
-  const uint32_t tgp = (tail_groups + 15u) / 16u * 16u;
-#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows)
-  if (tgp == 16) MSC_TAIL_ROWS(16);
-  else if (tgp == 32) MSC_TAIL_ROWS(32);
-  else if (tgp == 48) MSC_TAIL_ROWS(48);
-  else MSC_TAIL_ROWS(64);
+  for (uint32_t kb = k0; kb < K; kb += 64) {
+    const uint32_t kend = std::min<uint32_t>(K, kb + 64), tgp = (kend - kb + 15u) / 16u * 16u;
+    // (the packed tables are this launch's: the stream orders the next block's k_tail_pack behind it)
+    if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, kb, tp.pack);
+#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
+    if (tgp == 16) MSC_TAIL_ROWS(16);
+    else if (tgp == 32) MSC_TAIL_ROWS(32);
+    else if (tgp == 48) MSC_TAIL_ROWS(48);
+    else MSC_TAIL_ROWS(64);
 #undef MSC_TAIL_ROWS
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

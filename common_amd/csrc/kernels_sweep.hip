@@ -152,9 +152,10 @@ MSC_DEV int sample_from_scores(const float (&s)[G], float u01, int lane, uint32_
   return k < (int)K ? k : (int)K - 1;
 }
 
-// The same draw over a full 256-group tile (4 entries per lane) FOLLOWED by a tail of up to 64 groups (4 per lane on lanes
-// 0..15; -inf elsewhere and beyond K): one maximum, two running sums, the dart thrown at their total, the tile searched
+// The same draw over a full 256-group tile (4 entries per lane) FOLLOWED by a tail of up to 64 TAILP groups (4 per lane on
+// lanes 0 .. 16 TAILP - 1; -inf elsewhere and beyond K): one maximum, two running sums, the dart thrown at their total, the tile searched
 // first -- the CDF order of sample_discrete (k ascending).
+template <int TAILP>
 MSC_DEV int sample_tile_and_tail(const float (&sm)[4], const float (&st)[4], float u01, int lane, uint32_t K) {
   float m = fmaxf(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])));
   m = wave_max(m);
@@ -188,7 +189,7 @@ MSC_DEV int sample_tile_and_tail(const float (&sm)[4], const float (&st)[4], flo
     c += pt[j];
     nmiss += c < dart ? 1 : 0;
   }
-  hit = __builtin_amdgcn_ballot_w64(nmiss < 4 && lane < 16);
+  hit = __builtin_amdgcn_ballot_w64(nmiss < 4 && lane < 16 * TAILP);
   if (hit == 0ull) return (int)K - 1;
   const int l = (int)__builtin_ctzll(hit);
   const int k = kGroupTile + 4 * l + lane_bcast(nmiss, l);
@@ -1064,11 +1065,11 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // each, the table slot and a barrier of their own) and the nich phase (waves 8-15, the same rows, constants from L2) --
 // kernels_score.hip k_score_tile_roles, where the why is written down.  The lookup waves take the sums over and draw.
 // ---------------------------------------------------------------------------
-// TAIL: 256 < K <= 320 -- the groups beyond the tile were scored by k_score_tail_rows (leave-one-out value and prior included)
-// into `tail`, 64 floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
+// TAILP = 1, 2: 256 < K <= 320, 384 -- the groups beyond the tile were scored by k_score_tail_rows (leave-one-out value and
+// prior included) into `tail`, 64 TAILP floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
 // nich sums are read (the region is the wave's own until every lookup wave has passed the next chunk's first barrier)
 // and draws over tile + tail.  An instantiation of its own: the K <= 256 kernel keeps its registers.
-template <bool TAIL>
+template <int TAILP>
 __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                                uint64_t row_id0, int32_t *__restrict__ z,
@@ -1076,6 +1077,8 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
                                                                const uint64_t *__restrict__ rng, ZeroSpans zero,
                                                                const float *__restrict__ tail) {
   constexpr int R = 16;
+  constexpr bool TAIL = TAILP > 0;
+  constexpr int TL = 16 * (TAIL ? TAILP : 1);            // lanes that hold a row's tail scores, four each
   const uint64_t seed = rng[0], sweep = rng[1];
   zero_spans(zero);
   __shared__ float4 lds[kGrpRows * 64];
@@ -1149,11 +1152,12 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
     float4 *mytail = lds + (size_t)pair * R * 64;
     if (TAIL) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the nich sums are read: the region is free)
+      constexpr int RPI = 64 / TL;                         // rows per instruction: four of 64 floats, two of 128
 #pragma unroll
-      for (int i = 0; i < R / 4; i++) {                    // four rows of 64 floats per instruction
-        uint64_t tr = rb + (uint64_t)(4 * i + (lane >> 4));
+      for (int i = 0; i < R / RPI; i++) {
+        uint64_t tr = rb + (uint64_t)(RPI * i + lane / TL);
         tr = tr < nrows ? tr : nrows - 1;
-        glds16(tail + tr * 64 + 4 * (lane & 15), mytail + (size_t)i * 64);
+        glds16(tail + tr * (4 * TL) + 4 * (lane % TL), mytail + (size_t)i * 64);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1167,12 +1171,12 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       float sc[4] = {s4.x, s4.y, s4.z, s4.w};
       int pick;
       if (TAIL) {
-        const float4 t4 = mytail[(size_t)r * 16 + (lane & 15)];
+        const float4 t4 = mytail[(size_t)r * TL + (lane % TL)];
         float st[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (lane >= 16 || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
-        pick = sample_tile_and_tail(sc, st, lane_bcast(u01, r), lane, K);
+          if (lane >= TL || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
+        pick = sample_tile_and_tail<TAIL ? TAILP : 1>(sc, st, lane_bcast(u01, r), lane, K);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -1625,7 +1629,7 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
     hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (roles_ok && tile_roles_enabled())
-    hipLaunchKernelGGL(k_sweep_tile_roles<false>, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL(k_sweep_tile_roles<0>, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero, static_cast<const float *>(nullptr));
   else if (R == 16)
     hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
@@ -1636,7 +1640,7 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// 256 < K <= 320, whatever the row count (so that a shard draws from the same bits as the whole): the role-split kernel
+// 256 < K <= 384, whatever the row count (so that a shard draws from the same bits as the whole): the role-split kernel
 // over the full tile, the tail's scores from `tail` (k_score_tail_rows wrote them)
 int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                             uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
@@ -1644,8 +1648,12 @@ int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *fea
   uint64_t gx = (nrows + 127) / 128;
   const uint64_t cap = (uint64_t)num_cus * 4;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(k_sweep_tile_roles<true>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
-                     row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+  if (K <= (uint32_t)kGroupTile + 64)
+    hipLaunchKernelGGL(k_sweep_tile_roles<1>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
+                       row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+  else
+    hipLaunchKernelGGL(k_sweep_tile_roles<2>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
+                       row0, nrows, row_id0, z, own, crp, rng, zero, tail);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

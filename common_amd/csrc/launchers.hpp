@@ -60,7 +60,8 @@ enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TIL
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
-// narrow_tail: score a partly filled last tile (<= 64 groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
+constexpr uint32_t kTailMaxGroups = 128;
+// narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {
   bool ok = false;

@@ -231,7 +231,7 @@ TAIL_PLANS = {
 
 
 @pytest.mark.parametrize("plan", sorted(TAIL_PLANS))
-@pytest.mark.parametrize("K", [257, 270, 285, 300, 320])
+@pytest.mark.parametrize("K", [257, 270, 285, 300, 320, 321, 345, 384])
 def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
     """256 < K <= 320: the groups beyond the first tile come from k_score_tail_rows (lane <-> row; 1 / 14 / 29 / 44 / 64
     groups: every register tiling of it), whatever the plan holds: lookup features and nich features, one kind only, more

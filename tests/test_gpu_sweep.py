@@ -497,11 +497,11 @@ def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
     assert (whole.cpu().numpy() != z).mean() > 0.05
 
 
-@pytest.mark.parametrize("K,empty", [(257, 0), (300, 3), (320, 40)])
+@pytest.mark.parametrize("K,empty", [(257, 0), (300, 3), (320, 40), (321, 0), (350, 5), (384, 70)])
 def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty):
-    """256 < K <= 320 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
-    (k_score_tail_rows: 64 floats per row, leave-one-out value and prior included) and the role-split sweep kernel draws over
-    tile + tail (k_sweep_tile_roles<true>, sample_tile_and_tail) -- whatever the row count.  Against the oracle's sweep
+    """256 < K <= 384 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
+    (k_score_tail_rows: 64 or 128 floats per row, leave-one-out value and prior included) and the role-split sweep kernel
+    draws over tile + tail (k_sweep_tile_roles<1 | 2>, sample_tile_and_tail) -- whatever the row count.  Against the oracle's sweep
     (every disagreeing draw on a CDF step), rows whose own group lies in the tail and empty tail groups included; and the
     same sweep in three shards draws the same assignments."""
     import common_amd
