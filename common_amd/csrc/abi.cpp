@@ -1425,7 +1425,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
     TailPlan tail;
-    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->kpad > (uint32_t)kGroupTile && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
+    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
     auto launch = [&](int shape) {
       return launch_score(s, st->ctx->num_cus, path, tail, shape, descs,
@@ -1772,6 +1772,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       // (the kernel stores at out + row * ld + k: handing it tail_scores - 256 puts group 256 + j at column j)
       TailPlan tail;
       MSC_TRY(tail_plan(st, tail));
+      tail.exact = false;                                  // (nothing else scores these groups for a draw: one sum per group)
       if (launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
                             kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld) == 0) {
         rc = launch_sweep_roles_tail(s, cus, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,

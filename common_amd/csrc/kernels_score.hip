@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ 
   }
 }
 
-template <int TGP>
+template <int TGP, bool SPLIT>
 __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
     uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own, const float *__restrict__ crp,
@@ -1081,7 +1081,9 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
     const bool single = pri && gown >= 0 && __builtin_isinf(crp[kpad + gown]);   // the row is its group's only member
     const float ownv = gown >= 0 ? own[r] : 0.f;
     const float *prl = pr[single ? 1 : 0];
-    float acc[TGP];
+    // SPLIT: (prior + lookups) + (nich features), then the prior's high half -- the association of score_tile, two sums per
+    // group, the tile kernels' bits; else one sum per group: prior + lookups + the nich features' c0, then the evaluations
+    float acc[TGP], accn[SPLIT ? TGP : 1];
     // the prior is a (hi, lo) pair per group: the sums start from lo, hi is added after the last feature (k_score_tile)
 #pragma unroll
     for (int g = 0; g < TGP; g++) acc[g] = prl[g];
@@ -1124,11 +1126,14 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;    // (the batch's values pass through w0: no indexed register)
       }
     }
-    // ---- second phase: plain nich features.  The accumulator takes the features' summed c0 once and every evaluation is
+    // ---- second phase: plain nich features.  Their accumulator starts from the features' summed c0 and every evaluation is
     // nich_accum's two fused multiply-adds on it (as in the tile kernels' second phase); the groups' constants are SCALAR
     // operands but for s*mu (hi), which an instruction needs beside s (one scalar operand an instruction on this chip):
     // that one comes from LDS, a broadcast read.  9 plain + 2 transcendental instructions an evaluation, no copy.
-    if (nsplit < nfeat) {
+    if (SPLIT) {
+#pragma unroll
+      for (int g = 0; g < TGP; g++) accn[g] = c0s[g];
+    } else if (nsplit < nfeat) {
 #pragma unroll
       for (int g = 0; g < TGP; g++) acc[g] += c0s[g];
     }
@@ -1142,16 +1147,22 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
         const float x = __uint_as_float(w0);
         const scalar_f tab = (scalar_f)(feats[f].tab) + k0;
         const float *mhf = mhl + (size_t)(f - nsplit) * 64;
+        // NB groups' constants at a time, 4 NB scalar registers (volatile: left to itself the compiler merges the loads of
+        // sixteen groups, holds hundreds of registers' worth at once and spills them through vector lanes); four at a
+        // time where two sums per group leave few registers for the evaluations' temporaries
+        constexpr int NB = (!SPLIT || TGP <= 32) ? 8 : 4;
+        typedef float f32xn __attribute__((ext_vector_type(NB)));
+        typedef const volatile __attribute__((address_space(4))) f32xn *scalar_fn;
 #pragma unroll
-        for (int gb = 0; gb < TGP; gb += 8) {
-          // eight groups' constants at a time, 32 scalar registers (volatile: left to itself the compiler merges the
-          // loads of sixteen groups, holds hundreds of registers' worth at once and spills them through vector lanes)
-          typedef float f32x8 __attribute__((ext_vector_type(8)));
-          typedef const volatile __attribute__((address_space(4))) f32x8 *scalar_f8;
-          const f32x8 ml = *(scalar_f8)(tab + (size_t)NICH_MU_LO * kpad + gb), c1l = *(scalar_f8)(tab + (size_t)NICH_C1LN2 * kpad + gb),
-                      c1 = *(scalar_f8)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_f8)(tab + (size_t)NICH_C2 * kpad + gb);
+        for (int gb = 0; gb < TGP; gb += NB) {
+          const f32xn ml = *(scalar_fn)(tab + (size_t)NICH_MU_LO * kpad + gb), c1l = *(scalar_fn)(tab + (size_t)NICH_C1LN2 * kpad + gb),
+                      c1 = *(scalar_fn)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_fn)(tab + (size_t)NICH_C2 * kpad + gb);
 #pragma unroll
-          for (int j = 0; j < 8; j++) acc[gb + j] = nich_accum(acc[gb + j], x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
+          for (int j = 0; j < NB; j++) {
+            float &a = SPLIT ? accn[gb + j] : acc[gb + j];
+            a = nich_accum(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
+          }
+          if (NB == 4) __builtin_amdgcn_sched_barrier(0);
         }
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
       }
@@ -1163,30 +1174,30 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const int g = 4 * q + c;
-        sv[c] = gown == (int)(k0 + g) ? ownv : acc[g] + prh[g];
+        sv[c] = gown == (int)(k0 + g) ? ownv : (SPLIT && nsplit < nfeat ? acc[g] + accn[g] : acc[g]) + prh[g];
       }
       if (has_row) store_row<false>(out, ld, r, k0 + 4 * q, kend, make_float4(sv[0], sv[1], sv[2], sv[3]), vec_ok);
     }
   }
 }
 
-template <int TGP>
+template <int TGP, bool SPLIT>
 static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend) {
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL(k_score_tail_rows<TGP>, dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
                      row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend);
 }
 
-// -> 0: launched; 1: the tail is not one for this kernel (the caller's tile kernels take it)
+// -> 0: launched; 1: the groups are not for this kernel (the caller's tile kernels take them)
 int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                       float *out, uint64_t ld) {
-  // up to kTailMaxGroups groups, 64 a launch (a lane's sums are its registers); beyond, the tile kernels keep the tile: three
-  // launches would cost what a tile pass costs
+  // up to kTailMaxGroups groups, at most 48 (two sums per group: 32 or 48 at four waves a SIMD) or 64 a launch -- a lane's
+  // sums are its registers; beyond, the tile kernels keep the tile: three launches cost what a tile pass costs
   if (!tp.ok || K <= k0 || K - k0 > kTailMaxGroups || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return 1;
   // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
   const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
@@ -1196,15 +1207,24 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
   const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
   const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
   const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
-  for (uint32_t kb = k0; kb < K; kb += 64) {
-    const uint32_t kend = std::min<uint32_t>(K, kb + 64), tgp = (kend - kb + 15u) / 16u * 16u;
+  // launches of equal width: 44 groups = 48; 64 = 32 + 32 (48 + 16 measured 2 % slower); 128 = 48 + 48 + 32
+  const uint32_t groups = K - k0, widest = tp.exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
+  const uint32_t blk = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
+  for (uint32_t kb = k0; kb < K; kb += blk) {
+    const uint32_t kend = std::min<uint32_t>(K, kb + blk), tgp = (kend - kb + 15u) / 16u * 16u;
     // (the packed tables are this launch's: the stream orders the next block's k_tail_pack behind it)
     if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, kb, tp.pack);
-#define MSC_TAIL_ROWS(T) launch_tail_rows_t<T>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
-    if (tgp == 16) MSC_TAIL_ROWS(16);
-    else if (tgp == 32) MSC_TAIL_ROWS(32);
-    else if (tgp == 48) MSC_TAIL_ROWS(48);
-    else MSC_TAIL_ROWS(64);
+#define MSC_TAIL_ROWS(T, S) launch_tail_rows_t<T, S>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
+    if (tp.exact) {
+      if (tgp == 16) MSC_TAIL_ROWS(16, true);
+      else if (tgp == 32) MSC_TAIL_ROWS(32, true);
+      else MSC_TAIL_ROWS(48, true);
+    } else {
+      if (tgp == 16) MSC_TAIL_ROWS(16, false);
+      else if (tgp == 32) MSC_TAIL_ROWS(32, false);
+      else if (tgp == 48) MSC_TAIL_ROWS(48, false);
+      else MSC_TAIL_ROWS(64, false);
+    }
 #undef MSC_TAIL_ROWS
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1248,9 +1268,13 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     const uint64_t cap = (uint64_t)num_cus * 4;
     if (gx > cap) gx = cap;
     if (gx == 0) gx = 1;
-    // the last tile alone on the narrow kernel when it is partly filled and the plan allows (path flag from abi.cpp)
-    const bool tail = ktiles > 1 && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
-                                                      (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
+    // the last tile alone on the lane <-> row kernel when it is partly filled and the plan allows (flag from abi.cpp) and
+    // the rows are many: its bits are the tile kernels', so the choice is free; few rows (a per-entity call's one) are
+    // better off with lanes as groups.  A state of at most kTailMaxGroups groups is all "last tile".
+    const bool many_rows = nrows >= kTailMinRows;
+    const bool tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
+                                                     (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
+    if (tail && ktiles == 1) return;
     const dim3 grid((unsigned)gx, tail ? ktiles - 1 : ktiles);
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,

@@ -61,10 +61,13 @@ struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 constexpr uint32_t kTailMaxGroups = 128;
+constexpr uint64_t kTailMinRows = 16384;     // score passes: fewer rows stay with the tile kernels (same bits)
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {
   bool ok = false;
+  bool exact = true;          // the tile kernels' bits (two sums per group: score passes, where the row count picks the kernel);
+                              // false: one sum per group, faster (the fused sweep's tail, which takes this kernel whatever the row count)
   uint32_t max_rows = 0;      // the largest lookup table (rows a value may select)
   uint32_t pack_rows = 0;     // all lookup tables together
   float *pack = nullptr;      // scratch of pack_rows x 64 floats (the tail groups' tables, k_tail_pack), owned by the state

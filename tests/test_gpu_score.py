@@ -231,21 +231,22 @@ TAIL_PLANS = {
 
 
 @pytest.mark.parametrize("plan", sorted(TAIL_PLANS))
-@pytest.mark.parametrize("K", [257, 270, 285, 300, 320, 321, 345, 384])
+@pytest.mark.parametrize("K", [40, 100, 128, 257, 270, 285, 300, 320, 321, 345, 384])
 def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
-    """256 < K <= 320: the groups beyond the first tile come from k_score_tail_rows (lane <-> row; 1 / 14 / 29 / 44 / 64
-    groups: every register tiling of it), whatever the plan holds: lookup features and nich features, one kind only, more
-    table rows than one stage of its slot.  Plain and leave-one-out + prior against the oracle on sampled rows; rows whose
-    own group lies in the tail, a singleton tail group, an empty tail group and an unassigned row included; a row range
-    (row0 > 0, a count that is no multiple of the kernel's 512-row visits) gives the same bits as the whole."""
+    """A last tile of at most 128 groups (K <= 128: the whole state; 256 < K <= 384: the groups beyond the first tile) comes
+    from k_score_tail_rows when the rows are many (lane <-> row; launches of 16 / 32 / 48 groups: every register tiling
+    of it), whatever the plan holds: lookup features and nich features, one kind only, more table rows than one stage of its
+    slot.  Plain and leave-one-out + prior against the oracle on sampled rows; rows whose own group lies in the tail, a
+    singleton tail group, an empty tail group and an unassigned row included; a row range of few rows (row0 > 0) -- which
+    the tile kernels score -- gives the same bits as the whole."""
     import common_amd
-    N = 3000
+    N = 17_000
     rng = np.random.default_rng(K + len(plan))
     specs = TAIL_PLANS[plan]
     feats = [make_feature(f, N, K, rng, d) for f, d in specs]
     z = rng.integers(0, K, N).astype(np.int32)
     z[z == K - 1] = 0                                      # the last group: empty
-    if K > 258:
+    if K != 257:
         z[z == K - 2] = 1
         z[1234] = K - 2                                    # a tail group with exactly one member
     z[77] = -1
@@ -257,7 +258,7 @@ def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
     st.set_group_counts(counts.astype(np.uint32))
     st.set_alpha(1.4)
     zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
-    in_tail = np.flatnonzero(z >= 256)[:40]
+    in_tail = np.flatnonzero(z >= (256 if K > 256 else 0))[:40]
     rows = np.unique(np.concatenate([[1234, 77, 0, N - 1], in_tail, rng.choice(N, 120, replace=False)]))
     rt = torch.from_numpy(rows).to(gpu_ctx.torch_device)
     plain = st.score_value(view)
@@ -268,6 +269,38 @@ def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
     part = torch.full((1531, K), -7.0, dtype=torch.float32, device=gpu_ctx.torch_device)
     st.score_value(view, out=part, z=zt[700:700 + 1531].contiguous(), crp_prior=True, row0=700, nrows=1531)
     assert torch.equal(part, got[700:700 + 1531])
+
+
+@pytest.mark.parametrize("plan", ["mixed", "nich_only", "lookups_only"])
+@pytest.mark.parametrize("K", [70, 128, 270, 300, 384])
+def test_narrow_kernel_gives_the_tile_kernels_bits(gpu_ctx, plan, K, monkeypatch):
+    """k_score_tail_rows sums as score_tile does -- (prior lo + lookups) + (c0 sum, then nich_accum per feature), prior hi
+    last -- so the choice between it and the tile kernels is free to depend on the row count: the same state planned with
+    and without it (MSC_NO_NARROW_TAIL, read when a state plans its kernels) scores every entry to the same bits."""
+    import common_amd
+    N = 16_400
+    rng = np.random.default_rng(K)
+    specs = TAIL_PLANS[plan]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K - 1, N).astype(np.int32)
+    z[11] = -1
+    fs = state_from_assignment(feats, K, z)
+    counts = np.bincount(z[z >= 0], minlength=K)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    got = {}
+    for narrow in (True, False):
+        if narrow:
+            monkeypatch.delenv("MSC_NO_NARROW_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("MSC_NO_NARROW_TAIL", "1")
+        view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+        st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+        load_state(st, fs)
+        st.set_group_counts(counts.astype(np.uint32))
+        st.set_alpha(0.7)
+        got[narrow] = (st.score_value(view), st.score_value(view, z=zt, crp_prior=True), st.score_value(view, crp_prior=True))
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 16, 17, 20, 24, 31, 32, 33, 48, 64, 100, 128])
