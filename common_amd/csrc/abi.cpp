@@ -1718,6 +1718,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   bool has_dm = false;
   for (uint32_t f = 0; f < st->nfeat; f++) has_dm |= st->feats[f].family == MSC_DM;
   int rc = -2;
+  bool not_zeroed = false;
   ZeroSpans zero;
   if (zeroed) {
     zero.a = reinterpret_cast<unsigned long long *>(st->red_i64); zero.na = st->n_i64;
@@ -1746,8 +1747,37 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     } else if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
-    else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
-    if (zeroed) *zeroed = rc == 0;
+    else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr) {
+      // at most 128 groups on a plan of lookup + plain nich features: the lane <-> row kernel, whose cost follows the
+      // groups (a tile pass costs what 256 cost).  Up to 64: scores and draw in one launch, a lane draws its own row.
+      // Beyond: the scores into 128 floats per row, then the row sampler.  Whatever the row count (a shard draws what
+      // the whole draws).
+      TailPlan tail;
+      MSC_TRY(tail_plan(st, tail));
+      tail.exact = false;
+      if (st->K <= 64) {
+        rc = launch_sweep_rows(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
+                               z_dev, st->own, st->logpc, st->rng_dev, zero);
+        if (rc == 1) rc = -2;
+      } else {
+        const size_t need = ((size_t)nrows + 16) * 128;
+        if (st->tail_floats < need) {
+          void *p = nullptr;
+          MSC_HIP(hipMalloc(&p, need * sizeof(float)));
+          st->owned.push_back(p);
+          st->tail_scores = static_cast<float *>(p);
+          st->tail_floats = need;
+        }
+        rc = launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, 0, row0, nrows,
+                               z_dev, st->own, st->logpc, st->tail_scores, 128);
+        if (rc == 0) {
+          rc = launch_sample_rows(s, cus, st->tail_scores, 128, st->K, nrows, row_id0, z_dev, st->rng_dev);
+          not_zeroed = true;                              // (nothing emptied the additive tables on the way)
+        } else if (rc == 1) rc = -2;
+      }
+      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    if (zeroed) *zeroed = rc == 0 && !not_zeroed;
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
   // included) into 64 or 128 floats per row, then the fused kernel over the tile draws over both -- nothing materialised

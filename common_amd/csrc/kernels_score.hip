@@ -1021,12 +1021,22 @@ __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ 
   }
 }
 
-template <int TGP, bool SPLIT>
+// DRAW (a state of at most 64 groups, one launch, k0 = 0): nothing is stored -- a lane holds its row's whole score vector,
+// so it draws the row's new group by itself (maximum, exponentials, running sum against the dart: sample_discrete's CDF
+// order, no cross-lane step) and writes it to z; (seed, sweep) from `rng`, the uniform of global row row_id0 + r.
+template <int TGP, bool SPLIT, bool DRAW = false>
 __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
-    uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own, const float *__restrict__ crp,
-    float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows, uint32_t kend) {
+    uint64_t nrows, int32_t *z, const float *__restrict__ own, const float *__restrict__ crp,
+    float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows, uint32_t kend,
+    const uint64_t *__restrict__ rng, uint64_t row_id0, ZeroSpans zero) {
   // (groups [k0, kend) are this launch's; K is the table's: an id outside [0, K) is an unassigned row)
+  uint64_t seed = 0, sweep = 0;
+  if (DRAW) {
+    seed = rng[0];
+    sweep = rng[1];
+    zero_spans(zero);                                    // (the additive tables, for the accumulate pass that follows)
+  }
   extern __shared__ __attribute__((aligned(16))) float tl[];              // cap_rows x kTailStride
   // the prior of the tail's groups as a row starts from it / ends with it: [0] low halves, [1] the same for a row that is
   // its group's only member, [2] / [3] the high halves likewise -- a lane picks its pair of rows by address
@@ -1168,6 +1178,31 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
       }
     }
     const float *prh = pr[single ? 3 : 2];
+    if (DRAW) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < TGP; g++) {
+        const float sg = gown == g ? ownv : acc[g] + prh[g];
+        acc[g] = (uint32_t)g < K ? sg : -INFINITY;
+        m = fmaxf(m, acc[g]);
+      }
+      float total = 0.f;
+#pragma unroll
+      for (int g = 0; g < TGP; g++) {
+        acc[g] = __builtin_amdgcn_exp2f((acc[g] - m) * 1.44269504088896340736f);   // exp(-inf) = 0
+        total += acc[g];
+      }
+      const float dart = philox_uniform01(seed, sweep, row_id0 + r) * total;
+      float c = 0.f;
+      int pick = 0;
+#pragma unroll
+      for (int g = 0; g < TGP; g++) {
+        c += acc[g];
+        pick += c < dart ? 1 : 0;
+      }
+      if (has_row) z[r] = pick < (int)K ? pick : (int)K - 1;
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < TGP / 4; q++) {
       float sv[4];
@@ -1181,15 +1216,50 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
   }
 }
 
-template <int TGP, bool SPLIT>
+template <int TGP, bool SPLIT, bool DRAW = false>
 static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
-                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend) {
+                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
+                               const uint64_t *rng = nullptr, uint64_t row_id0 = 0, ZeroSpans zero = ZeroSpans()) {
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
-                     row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+                     row0, nrows, const_cast<int32_t *>(z), own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+}
+
+// the geometry the launches of one pass share; false: not for this kernel
+static bool tail_rows_geometry(const TailPlan &tp, int num_cus, int nfeat, int nsplit, uint64_t nrows, uint32_t &cap_rows, size_t &lds,
+                               unsigned &grid) {
+  if (!tp.ok || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return false;
+  // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
+  cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
+  lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
+  if (lds > 64u * 1024u) return false;                   // (more than 48 nich columns: the tile kernels keep the tile)
+  const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
+  const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
+  grid = (unsigned)std::min<uint64_t>(tchunks ? tchunks : 1, (uint64_t)num_cus * 2);
+  return true;
+}
+
+// a state of at most 64 groups: leave-one-out + prior scores and the draw in one launch of the lane <-> row kernel (own from
+// launch_loo_own; zero: the additive tables a sweep step wants emptied).  -> 0: launched; 1: not for this kernel
+int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                      uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own, const float *crp,
+                      const uint64_t *rng, ZeroSpans zero) {
+  uint32_t cap_rows = 0;
+  size_t lds = 0;
+  unsigned grid = 0;
+  if (K > 64 || crp == nullptr || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
+  if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, 0u, tp.pack);
+  const uint32_t tgp = (K + 15u) / 16u * 16u;
+#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
+  if (tgp == 16) MSC_SWEEP_ROWS(16);
+  else if (tgp == 32) MSC_SWEEP_ROWS(32);
+  else if (tgp == 48) MSC_SWEEP_ROWS(48);
+  else MSC_SWEEP_ROWS(64);
+#undef MSC_SWEEP_ROWS
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // -> 0: launched; 1: the groups are not for this kernel (the caller's tile kernels take them)
@@ -1198,15 +1268,11 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
                       float *out, uint64_t ld) {
   // up to kTailMaxGroups groups, at most 48 (two sums per group: 32 or 48 at four waves a SIMD) or 64 a launch -- a lane's
   // sums are its registers; beyond, the tile kernels keep the tile: three launches cost what a tile pass costs
-  if (!tp.ok || K <= k0 || K - k0 > kTailMaxGroups || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return 1;
-  // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
-  const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
-  const size_t lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
-  if (lds > 64u * 1024u) return 1;                       // (more than 48 nich columns: the tile kernels keep the tile)
+  uint32_t cap_rows = 0;
+  size_t lds = 0;
+  unsigned grid = 0;
+  if (K <= k0 || K - k0 > kTailMaxGroups || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
   if (nrows == 0) return 0;
-  const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
-  const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
-  const unsigned grid = (unsigned)std::min<uint64_t>(tchunks, (uint64_t)num_cus * 2);
   // launches of equal width: 44 groups = 48; 64 = 32 + 32 (48 + 16 measured 2 % slower); 128 = 48 + 48 + 32
   const uint32_t groups = K - k0, widest = tp.exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
   const uint32_t blk = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;

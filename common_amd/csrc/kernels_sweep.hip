@@ -17,21 +17,6 @@
 
 namespace msc {
 
-// ---- Philox-4x32-10 (Salmon et al. SC'11): uniform of (seed, sweep, global row) ----
-MSC_DEV float philox_uniform01(uint64_t seed, uint64_t sweep, uint64_t row) {
-  uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = (uint32_t)sweep, c3 = (uint32_t)(sweep >> 32);
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
-}
-
 // ---- wavefront primitives (64 lanes), on the DPP cross-lane path (no LDS traffic) ---------
 // row_shr:n shifts within each row of 16 lanes; row_bcast:15 / :31 carry the running value of
 // the previous row(s) into rows {1,3} / {2,3}.  Lanes without a source keep `identity`.
@@ -196,16 +181,6 @@ MSC_DEV int sample_tile_and_tail(const float (&sm)[4], const float (&st)[4], flo
   return k < (int)K ? k : (int)K - 1;
 }
 
-// the whole grid shares the zeroing of the additive tables (nothing in a sweep kernel reads them)
-MSC_DEV void zero_spans(const ZeroSpans &zs) {
-  const size_t n = zs.na + zs.nb;
-  if (n == 0) return;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (i < zs.na) zs.a[i] = 0ull;
-    else zs.b[i - zs.na] = 0ull;
-  }
-}
 
 // ---------------------------------------------------------------------------
 // (G = 16 asks for three waves per SIMD: at two the dependent transcendental chains of one wave pair leave the vector

@@ -76,11 +76,6 @@ struct TailPlan {
 int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp,
                       float *out, uint64_t ld);
-int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
-                 uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
-                 const float *own, const float *crp, float *out, uint64_t ld);
-
-// kernels_sweep.hip  (return -2: shape not covered by this kernel)
 // two runs of 8-byte words that a fused sweep kernel zeroes on its way (the additive tables, which the accumulate
 // pass that follows in a sweep step wants empty); all null / 0 when nothing follows
 struct ZeroSpans {
@@ -89,6 +84,15 @@ struct ZeroSpans {
   unsigned long long *b = nullptr;
   size_t nb = 0;
 };
+// (kernels_score.hip: the lane <-> row kernel with the draw in it)
+int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                      uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own, const float *crp,
+                      const uint64_t *rng, ZeroSpans zero);
+int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
+                 uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
+                 const float *own, const float *crp, float *out, uint64_t ld);
+
+// kernels_sweep.hip  (return -2: shape not covered by this kernel)
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);

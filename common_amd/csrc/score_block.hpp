@@ -19,6 +19,7 @@
 
 #include "device_error.hpp"
 #include "family_math.hpp"
+#include "launchers.hpp"
 
 namespace msc {
 
@@ -529,6 +530,33 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nspli
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], accn[r]);
     }
+  }
+}
+
+// ---- what the kernels that draw share (kernels_sweep.hip, and the lane <-> row kernel of kernels_score.hip) ----
+// ---- Philox-4x32-10 (Salmon et al. SC'11): uniform of (seed, sweep, global row) ----
+MSC_DEV float philox_uniform01(uint64_t seed, uint64_t sweep, uint64_t row) {
+  uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = (uint32_t)sweep, c3 = (uint32_t)(sweep >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+// the whole grid shares the zeroing of the additive tables (nothing in a sweep kernel reads them)
+MSC_DEV void zero_spans(const ZeroSpans &zs) {
+  const size_t n = zs.na + zs.nb;
+  if (n == 0) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (i < zs.na) zs.a[i] = 0ull;
+    else zs.b[i - zs.na] = 0ull;
   }
 }
 

@@ -530,3 +530,68 @@ def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K
         parts[lo:lo + n] = zs
     assert torch.equal(whole, parts)
     assert (whole.cpu().numpy() != zz).mean() > 0.05
+
+
+ROWS_PLANS = {
+    # (tables too large for the K <= 64 narrow tiling's LDS: these states are the lane <-> row kernel's)
+    "mixed": [(orc.DD, 60), (orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 64), (orc.NICH, 0), (orc.DD, 50), (orc.DD, 61),
+              (orc.BBNC, 0), (orc.DD, 33)],
+    "lookups_only": [(orc.DD, 64)] * 5 + [(orc.GP, 0)],
+    "many_stages": [(orc.DD, 60)] * 9 + [(orc.NICH, 0)] * 9,
+}
+
+
+@pytest.mark.parametrize("plan", sorted(ROWS_PLANS))
+@pytest.mark.parametrize("K,empty", [(2, 0), (5, 1), (17, 3), (33, 0), (48, 9), (64, 2), (65, 0), (100, 20), (128, 1)])
+def test_sweep_on_the_lane_row_kernel_matches_oracle_and_its_shards(gpu_ctx, plan, K, empty):
+    """A state of at most 128 groups on a plan of lookup + plain nich features sweeps on the lane <-> row kernel whatever
+    the row count: up to 64 groups a lane scores its row against every group and draws by itself (k_score_tail_rows<.,
+    false, true>: 16 / 32 / 48 / 64 sums a lane), beyond that the scores go through 128 floats per row to the row sampler.
+    Against the oracle's sweep (every disagreeing draw on a CDF step), empty groups on offer; unassigned rows draw too; the
+    same sweep in three shards draws the same assignments; and the sweep step's tables equal an accumulate over the result."""
+    _rows_sweep_case(gpu_ctx, ROWS_PLANS[plan], K, empty)
+
+
+def test_sweep_on_the_lane_row_kernel_sixteen_sums(gpu_ctx):
+    """(12 groups and more table rows than the narrow tiling's LDS holds even then: the kernel's narrowest instantiation)"""
+    _rows_sweep_case(gpu_ctx, [(orc.DD, 64)] * 17 + [(orc.NICH, 0)], 12, 2)
+
+
+def _rows_sweep_case(gpu_ctx, specs, K, empty):
+    import common_amd
+    got, want, scores, z = _run(gpu_ctx, specs, 2000, K, seed=70 + K, sweep_idx=1, alpha=1.1, empty=empty)
+    _check_agreement(got, want, scores, 70 + K, 1, 0.995)
+    rng = np.random.default_rng(K)
+    N = 9_000
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    zz = rng.integers(0, max(1, K - empty), N).astype(np.int32)
+    zz[5] = -1
+    fs = state_from_assignment(feats, K, zz)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(zz[zz >= 0], minlength=K).astype(np.uint32))
+    st.set_alpha(1.1)
+    whole = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, whole, seed=9, sweep=1)
+    parts = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=9, sweep=1, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
+    w = whole.cpu().numpy()
+    assert w.min() >= 0 and w.max() < K and (K == 1 or (w != zz).mean() > 0.05)
+    # a whole step (draw, then the tables rebuilt from the new assignment) against accumulate over the same assignment
+    zs = torch.from_numpy(np.where(zz < 0, 0, zz)).to(gpu_ctx.torch_device)
+    st.accumulate(view, zs)
+    st.sweep_step(view, zs, seed=4, sweep=0)
+    ref = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    ref.accumulate(view, zs)
+    assert np.array_equal(st.get_group_counts(), ref.get_group_counts())
+    assert np.array_equal(st.get_group_counts(), np.bincount(zs.cpu().numpy(), minlength=K))
+    for f in range(len(specs)):
+        a, b = st.get_ss(f), ref.get_ss(f)
+        for name in a.dtype.names:
+            if name != "p":                                     # (bbnc's group parameter is the state's own, not a sum over rows)
+                assert np.array_equal(a[name], b[name]), (f, name)
