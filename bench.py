@@ -537,6 +537,27 @@ def extra_c3(a, torch, common_amd, ctx):
     w, savg, smn = timed(torch, one, max(3, steps // 2), 1)
     r["sweep_ms"] = savg
     r["sweep_rows_per_s"] = N / (savg * 1e-3)
+    # the same columns at other table sizes (a CRP table is not a multiple of 256): at most 128 groups and the groups
+    # beyond a tile up to 384 run on the lane <-> row kernel (k_score_tail_rows), whose cost follows the groups
+    del out, st
+    other = []
+    for k in (32, 128, 300):
+        z2 = z % k
+        s2 = common_amd.State(ctx, spec, k)
+        s2.set_alpha(1.0)
+        s2.accumulate(view, z2)
+        o2 = torch.empty((N, k), dtype=torch.float32, device=ctx.torch_device)
+        _, sc_avg, _ = timed(torch, lambda: s2.score_value(view, out=o2), max(3, steps // 2), 2)
+        zz, it = z2.clone(), [0]
+
+        def step():
+            s2.sweep_step(view, zz, seed=73, sweep=it[0])
+            it[0] += 1
+        _, sw_avg, _ = timed(torch, step, max(3, steps // 2), 2)
+        other.append({"K": k, "score_ms": sc_avg, "sweep_ms": sw_avg, "evals_per_s": float(N) * k * len(spec) / (sc_avg * 1e-3),
+                      "sweep_rows_per_s": N / (sw_avg * 1e-3)})
+        del o2, s2
+    r["other_table_sizes"] = other
     return r
 
 
