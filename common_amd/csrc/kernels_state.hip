@@ -95,19 +95,54 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
     if (scalar_col && fd.mask == nullptr) {
       // an unmasked scalar column: U (group, value) pairs per thread go out together before the first LDS atomic
       const bool u8 = fd.family == MSC_BB || fd.family == MSC_BBNC;
+      // four consecutive rows a load where the addresses allow (16 bytes of z, 16 or 4 of the column): a quarter of the
+      // memory instructions for the same bytes (sixteen bb columns alone 50 -> 35 us; fetching the next batch ahead of
+      // this batch's atomics, tried on top, nearly doubled every family's time)
+      const bool vec4 = hi - lo >= 4 && ((lo | row0) & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(fd.col) & 15) == 0;
       for (uint64_t base = lo; base < hi; base += (uint64_t)U * nt) {
         int g[U];
         uint32_t w[U];
+        if (vec4) {
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-          const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
-          g[j] = n < hi ? z[n] : -1;
-        }
+          for (int j = 0; j < U / 4; j++) {
+            const uint64_t n = base + 4 * ((uint64_t)threadIdx.x + (uint64_t)j * nt);
+            const bool whole = n + 3 < hi;
+            const uint64_t ns = whole ? n : lo;                   // (a whole quad of the slice; a partial last quad is redone below)
+            const int4 zq = *reinterpret_cast<const int4 *>(z + ns);
+            uint32_t q0, q1, q2, q3;
+            if (u8) {
+              const uint32_t b = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(fd.col) + row0 + ns);
+              q0 = b & 0xffu; q1 = (b >> 8) & 0xffu; q2 = (b >> 16) & 0xffu; q3 = b >> 24;
+            } else {
+              const uint4 b = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(fd.col) + row0 + ns);
+              q0 = b.x; q1 = b.y; q2 = b.z; q3 = b.w;
+            }
+            g[4 * j] = whole ? zq.x : -1; g[4 * j + 1] = whole ? zq.y : -1; g[4 * j + 2] = whole ? zq.z : -1; g[4 * j + 3] = whole ? zq.w : -1;
+            w[4 * j] = q0; w[4 * j + 1] = q1; w[4 * j + 2] = q2; w[4 * j + 3] = q3;
+            if (!whole && n < hi) {                                // the slice's last, partial quad: row by row
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-          const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
-          const uint64_t row = row0 + (n < hi ? n : lo);           // (a row of the slice whatever this thread's share is)
-          w[j] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row] : reinterpret_cast<const uint32_t *>(fd.col)[row];
+              for (int c = 0; c < 4; c++) {
+                const uint64_t m = n + c;
+                if (m < hi) {
+                  g[4 * j + c] = z[m];
+                  w[4 * j + c] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row0 + m] : reinterpret_cast<const uint32_t *>(fd.col)[row0 + m];
+                }
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
+            g[j] = n < hi ? z[n] : -1;
+          }
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            const uint64_t n = base + threadIdx.x + (uint64_t)j * nt;
+            const uint64_t row = row0 + (n < hi ? n : lo);           // (a row of the slice whatever this thread's share is)
+            w[j] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row] : reinterpret_cast<const uint32_t *>(fd.col)[row];
+          }
         }
 #pragma unroll
         for (int j = 0; j < U; j++) {
@@ -651,6 +686,8 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
     slices = 65535;
     per = (nrows + slices - 1) / slices;
   }
+  per = (per + 3) / 4 * 4;                                 // (slices start on a multiple of four rows: 16-byte loads)
+  slices = std::max<uint64_t>(1, (nrows + per - 1) / per);
   // small histograms: 256-thread workgroups, several per CU; large ones (many groups) keep 1024 threads to zero and
   // flush their bins
   const unsigned threads = lds <= 40u * 1024u ? 256u : 1024u;

@@ -47,6 +47,40 @@ def test_accumulate_matches_sequential_add_value(gpu_ctx, K):
     assert np.array_equal(st.get_group_counts(), want_cnt)
 
 
+@pytest.mark.parametrize("row0,n", [(0, 1), (0, 3), (4, 4), (8, 5), (1, 4099), (2, 8190), (3, 6), (4096, 9001), (12, 16384 + 7)])
+def test_accumulate_row_ranges_of_any_alignment(gpu_ctx, row0, n):
+    """the row loop of k_accumulate takes four consecutive rows a load where the range starts on a multiple of four rows
+    (and z is 16-byte aligned), row by row otherwise and for a partial last quad: ranges of every alignment and length,
+    z passed at its own offset, integer tables bit-exact against numpy"""
+    import common_amd
+    rng = np.random.default_rng(row0 * 131 + n)
+    N, K = 26_000, 37
+    specs = [(orc.BB, 0), (orc.GP, 0), (orc.DD, 9), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(-1, K, N).astype(np.int32)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    for zarg in (zt[row0:row0 + n].contiguous(), zt[row0:row0 + n]):      # its own allocation; a view at a 4-byte offset
+        st.accumulate(view, zarg, row0=row0, nrows=n)
+        zz = z[row0:row0 + n]
+        ok = zz >= 0
+        assert np.array_equal(st.get_group_counts(), np.bincount(zz[ok], minlength=K))
+        sl = slice(row0, row0 + n)
+        bb = st.get_ss(0)
+        v = feats[0]["values"][sl][ok]
+        assert np.array_equal(bb["heads"], np.bincount(zz[ok][v], minlength=K))
+        assert np.array_equal(bb["tails"], np.bincount(zz[ok][~v], minlength=K))
+        gp = st.get_ss(1)
+        assert np.array_equal(gp["sum"], np.bincount(zz[ok], weights=feats[1]["values"][sl][ok], minlength=K).astype(np.uint64))
+        dd = st.get_ss(2)
+        want = np.zeros((K, 9), dtype=np.int64)
+        np.add.at(want, (zz[ok], feats[2]["values"][sl][ok]), 1)
+        assert np.array_equal(np.asarray(dd["counts"]).reshape(K, -1)[:, :9], want)
+        nich = st.get_ss(3)
+        assert np.array_equal(nich["count"], np.bincount(zz[ok], minlength=K))
+
+
 def test_incremental_add_then_remove_rows(gpu_ctx):
     import common_amd
     rng = np.random.default_rng(4)
