@@ -687,13 +687,18 @@ static void plan_groups(msc_state *st) {
   // the narrow kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase (what it
   // implements), whatever the second holds of plain nich features
   st->tile_narrow_tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
-  for (uint32_t i = 0; i < split; i++) st->tile_narrow_tail_ok &= t[i].kind != MSC_KIND_GENERIC;
+  // (a masked nich column among them is evaluated like the second phase's features, under the row's mask)
+  for (uint32_t i = 0; i < split; i++)
+    st->tile_narrow_tail_ok &= t[i].kind != MSC_KIND_GENERIC || (t[i].family == MSC_NICH && t[i].mask != nullptr && t[i].col != nullptr);
   for (uint32_t i = split; i < n; i++) st->tile_narrow_tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
   st->tail_max_rows = st->tail_pack_rows = 0;
+  st->tail_masked_nich = false;
   if (st->tile_narrow_tail_ok)
     for (uint32_t i = 0; i < split; i++) {
-      st->tail_max_rows = std::max(st->tail_max_rows, t[i].run_clamp + 1);
-      st->tail_pack_rows += t[i].run_clamp + 1;
+      const uint32_t rows = t[i].kind == MSC_KIND_GENERIC ? 0u : t[i].run_clamp + 1;
+      st->tail_masked_nich |= t[i].kind == MSC_KIND_GENERIC;
+      st->tail_max_rows = std::max(st->tail_max_rows, rows);
+      st->tail_pack_rows += rows;
     }
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];
@@ -1333,6 +1338,7 @@ static int tail_plan(msc_state *st, TailPlan &tp) {
     st->tail_pack_floats = need;
   }
   tp.ok = true;
+  tp.masked_nich = st->tail_masked_nich;
   tp.max_rows = st->tail_max_rows;
   tp.pack_rows = st->tail_pack_rows;
   tp.pack = st->tail_pack;

@@ -1008,13 +1008,19 @@ const Nich1Shape kNich1Shapes[kNich1NumShapes] = {{4, 2}, {4, 1}, {4, 4}, {4, 6}
 constexpr int kTailRowsWaves = 8;                     // 512 rows per workgroup visit
 constexpr uint32_t kTailStride = 65;                   // floats per staged table row (64 groups + 1)
 
+// table rows a first-phase feature brings to the slot: a lookup feature's selectable rows; none for a masked nich column
+// (the one generic kind the plan admits there: evaluated like the second phase's, under the row's mask)
+__host__ __device__ inline uint32_t tail_table_rows(uint32_t kind, uint32_t run_clamp) {
+  return kind == MSC_KIND_GENERIC ? 0u : run_clamp + 1;
+}
+
 __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ feats, uint32_t kpad, uint32_t k0,
                                                     float *__restrict__ pack) {
   const int f = blockIdx.x;
   uint32_t off = 0;
-  for (int i = 0; i < f; i++) off += feats[i].run_clamp + 1;
+  for (int i = 0; i < f; i++) off += tail_table_rows(feats[i].kind, feats[i].run_clamp);
   const FeatDesc &fd = feats[f];
-  const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u, rows = fd.run_clamp + 1;
+  const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u, rows = tail_table_rows(fd.kind, fd.run_clamp);
   for (uint32_t e = threadIdx.x; e < rows * 64u; e += 256u) {
     const uint32_t r = e >> 6, g = e & 63u;
     pack[(size_t)(off + r) * 64 + g] = fd.tab[(size_t)(first_row + r) * kpad + k0 + g];      // (k0 + 63 < kpad)
@@ -1024,8 +1030,9 @@ __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ 
 // DRAW (a state of at most 64 groups, one launch, k0 = 0): nothing is stored -- a lane holds its row's whole score vector,
 // so it draws the row's new group by itself (maximum, exponentials, running sum against the dart: sample_discrete's CDF
 // order, no cross-lane step) and writes it to z; (seed, sweep) from `rng`, the uniform of global row row_id0 + r.
-template <int TGP, bool SPLIT, bool DRAW = false>
-__global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
+// MNICH: the first phase may hold masked nich columns (an instantiation of its own: the branch costs the others registers)
+template <int TGP, bool SPLIT, bool DRAW = false, bool MNICH = false>
+__global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
     uint64_t nrows, int32_t *z, const float *__restrict__ own, const float *__restrict__ crp,
     float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows, uint32_t kend,
@@ -1113,7 +1120,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
           off = 0;
           uint32_t rows = 0;
           while (stage_end < nsplit) {
-            const uint32_t rw = feats[stage_end].run_clamp + 1;
+            const uint32_t rw = tail_table_rows(feats[stage_end].kind, feats[stage_end].run_clamp);
             if (rows + rw > cap_rows && rows > 0) break;       // (the launcher sizes the slot for the largest table)
             rows += rw;
             stage_end++;
@@ -1126,13 +1133,35 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
           }
           __syncthreads();
         }
-        const uint32_t rc = feats[f].run_clamp;
-        const int v = (int)w0;
-        const uint32_t idx = v < 0 ? 0u : ((uint32_t)v > rc ? rc : (uint32_t)v);
-        const float *b = tl + (size_t)(off + idx) * kTailStride;
+        if (MNICH && feats[f].kind == MSC_KIND_GENERIC) {
+          // a masked nich column, in the caller's place among the lookups: acc += nich_eval(...) unless the row's value is
+          // masked (add_feature's generic branch, the same bits); constants as scalar operands, four groups at a time
+          const bool masked = feats[f].mask[rr] != 0;
+          const float x = __uint_as_float(w0);
+          const scalar_f tab = (scalar_f)(feats[f].tab) + k0;
+          typedef float f32x4s __attribute__((ext_vector_type(4)));
+          typedef const volatile __attribute__((address_space(4))) f32x4s *scalar_f4;
 #pragma unroll
-        for (int g = 0; g < TGP; g++) acc[g] += b[g];
-        off += rc + 1;
+          for (int gb = 0; gb < TGP; gb += 4) {
+            const f32x4s mh = *(scalar_f4)(tab + (size_t)NICH_MU_HI * kpad + gb), ml = *(scalar_f4)(tab + (size_t)NICH_MU_LO * kpad + gb),
+                         c0 = *(scalar_f4)(tab + (size_t)NICH_C0 * kpad + gb), c1l = *(scalar_f4)(tab + (size_t)NICH_C1LN2 * kpad + gb),
+                         c1 = *(scalar_f4)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_f4)(tab + (size_t)NICH_C2 * kpad + gb);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float e = acc[gb + j] + nich_eval(x, mh[j], ml[j], c0[j], c1l[j], c1[j], c2[j]);
+              acc[gb + j] = masked ? acc[gb + j] : e;
+            }
+            __builtin_amdgcn_sched_barrier(0);               // (four evaluations' temporaries at a time)
+          }
+        } else {
+          const uint32_t rc = feats[f].run_clamp;
+          const int v = (int)w0;
+          const uint32_t idx = v < 0 ? 0u : ((uint32_t)v > rc ? rc : (uint32_t)v);
+          const float *b = tl + (size_t)(off + idx) * kTailStride;
+#pragma unroll
+          for (int g = 0; g < TGP; g++) acc[g] += b[g];
+          off += rc + 1;
+        }
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;    // (the batch's values pass through w0: no indexed register)
       }
     }
@@ -1216,22 +1245,30 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, 4) void k_score_tail_rows(
   }
 }
 
+template <int TGP, bool SPLIT, bool DRAW, bool MNICH>
+static void launch_tail_rows_m(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+                               uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
+                               const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
+                               const uint64_t *rng, uint64_t row_id0, ZeroSpans zero) {
+  static unsigned long long attr_devices = 0;
+  if (first_use_on_device(attr_devices))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW, MNICH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW, MNICH>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+                     row0, nrows, const_cast<int32_t *>(z), own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+}
 template <int TGP, bool SPLIT, bool DRAW = false>
-static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, bool mnich, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
                                const uint64_t *rng = nullptr, uint64_t row_id0 = 0, ZeroSpans zero = ZeroSpans()) {
-  static unsigned long long attr_devices = 0;
-  if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
-                     row0, nrows, const_cast<int32_t *>(z), own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  if (mnich) launch_tail_rows_m<TGP, SPLIT, DRAW, true>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  else launch_tail_rows_m<TGP, SPLIT, DRAW, false>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
 }
 
 // the geometry the launches of one pass share; false: not for this kernel
 static bool tail_rows_geometry(const TailPlan &tp, int num_cus, int nfeat, int nsplit, uint64_t nrows, uint32_t &cap_rows, size_t &lds,
                                unsigned &grid) {
-  if (!tp.ok || (nsplit > 0 && tp.pack == nullptr) || tp.max_rows > 200) return false;
+  if (!tp.ok || (tp.pack_rows > 0 && tp.pack == nullptr) || tp.max_rows > 200) return false;
   // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
   cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
   lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
@@ -1253,7 +1290,7 @@ int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const
   if (K > 64 || crp == nullptr || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
   if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, 0u, tp.pack);
   const uint32_t tgp = (K + 15u) / 16u * 16u;
-#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
+#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
   if (tgp == 16) MSC_SWEEP_ROWS(16);
   else if (tgp == 32) MSC_SWEEP_ROWS(32);
   else if (tgp == 48) MSC_SWEEP_ROWS(48);
@@ -1280,7 +1317,7 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
     const uint32_t kend = std::min<uint32_t>(K, kb + blk), tgp = (kend - kb + 15u) / 16u * 16u;
     // (the packed tables are this launch's: the stream orders the next block's k_tail_pack behind it)
     if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, kb, tp.pack);
-#define MSC_TAIL_ROWS(T, S) launch_tail_rows_t<T, S>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
+#define MSC_TAIL_ROWS(T, S) launch_tail_rows_t<T, S>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
     if (tp.exact) {
       if (tgp == 16) MSC_TAIL_ROWS(16, true);
       else if (tgp == 32) MSC_TAIL_ROWS(32, true);
