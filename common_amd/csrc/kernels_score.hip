@@ -1268,11 +1268,14 @@ static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, bo
 // the geometry the launches of one pass share; false: not for this kernel
 static bool tail_rows_geometry(const TailPlan &tp, int num_cus, int nfeat, int nsplit, uint64_t nrows, uint32_t &cap_rows, size_t &lds,
                                unsigned &grid) {
-  if (!tp.ok || (tp.pack_rows > 0 && tp.pack == nullptr) || tp.max_rows > 200) return false;
-  // the slot: up to 200 table rows (52 KiB; with the nich features' block two workgroups a CU)
-  cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, 200u));
-  lds = ((size_t)cap_rows * kTailStride + (size_t)(nfeat - nsplit) * 64) * sizeof(float);
-  if (lds > 64u * 1024u) return false;                   // (more than 48 nich columns: the tile kernels keep the tile)
+  if (!tp.ok || (tp.pack_rows > 0 && tp.pack == nullptr)) return false;
+  // the slot: up to 200 table rows (52 KiB) in what 64 KiB leave beside the second phase's block (64 floats a nich
+  // feature) -- two workgroups a CU; it must hold the largest table
+  const size_t nich_bytes = (size_t)(nfeat - nsplit) * 64 * sizeof(float);
+  if (nich_bytes + (size_t)std::max<uint32_t>(1u, tp.max_rows) * kTailStride * sizeof(float) > 64u * 1024u) return false;
+  const uint32_t fit = (uint32_t)((64u * 1024u - nich_bytes) / (kTailStride * sizeof(float)));
+  cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(tp.pack_rows, std::min<uint32_t>(200u, fit)));
+  lds = (size_t)cap_rows * kTailStride * sizeof(float) + nich_bytes;
   const uint64_t rows_wg = (uint64_t)kTailRowsWaves * 64;
   const uint64_t tchunks = (nrows + rows_wg - 1) / rows_wg;
   grid = (unsigned)std::min<uint64_t>(tchunks ? tchunks : 1, (uint64_t)num_cus * 2);

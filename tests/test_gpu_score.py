@@ -227,6 +227,7 @@ TAIL_PLANS = {
     "lookups_only": [(orc.BB, 0), (orc.DD, 12), (orc.GP, 0)],
     "nich_only": [(orc.NICH, 0), (orc.NICH, 0), (orc.NICH, 0)],
     "many_stages": [(orc.DD, 60)] * 9 + [(orc.NICH, 0)] * 9,      # 540 table rows: three stages of the kernel's slot; two value batches
+    "many_nich": [(orc.DD, 60), (orc.GP, 0)] + [(orc.NICH, 0)] * 70,   # the second phase's block takes 17.5 KiB of the slot's 64
 }
 
 
@@ -240,6 +241,8 @@ def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
     singleton tail group, an empty tail group and an unassigned row included; a row range of few rows (row0 > 0) -- which
     the tile kernels score -- gives the same bits as the whole."""
     import common_amd
+    if plan == "many_nich" and K not in (100, 300):
+        pytest.skip("the wide plan at two table sizes")
     N = 17_000
     rng = np.random.default_rng(K + len(plan))
     specs = TAIL_PLANS[plan]
