@@ -622,8 +622,17 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
 // (and an inner loop) of their own.  (Float addition order follows this plan, not the caller's feature order.)
 // Consecutive features are packed into groups whose table blocks fit the LDS slot together: greedy, at most
 // kGrpRows rows per group, never across the two phases.
-static void plan_groups(msc_state *st) {
+// what the choice of kernels depends on, for one plan
+struct PlanFacts {
+  bool roles_ok = false, tail_ok = false, tail_masked_nich = false;
+  uint32_t tail_max_rows = 0, tail_pack_rows = 0;
+};
+
+// group packing, lookup kinds and runs of a plan `t` whose first `split` entries are the first phase (`extra`: one more
+// table row for a masked lookup column's zero row)
+static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std::vector<uint32_t> &extra) {
   auto rows_of = [](const FeatDesc &d) -> uint32_t {
+    if (d.fuse_n >= 2) return 1u << d.fuse_n;
     switch (d.family) {
       case MSC_BB:
       case MSC_BBNC: return 2;
@@ -637,22 +646,7 @@ static void plan_groups(msc_state *st) {
       default: return 0;
     }
   };
-  auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
-  std::vector<FeatDesc> &t = st->desc_tile_host;
-  t.clear();
-  for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
-  st->tile_split = (uint32_t)t.size();
-  for (const FeatDesc &d : st->desc_host) if (nich_tail(d)) t.push_back(d);
-  // masked lookup columns: the tile plan reads the copy with the mask folded in (bind_view) and sees no mask -- a masked
-  // value selects the table's zero row, which the feature stages with the others (one more row: `extra`)
-  std::vector<uint32_t> extra(t.size(), 0u);
-  for (size_t i = 0; i < t.size(); i++)
-    if (t[i].mask != nullptr && t[i].col_sentinel != nullptr) {
-      t[i].col = t[i].col_sentinel;
-      t[i].mask = nullptr;
-      extra[i] = 1;
-    }
-  const uint32_t n = st->nfeat, split = st->tile_split;
+  const uint32_t n = (uint32_t)t.size();
   uint32_t f = 0;
   while (f < n) {
     const uint32_t limit = f < split ? split : n;
@@ -661,6 +655,11 @@ static void plan_groups(msc_state *st) {
       t[g].grp_off = used;
       t[g].grp_rows = rows_of(t[g]) + extra[g];
       used += t[g].grp_rows;
+      g++;
+    }
+    if (g == f) {                                           // (a block larger than the slot: a group of its own, nothing staged)
+      t[g].grp_off = 0;
+      t[g].grp_rows = 0;
       g++;
     }
     for (uint32_t i = f; i < g; i++) t[i].grp_end = g;
@@ -673,38 +672,78 @@ static void plan_groups(msc_state *st) {
     d.kind = MSC_KIND_GENERIC;
     if (d.mask != nullptr || d.col == nullptr || d.grp_rows == 0) continue;
     // (run_clamp: the largest row a value may select -- with the mask folded in that is the zero row)
-    if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = 1 + extra[i];
+    if (d.fuse_n >= 2) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = d.grp_rows - 1;
+    else if (d.family == MSC_BB || d.family == MSC_BBNC) d.kind = MSC_KIND_LOOKUP_U8, d.run_clamp = 1 + extra[i];
     else if ((d.family == MSC_GP || d.family == MSC_BNB) && d.grp_rows >= d.vcap + extra[i]) d.kind = MSC_KIND_LOOKUP_U32, d.run_clamp = d.grp_rows - 1;
     else if (d.family == MSC_DD && d.grp_rows >= d.dim + extra[i]) d.kind = MSC_KIND_LOOKUP_I32, d.run_clamp = d.dim - 1 + extra[i];
   }
+  PlanFacts pf;
   bool has_dm = false;
-  st->tile_roles_ok = split > 0 && split < n;
+  pf.roles_ok = split > 0 && split < n;
   for (uint32_t i = 0; i < n; i++) {
     has_dm |= t[i].family == MSC_DM;
-    if (i < split && t[i].kind == MSC_KIND_GENERIC) st->tile_roles_ok = false;
+    if (i < split && t[i].kind == MSC_KIND_GENERIC) pf.roles_ok = false;
   }
-  if (has_dm) st->tile_roles_ok = false;
-  // the narrow kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase (what it
-  // implements), whatever the second holds of plain nich features
-  st->tile_narrow_tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
+  if (has_dm) pf.roles_ok = false;
+  // the lane <-> row kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase
+  // (what it implements), whatever the second holds of plain nich features
+  pf.tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
   // (a masked nich column among them is evaluated like the second phase's features, under the row's mask)
   for (uint32_t i = 0; i < split; i++)
-    st->tile_narrow_tail_ok &= t[i].kind != MSC_KIND_GENERIC || (t[i].family == MSC_NICH && t[i].mask != nullptr && t[i].col != nullptr);
-  for (uint32_t i = split; i < n; i++) st->tile_narrow_tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
-  st->tail_max_rows = st->tail_pack_rows = 0;
-  st->tail_masked_nich = false;
-  if (st->tile_narrow_tail_ok)
+    pf.tail_ok &= t[i].kind != MSC_KIND_GENERIC || (t[i].family == MSC_NICH && t[i].mask != nullptr && t[i].col != nullptr);
+  for (uint32_t i = split; i < n; i++) pf.tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
+  if (pf.tail_ok)
     for (uint32_t i = 0; i < split; i++) {
       const uint32_t rows = t[i].kind == MSC_KIND_GENERIC ? 0u : t[i].run_clamp + 1;
-      st->tail_masked_nich |= t[i].kind == MSC_KIND_GENERIC;
-      st->tail_max_rows = std::max(st->tail_max_rows, rows);
-      st->tail_pack_rows += rows;
+      pf.tail_masked_nich |= t[i].kind == MSC_KIND_GENERIC;
+      pf.tail_max_rows = std::max(pf.tail_max_rows, rows);
+      pf.tail_pack_rows += rows;
     }
   for (uint32_t i = n; i-- > 0;) {
     FeatDesc &d = t[i];
     if (d.kind == MSC_KIND_GENERIC) d.run_end = i;
     else d.run_end = (i + 1 < d.grp_end && t[i + 1].kind != MSC_KIND_GENERIC) ? t[i + 1].run_end : i + 1;
   }
+  return pf;
+}
+
+// the byte column holding the bits of m bool columns (kept by the view: every state that fuses the same columns shares it)
+static int packed_column(const msc_dataview *view, const void *const *cols, int m, const void **out) {
+  const std::vector<const void *> key(cols, cols + m);
+  for (const auto &e : view->packed_bits)
+    if (e.first == key) {
+      *out = e.second;
+      return MSC_OK;
+    }
+  void *dst = nullptr;
+  MSC_HIP(hipMalloc(&dst, std::max<size_t>(1, (size_t)view->nrows)));
+  view->owned_lazy.push_back(dst);
+  if (launch_pack_bits(view->ctx->stream, cols, m, view->nrows, dst)) return fail(MSC_EHIP, "k_pack_bits launch failed");
+  view->packed_bits.emplace_back(key, dst);
+  *out = dst;
+  return MSC_OK;
+}
+
+static int plan_groups(msc_state *st) {
+  auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
+  std::vector<FeatDesc> &t = st->desc_tile_host;
+  t.clear();
+  for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
+  st->tile_split = (uint32_t)t.size();
+  for (const FeatDesc &d : st->desc_host) if (nich_tail(d)) t.push_back(d);
+  // masked lookup columns: the tile plan reads the copy with the mask folded in (bind_view) and sees no mask -- a masked
+  // value selects the table's zero row, which the feature stages with the others (one more row: `extra`)
+  std::vector<uint32_t> extra(t.size(), 0u);
+  for (size_t i = 0; i < t.size(); i++) {
+    t[i].fuse_n = 0;
+    if (t[i].mask != nullptr && t[i].col_sentinel != nullptr) {
+      t[i].col = t[i].col_sentinel;
+      t[i].mask = nullptr;
+      extra[i] = 1;
+    }
+  }
+  const uint32_t n = st->nfeat, split = st->tile_split;
+  PlanFacts facts = plan_layout(t, split, extra);
   // The leave-one-out pass (k_loo_own_lds) stages what a row gathers per feature -- the lookup families' "value against
   // the group minus one" tables, nich's twelve doubles per group -- for ALL kpad groups (a row's own group is any of
   // them): consecutive features share the 64 KiB slot while their blocks fit; a feature whose block does not fit, or
@@ -729,13 +768,86 @@ static void plan_groups(msc_state *st) {
     for (uint32_t i = f0; i < g; i++) t[i].loo_stage_end = g;
     f0 = g;
   }
+  // The score / sweep kernels' plan: the unmasked bb / bbnc columns of the first phase come first, fused four (three, two)
+  // at a time -- one byte column of the members' bits, one table of 2^m rows (FeatDesc::fuse_*; k_fuse_tables fills the
+  // tables at the head of a call) -- then the other first-phase features in the caller's order, then the second phase.
+  // A quarter of the LDS reads and additions for the same sum; the order and the association of the terms --
+  // ((t0 + t1) + t2) + t3 per fused feature -- are the same in every kernel that walks this plan.  The leave-one-out
+  // pass walks the plan above.
+  std::vector<FeatDesc> &tf = st->desc_fuse_host;
+  std::vector<uint32_t> extra_f;
+  tf.clear();
+  const bool may_fuse = st->bound_view != nullptr && std::getenv("MSC_NO_BB_FUSE") == nullptr;
+  std::vector<uint32_t> members;                           // the fusable features, in plan order
+  for (uint32_t i = 0; i < split; i++) {
+    const FeatDesc &d = t[i];
+    if (may_fuse && (d.family == MSC_BB || d.family == MSC_BBNC) && d.kind == MSC_KIND_LOOKUP_U8 && extra[i] == 0 &&
+        d.mask == nullptr && d.col != nullptr && d.tab != nullptr)
+      members.push_back(i);
+  }
+  if (members.size() < 2) members.clear();
+  std::vector<uint32_t> quad_sizes;
+  for (size_t left = members.size(); left >= 2;) {
+    const uint32_t m = left == 5 ? 3u : (uint32_t)std::min<size_t>(4, left);       // (never a single one left over)
+    quad_sizes.push_back(m);
+    left -= m;
+  }
+  const size_t need = quad_sizes.size() * 16 * (size_t)st->kpad;
+  if (st->fuse_tab_floats < need) {
+    void *p = nullptr;
+    MSC_HIP(hipMalloc(&p, need * sizeof(float)));
+    st->owned.push_back(p);
+    st->fuse_tab = static_cast<float *>(p);
+    st->fuse_tab_floats = need;
+  }
+  std::vector<bool> taken(n, false);
+  size_t at = 0;
+  for (size_t q = 0; q < quad_sizes.size(); q++) {
+    const uint32_t m = quad_sizes[q];
+    FeatDesc d = t[members[at]];
+    const void *cols[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (uint32_t j = 0; j < 4; j++) d.fuse_src[j] = nullptr;
+    for (uint32_t j = 0; j < m; j++) {
+      const FeatDesc &mj = t[members[at + j]];
+      cols[j] = mj.col;
+      d.fuse_src[j] = mj.tab;
+      taken[members[at + j]] = true;
+    }
+    MSC_TRY(packed_column(st->bound_view, cols, (int)m, &d.col));
+    d.fuse_n = m;
+    d.col_type = MSC_TYPE_U8;
+    d.family = MSC_BB;
+    d.tab = st->fuse_tab + q * 16 * (size_t)st->kpad;
+    d.loo_tab = nullptr;
+    tf.push_back(d);
+    extra_f.push_back(0u);
+    at += m;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (!taken[i]) {
+      tf.push_back(t[i]);
+      extra_f.push_back(extra[i]);
+    }
+  const std::vector<uint32_t> &fused = quad_sizes;
+  st->fuse_any = !fused.empty();
+  st->fuse_nfeat = (uint32_t)tf.size();
+  st->fuse_split = split - (n - st->fuse_nfeat);
+  if (st->fuse_any) facts = plan_layout(tf, st->fuse_split, extra_f);
+  st->tile_roles_ok = facts.roles_ok;
+  st->tile_narrow_tail_ok = facts.tail_ok;
+  st->tail_masked_nich = facts.tail_masked_nich;
+  st->tail_max_rows = facts.tail_max_rows;
+  st->tail_pack_rows = facts.tail_pack_rows;
+  return MSC_OK;
 }
 
 static int upload_desc(msc_state *st) {
-  plan_groups(st);
+  MSC_TRY(plan_groups(st));
   MSC_HIP(hipMemcpyAsync(st->desc_dev, st->desc_host.data(), sizeof(FeatDesc) * st->nfeat,
                          hipMemcpyHostToDevice, st->ctx->stream));
   MSC_HIP(hipMemcpyAsync(st->desc_tile_dev, st->desc_tile_host.data(), sizeof(FeatDesc) * st->nfeat,
+                         hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipMemcpyAsync(st->desc_fuse_dev, st->desc_fuse_host.data(), sizeof(FeatDesc) * st->fuse_nfeat,
                          hipMemcpyHostToDevice, st->ctx->stream));
   MSC_HIP(hipStreamSynchronize(st->ctx->stream));     // (the tile copy is rebuilt by the next call)
   return MSC_OK;
@@ -788,6 +900,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->logpc, crp_floats(st->kpad)))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->desc_fuse_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
@@ -1325,6 +1438,15 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
   return MSC_OK;
 }
 
+// the tables of the plan's fused bb runs follow their members' (whatever updated those -- prepare, commit, an entity op):
+// rebuilt at the head of every call that scores with the fused plan, one small launch
+static int refresh_fused_tables(msc_state *st) {
+  if (!st->fuse_any) return MSC_OK;
+  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, st->kpad))
+    return fail(MSC_EHIP, "k_fuse_tables launch failed");
+  return MSC_OK;
+}
+
 // what the narrow kernels of a partly filled last tile need (launchers.hpp); the packed-table scratch grows on demand
 static int tail_plan(msc_state *st, TailPlan &tp) {
   tp = TailPlan();
@@ -1409,6 +1531,7 @@ static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, ui
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
                      bool niw_f32, float *out_dev, uint64_t ld_out) {
   hipStream_t s = st->ctx->stream;
+  MSC_TRY(refresh_fused_tables(st));
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
     if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
@@ -1429,13 +1552,13 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     bool has_dm = false;
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
-    const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_tile_dev;
+    const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_fuse_dev;
     TailPlan tail;
     if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
     auto launch = [&](int shape) {
       return launch_score(s, st->ctx->num_cus, path, tail, shape, descs,
-                          (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0,
+                          (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0,
                           nrows, z_dev, st->own, crp ? st->logpc : nullptr, out_dev, ld_out);
     };
     // The single-nich pass is bound by the HBM write stream; its launch shape (rows per visit, visits per wave =
@@ -1718,6 +1841,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   }
   MSC_TRY(ensure_derived(st));
   MSC_TRY(ensure_crp(st));
+  MSC_TRY(refresh_fused_tables(st));
   hipStream_t s = st->ctx->stream;
   const int cus = st->ctx->num_cus;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
@@ -1762,7 +1886,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       MSC_TRY(tail_plan(st, tail));
       tail.exact = false;
       if (st->K <= 64) {
-        rc = launch_sweep_rows(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
+        rc = launch_sweep_rows(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0,
                                z_dev, st->own, st->logpc, st->rng_dev, zero);
         if (rc == 1) rc = -2;
       } else {
@@ -1774,15 +1898,15 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
           st->tail_scores = static_cast<float *>(p);
           st->tail_floats = need;
         }
-        rc = launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, 0, row0, nrows,
+        rc = launch_score_tail(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, 0, row0, nrows,
                                z_dev, st->own, st->logpc, st->tail_scores, 128);
         if (rc == 0) {
           rc = launch_sample_rows(s, cus, st->tail_scores, 128, st->K, nrows, row_id0, z_dev, st->rng_dev);
           not_zeroed = true;                              // (nothing emptied the additive tables on the way)
         } else if (rc == 1) rc = -2;
       }
-      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
-    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0 && !not_zeroed;
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
@@ -1809,9 +1933,9 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       TailPlan tail;
       MSC_TRY(tail_plan(st, tail));
       tail.exact = false;                                  // (nothing else scores these groups for a draw: one sum per group)
-      if (launch_score_tail(s, cus, tail, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad,
+      if (launch_score_tail(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad,
                             kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld) == 0) {
-        rc = launch_sweep_roles_tail(s, cus, st->desc_tile_dev, (int)st->nfeat, (int)st->tile_split, st->K, st->kpad, row0, nrows, row_id0,
+        rc = launch_sweep_roles_tail(s, cus, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0,
                                      z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);
         if (zeroed) *zeroed = rc == 0;
       }

@@ -465,6 +465,45 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ reco
   }
 }
 
+// two to four bool columns as one byte column of their bits (bit j = column j's value != 0): what a fused bb run of the
+// score / sweep plan reads (FeatDesc::fuse_*)
+struct PackCols { const uint8_t *c[4]; };
+__global__ __launch_bounds__(256) void k_pack_bits(PackCols cols, int m, uint64_t n, uint8_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t v = 0;
+  for (int j = 0; j < m; j++) v |= (cols.c[j][i] != 0 ? 1u : 0u) << j;
+  out[i] = (uint8_t)v;
+}
+int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint64_t n, void *out) {
+  if (n == 0) return 0;
+  PackCols pc;
+  for (int j = 0; j < 4; j++) pc.c[j] = static_cast<const uint8_t *>(cols[j < m ? j : 0]);
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pc, m, n, static_cast<uint8_t *>(out));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// the tables of the plan's fused bb runs: row i of a fused feature = its members' rows (i >> j) & 1, summed in member
+// order (floats, one association everywhere: every kernel that scores the run reads this table).  One block per feature
+// of the plan's first phase; the others leave at once.
+__global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict__ feats, uint32_t kpad) {
+  const FeatDesc &fd = feats[blockIdx.x];
+  const uint32_t m = fd.fuse_n;
+  if (m < 2) return;
+  const uint32_t rows = 1u << m;
+  for (uint32_t e = threadIdx.x; e < rows * kpad; e += 256) {
+    const uint32_t i = e / kpad, k = e - i * kpad;
+    float s = fd.fuse_src[0][(size_t)(i & 1u) * kpad + k];
+    for (uint32_t j = 1; j < m; j++) s += fd.fuse_src[j][(size_t)((i >> j) & 1u) * kpad + k];
+    fd.tab[(size_t)i * kpad + k] = s;
+  }
+}
+int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, uint32_t kpad) {
+  if (nsplit <= 0) return 0;
+  hipLaunchKernelGGL(k_fuse_tables, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // a masked lookup column with the mask folded in: masked rows hold `sentinel` (the index of the family's zero table row)
 template <typename T>
 __global__ __launch_bounds__(256) void k_mask_sentinel(const T *__restrict__ col, const uint8_t *__restrict__ mask, uint64_t n,

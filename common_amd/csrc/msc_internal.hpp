@@ -131,6 +131,14 @@ struct FeatDesc {
   // in the tile plan's copy of the descriptor (mask = null there), so a masked value is one more table row to the
   // lookup loops and nothing else; null when the column has no mask or the family no such row
   const void *col_sentinel;
+  // A FUSED run of unmasked bb / bbnc columns in the score / sweep kernels' plan (abi.cpp plan_groups): two to four bool
+  // columns read as one byte column of their bits (bit j = member j's value; the view keeps it, k_pack_bits) against one
+  // table of 2^n rows -- row i = the members' rows (i >> j) & 1 summed in member order -- that k_fuse_tables rebuilds into
+  // `tab` at the head of every scoring / sweep call from the members' own tables (fuse_src): to every kernel it is a lookup
+  // feature like any other, with a quarter of the reads and additions.  fuse_n = 0: an ordinary feature.
+  const float *fuse_src[4];
+  uint32_t fuse_n;
+  uint32_t pad2;
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -298,6 +306,9 @@ struct msc_dataview {
   // masked lookup columns with the mask folded in as a sentinel value (abi.cpp sentinel_column): per column,
   // ((element type, sentinel), device copy)
   mutable std::vector<std::vector<std::pair<std::pair<int, uint32_t>, const void *>>> sentinels;
+  // byte columns holding the bits of two to four bool columns (key: the member columns' device pointers), made when a
+  // state's plan fuses them (abi.cpp plan_groups, k_pack_bits)
+  mutable std::vector<std::pair<std::vector<const void *>, const void *>> packed_bits;
 };
 
 struct msc_feature_host {
@@ -342,6 +353,14 @@ struct msc_state {
   msc::FeatDesc *desc_tile_dev = nullptr;
   std::vector<msc::FeatDesc> desc_tile_host;
   uint32_t tile_split = 0;
+  // the same plan with runs of unmasked bb / bbnc columns fused (FeatDesc::fuse_*): what the score / sweep kernels walk;
+  // the leave-one-out pass keeps the plan above (its double sum over features stays term by term)
+  msc::FeatDesc *desc_fuse_dev = nullptr;
+  std::vector<msc::FeatDesc> desc_fuse_host;
+  uint32_t fuse_nfeat = 0, fuse_split = 0;
+  bool fuse_any = false;
+  float *fuse_tab = nullptr;          // the fused tables, 16 rows of kpad floats a fused feature
+  size_t fuse_tab_floats = 0;
   const msc_dataview *bound_view = nullptr;
   uint64_t bound_serial = 0;
   std::vector<uint32_t> bound_cols;
