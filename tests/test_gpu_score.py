@@ -441,3 +441,87 @@ def test_both_leave_one_out_kernels_give_a_row_the_same_bits(gpu_ctx, monkeypatc
     lik = oracle_scores(feats, fs, z=z, rows=rows)
     got = staged.cpu().numpy()[rows]
     assert (np.abs(got - want) / np.maximum(1.0, np.maximum(np.abs(want), np.abs(lik)))).max() <= TOL
+
+
+@pytest.mark.parametrize("nbb,K", [(2, 70), (3, 100), (5, 300), (9, 256), (16, 40)])
+def test_fused_bb_columns_follow_every_table_update(gpu_ctx, nbb, K, monkeypatch):
+    """The score / sweep plan fuses a state's unmasked bb / bbnc columns four (three, two) at a time -- one byte column of
+    their bits, one table of 2^m rows that k_fuse_tables rebuilds from the members' tables at the head of a call
+    (abi.cpp plan_groups).  Interleaved with other families, a masked bb column left out, 2 / 3 / 5 / 9 / 16 of them:
+    against the oracle after accumulate, after entity moves (k_entity_op updates the members' tables in place), after a
+    sweep step (k_commit_prepare) and after set_ss; few rows (tile kernels) and many (the lane <-> row kernel where it
+    applies) agree to the bit; the unfused plan (MSC_NO_BB_FUSE) agrees within the gate."""
+    import common_amd
+    rng = np.random.default_rng(nbb * 1000 + K)
+    N = 17_000
+    specs = []
+    for i in range(nbb):
+        specs += [(orc.BB, 0) if i % 3 else (orc.BBNC, 0), (orc.GP, 0) if i % 2 else (orc.DD, 6)]
+    specs += [(orc.BB, 0), (orc.NICH, 0), (orc.NICH, 0)]            # (the last bb column is masked: not fused)
+    masked_col = len(specs) - 3
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K - 1, N).astype(np.int32)
+    masks = [np.zeros(N, dtype=bool) for _ in feats]
+    masks[masked_col] = rng.random(N) < 0.25
+    dev = gpu_ctx.torch_device
+    cols = [torch.from_numpy(np.ascontiguousarray(f["values"])).to(dev) for f in feats]
+    mts = [torch.from_numpy(m.astype(np.uint8)).to(dev) if m.any() else None for m in masks]
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols, mts)
+    rows = np.unique(np.concatenate([[0, N - 1], rng.choice(N, 150, replace=False)]))
+    rt = torch.from_numpy(rows).to(dev)
+
+    def check(st, what):
+        """the state's scores against the twin evaluated on the suff-stats the state holds"""
+        want, mag = None, None
+        for i, (f, m) in enumerate(zip(feats, masks)):
+            F = orc.Family(f["family"], st.get_hp(i), f["dim"], "f64")
+            held = orc.widen_ss(f["family"], st.get_ss(i).astype(orc.ss_dtype(f["family"], f["dim"], "f32")), f["dim"])
+            sc = F.score_matrix(held, f["values"][rows])
+            sc[m[rows]] = 0.0
+            want = sc if want is None else want + sc
+            mag = np.maximum(1.0, np.abs(sc)) if mag is None else mag + np.maximum(1.0, np.abs(sc))
+        big = st.score_value(view)
+        assert (np.abs(big[rt].cpu().numpy() - want) / mag).max() <= TOL, what
+        few = st.score_value(view, row0=700, nrows=900)             # few rows: the tile kernels
+        assert torch.equal(few, big[700:1600]), what
+        return big
+
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, f in enumerate(feats):
+        st.set_hp(i, f["hp"])
+    st.set_alpha(1.2)
+    zt = torch.from_numpy(z).to(dev)
+    st.accumulate(view, zt)
+    for i, (fam, _) in enumerate(specs):                            # (a bbnc group's p is the state's own: give it values)
+        if fam == orc.BBNC:
+            rec = st.get_ss(i)
+            rec["p"] = rng.uniform(0.05, 0.95, K).astype(np.float32)
+            st.set_ss(i, rec)
+    fused = check(st, "accumulate")
+    for n in rng.choice(N, 40, replace=False):                      # entity moves
+        st.entity_op(view, int(n), int(z[n]), join=False, z=zt)
+        z[n] = int(rng.integers(0, K))
+        st.entity_op(view, int(n), int(z[n]), join=True, z=zt)
+    check(st, "entity_op")
+    st.sweep_step(view, zt, seed=5, sweep=0)                        # draw + tables rebuilt (k_commit_prepare)
+    check(st, "sweep_step")
+    rec = st.get_ss(0)
+    rec["heads"] += 3
+    st.set_ss(0, rec)
+    check(st, "set_ss")
+    # the unfused plan: another association of the same terms
+    monkeypatch.setenv("MSC_NO_BB_FUSE", "1")
+    st2 = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, f in enumerate(feats):
+        st2.set_hp(i, f["hp"])
+    monkeypatch.delenv("MSC_NO_BB_FUSE")
+    st3 = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    for i, f in enumerate(feats):
+        st3.set_hp(i, f["hp"])
+    for i in range(len(feats)):                                     # the same tables in both
+        st2.set_ss(i, st.get_ss(i))
+        st3.set_ss(i, st.get_ss(i))
+    a, b = st2.score_value(view)[rt].cpu().numpy(), st3.score_value(view)[rt].cpu().numpy()
+    assert (np.abs(a - b) / np.maximum(1.0, np.abs(a))).max() <= 1e-5
+    assert np.array_equal(b, st.score_value(view)[rt].cpu().numpy())
+    assert fused.shape == (N, K)
