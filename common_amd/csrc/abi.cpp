@@ -329,13 +329,14 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
   MSC_REQUIRE(ctx && out, "null argument");
   *out = nullptr;
   MSC_HIP(hipSetDevice(ctx->device));
-  // MSC_ALLOC_CANDIDATES (default 24; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6500: a
-  // candidate that fills at 6.5 TB/s takes the C2 pass at 0.87 of the HBM roof, one at 6.2 at 0.80-0.83).  Candidates
+  // MSC_ALLOC_CANDIDATES (default 24; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6650: a
+  // candidate that fills at 6.7 TB/s takes the C2 pass at 0.87-0.88 of the HBM roof, one at 6.5 at 0.83-0.87, one at 6.2
+  // at 0.80-0.83; when none reaches the mark the best of all is kept, ~1 ms a candidate).  Candidates
   // held side by side walk through physical memory, and where the fast stretches lie differs from box to box: one box
   // offered one within six candidates in ten processes of ten, another none within twelve in one process of twelve
   // (profiles/r03_alloc_distribution.jsonl)
   static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 24;
-  static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6500.f;
+  static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6650.f;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if (nbytes >= (64u << 20) && cand >= 1 && !capturing)
@@ -1531,7 +1532,6 @@ static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, ui
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
                      bool niw_f32, float *out_dev, uint64_t ld_out) {
   hipStream_t s = st->ctx->stream;
-  MSC_TRY(refresh_fused_tables(st));
   if (z_dev) {
     MSC_TRY(ensure_own(st, nrows));
     if (launch_loo_own(s, st->ctx->num_cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, crp ? st->logpc : nullptr, st->own))
@@ -1556,6 +1556,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     TailPlan tail;
     if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
+    if (path != MSC_PATH_NICH1) MSC_TRY(refresh_fused_tables(st));
     auto launch = [&](int shape) {
       return launch_score(s, st->ctx->num_cus, path, tail, shape, descs,
                           (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0,
@@ -1841,7 +1842,6 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   }
   MSC_TRY(ensure_derived(st));
   MSC_TRY(ensure_crp(st));
-  MSC_TRY(refresh_fused_tables(st));
   hipStream_t s = st->ctx->stream;
   const int cus = st->ctx->num_cus;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
@@ -1877,6 +1877,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     } else if (nich1) rc = launch_sweep_nich1(s, cus, st->desc_dev, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
+    else if (refresh_fused_tables(st)) return MSC_EHIP;    // (everything below walks the fused plan)
     else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr) {
       // at most 128 groups on a plan of lookup + plain nich features: the lane <-> row kernel, whose cost follows the
       // groups (a tile pass costs what 256 cost).  Up to 64: scores and draw in one launch, a lane draws its own row.
@@ -1918,6 +1919,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     bool plain = true;
     for (uint32_t f = 0; f < st->nfeat; f++) plain &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);
     if (plain) {
+      MSC_TRY(refresh_fused_tables(st));
       MSC_TRY(ensure_own(st, nrows));
       if (launch_loo_own(s, cus, loo_needs_heavy(st), st->loo_staged != 0, st->desc_tile_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev, st->logpc, st->own))
         return fail(MSC_EHIP, "k_loo_own launch failed");
