@@ -633,7 +633,11 @@ struct PlanFacts {
 // table row for a masked lookup column's zero row)
 static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std::vector<uint32_t> &extra) {
   auto rows_of = [](const FeatDesc &d) -> uint32_t {
-    if (d.fuse_n >= 2) return 1u << d.fuse_n;
+    if (d.fuse_n >= 2) {
+      uint32_t rows = 1;
+      for (uint32_t j = 0; j < d.fuse_n; j++) rows *= d.fuse_radix;
+      return rows;
+    }
     switch (d.family) {
       case MSC_BB:
       case MSC_BBNC: return 2;
@@ -709,8 +713,9 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
 }
 
 // the byte column holding the bits of m bool columns (kept by the view: every state that fuses the same columns shares it)
-static int packed_column(const msc_dataview *view, const void *const *cols, int m, const void **out) {
-  const std::vector<const void *> key(cols, cols + m);
+static int packed_column(const msc_dataview *view, const void *const *cols, int m, uint32_t radix, const void **out) {
+  std::vector<const void *> key(cols, cols + m);
+  key.push_back(reinterpret_cast<const void *>((uintptr_t)radix));
   for (const auto &e : view->packed_bits)
     if (e.first == key) {
       *out = e.second;
@@ -719,7 +724,7 @@ static int packed_column(const msc_dataview *view, const void *const *cols, int 
   void *dst = nullptr;
   MSC_HIP(hipMalloc(&dst, std::max<size_t>(1, (size_t)view->nrows)));
   view->owned_lazy.push_back(dst);
-  if (launch_pack_bits(view->ctx->stream, cols, m, view->nrows, dst)) return fail(MSC_EHIP, "k_pack_bits launch failed");
+  if (launch_pack_bits(view->ctx->stream, cols, m, radix, view->nrows, dst)) return fail(MSC_EHIP, "k_pack_bits launch failed");
   view->packed_bits.emplace_back(key, dst);
   *out = dst;
   return MSC_OK;
@@ -779,21 +784,28 @@ static int plan_groups(msc_state *st) {
   std::vector<uint32_t> extra_f;
   tf.clear();
   const bool may_fuse = st->bound_view != nullptr && std::getenv("MSC_NO_BB_FUSE") == nullptr;
-  std::vector<uint32_t> members;                           // the fusable features, in plan order
+  // (columns with a mask: their mask-folded copies, three states a value -- 0, 1, masked = the member's zero row --,
+  // three at a time against 27 rows)
+  std::vector<uint32_t> members[2];                        // [0] unmasked, [1] masked: the fusable features, in plan order
   for (uint32_t i = 0; i < split; i++) {
     const FeatDesc &d = t[i];
-    if (may_fuse && (d.family == MSC_BB || d.family == MSC_BBNC) && d.kind == MSC_KIND_LOOKUP_U8 && extra[i] == 0 &&
-        d.mask == nullptr && d.col != nullptr && d.tab != nullptr)
-      members.push_back(i);
+    if (may_fuse && (d.family == MSC_BB || d.family == MSC_BBNC) && d.kind == MSC_KIND_LOOKUP_U8 && d.mask == nullptr &&
+        d.col != nullptr && d.tab != nullptr)
+      members[extra[i] ? 1 : 0].push_back(i);
   }
-  if (members.size() < 2) members.clear();
-  std::vector<uint32_t> quad_sizes;
-  for (size_t left = members.size(); left >= 2;) {
-    const uint32_t m = left == 5 ? 3u : (uint32_t)std::min<size_t>(4, left);       // (never a single one left over)
-    quad_sizes.push_back(m);
-    left -= m;
+  struct Fused { uint32_t first, m, radix; };               // (first: index into members[radix - 2])
+  std::vector<Fused> quads;
+  for (uint32_t cls = 0; cls < 2; cls++) {
+    const size_t widest = cls == 0 ? 4 : 3;
+    size_t at = 0;
+    for (size_t left = members[cls].size(); left >= 2;) {
+      const uint32_t m = left == widest + 1 ? (uint32_t)widest - 1 : (uint32_t)std::min(widest, left);    // (never a single one left over)
+      quads.push_back(Fused{(uint32_t)at, m, 2u + cls});
+      at += m;
+      left -= m;
+    }
   }
-  const size_t need = quad_sizes.size() * 16 * (size_t)st->kpad;
+  const size_t need = quads.size() * 32 * (size_t)st->kpad;
   if (st->fuse_tab_floats < need) {
     void *p = nullptr;
     MSC_HIP(hipMalloc(&p, need * sizeof(float)));
@@ -802,34 +814,34 @@ static int plan_groups(msc_state *st) {
     st->fuse_tab_floats = need;
   }
   std::vector<bool> taken(n, false);
-  size_t at = 0;
-  for (size_t q = 0; q < quad_sizes.size(); q++) {
-    const uint32_t m = quad_sizes[q];
-    FeatDesc d = t[members[at]];
+  for (size_t q = 0; q < quads.size(); q++) {
+    const Fused &fq = quads[q];
+    const std::vector<uint32_t> &mem = members[fq.radix - 2];
+    FeatDesc d = t[mem[fq.first]];
     const void *cols[4] = {nullptr, nullptr, nullptr, nullptr};
     for (uint32_t j = 0; j < 4; j++) d.fuse_src[j] = nullptr;
-    for (uint32_t j = 0; j < m; j++) {
-      const FeatDesc &mj = t[members[at + j]];
+    for (uint32_t j = 0; j < fq.m; j++) {
+      const FeatDesc &mj = t[mem[fq.first + j]];
       cols[j] = mj.col;
       d.fuse_src[j] = mj.tab;
-      taken[members[at + j]] = true;
+      taken[mem[fq.first + j]] = true;
     }
-    MSC_TRY(packed_column(st->bound_view, cols, (int)m, &d.col));
-    d.fuse_n = m;
+    MSC_TRY(packed_column(st->bound_view, cols, (int)fq.m, fq.radix, &d.col));
+    d.fuse_n = fq.m;
+    d.fuse_radix = fq.radix;
     d.col_type = MSC_TYPE_U8;
     d.family = MSC_BB;
-    d.tab = st->fuse_tab + q * 16 * (size_t)st->kpad;
+    d.tab = st->fuse_tab + q * 32 * (size_t)st->kpad;
     d.loo_tab = nullptr;
     tf.push_back(d);
     extra_f.push_back(0u);
-    at += m;
   }
   for (uint32_t i = 0; i < n; i++)
     if (!taken[i]) {
       tf.push_back(t[i]);
       extra_f.push_back(extra[i]);
     }
-  const std::vector<uint32_t> &fused = quad_sizes;
+  const std::vector<Fused> &fused = quads;
   st->fuse_any = !fused.empty();
   st->fuse_nfeat = (uint32_t)tf.size();
   st->fuse_split = split - (n - st->fuse_nfeat);

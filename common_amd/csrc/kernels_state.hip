@@ -465,21 +465,26 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ reco
   }
 }
 
-// two to four bool columns as one byte column of their bits (bit j = column j's value != 0): what a fused bb run of the
-// score / sweep plan reads (FeatDesc::fuse_*)
+// two to four bool columns as one byte column of their digits (digit j = column j's value): what a fused bb feature of
+// the score / sweep plan reads (FeatDesc::fuse_*)
 struct PackCols { const uint8_t *c[4]; };
-__global__ __launch_bounds__(256) void k_pack_bits(PackCols cols, int m, uint64_t n, uint8_t *__restrict__ out) {
+// (radix 2: digit = value != 0; radix 3: the columns are the mask-folded copies -- 0, 1, 2 = masked)
+__global__ __launch_bounds__(256) void k_pack_bits(PackCols cols, int m, uint32_t radix, uint64_t n, uint8_t *__restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t v = 0;
-  for (int j = 0; j < m; j++) v |= (cols.c[j][i] != 0 ? 1u : 0u) << j;
+  uint32_t v = 0, place = 1;
+  for (int j = 0; j < m; j++) {
+    const uint32_t c = cols.c[j][i];
+    v += (radix == 2 ? (c != 0 ? 1u : 0u) : (c > 2u ? 2u : c)) * place;
+    place *= radix;
+  }
   out[i] = (uint8_t)v;
 }
-int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint64_t n, void *out) {
+int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_t radix, uint64_t n, void *out) {
   if (n == 0) return 0;
   PackCols pc;
   for (int j = 0; j < 4; j++) pc.c[j] = static_cast<const uint8_t *>(cols[j < m ? j : 0]);
-  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pc, m, n, static_cast<uint8_t *>(out));
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pc, m, radix, n, static_cast<uint8_t *>(out));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -488,14 +493,23 @@ int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint64_
 // of the plan's first phase; the others leave at once.
 __global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict__ feats, uint32_t kpad) {
   const FeatDesc &fd = feats[blockIdx.x];
-  const uint32_t m = fd.fuse_n;
+  const uint32_t m = fd.fuse_n, radix = fd.fuse_radix;
   if (m < 2) return;
-  const uint32_t rows = 1u << m;
-  for (uint32_t e = threadIdx.x; e < rows * kpad; e += 256) {
-    const uint32_t i = e / kpad, k = e - i * kpad;
-    float s = fd.fuse_src[0][(size_t)(i & 1u) * kpad + k];
-    for (uint32_t j = 1; j < m; j++) s += fd.fuse_src[j][(size_t)((i >> j) & 1u) * kpad + k];
-    fd.tab[(size_t)i * kpad + k] = s;
+  uint32_t rows = 1;
+  for (uint32_t j = 0; j < m; j++) rows *= radix;
+  for (uint32_t k = threadIdx.x; k < kpad; k += 256) {
+    float e[4][3];                                       // the members' entries for this group (digit 2 of a masked member: its zero row)
+    for (uint32_t j = 0; j < m; j++)
+      for (uint32_t d = 0; d < radix; d++) e[j][d] = fd.fuse_src[j][(size_t)d * kpad + k];
+    for (uint32_t i = 0; i < rows; i++) {                // (i and its digits are uniform: scalar arithmetic)
+      uint32_t rest = i / radix;
+      float s = e[0][i % radix];
+      for (uint32_t j = 1; j < m; j++) {
+        s += e[j][rest % radix];
+        rest /= radix;
+      }
+      fd.tab[(size_t)i * kpad + k] = s;
+    }
   }
 }
 int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, uint32_t kpad) {

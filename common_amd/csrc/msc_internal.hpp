@@ -131,14 +131,15 @@ struct FeatDesc {
   // in the tile plan's copy of the descriptor (mask = null there), so a masked value is one more table row to the
   // lookup loops and nothing else; null when the column has no mask or the family no such row
   const void *col_sentinel;
-  // A FUSED run of unmasked bb / bbnc columns in the score / sweep kernels' plan (abi.cpp plan_groups): two to four bool
-  // columns read as one byte column of their bits (bit j = member j's value; the view keeps it, k_pack_bits) against one
-  // table of 2^n rows -- row i = the members' rows (i >> j) & 1 summed in member order -- that k_fuse_tables rebuilds into
+  // FUSED bb / bbnc columns in the score / sweep kernels' plan (abi.cpp plan_groups): two to four bool columns read as
+  // one byte column of their digits (digit j = member j's value -- a bit, or 0 / 1 / 2 = masked for columns with a mask;
+  // the view keeps it, k_pack_bits) against one table of radix^n rows -- row i = the members' rows digit_j(i) summed in
+  // member order -- that k_fuse_tables rebuilds into
   // `tab` at the head of every scoring / sweep call from the members' own tables (fuse_src): to every kernel it is a lookup
   // feature like any other, with a quarter of the reads and additions.  fuse_n = 0: an ordinary feature.
   const float *fuse_src[4];
   uint32_t fuse_n;
-  uint32_t pad2;
+  uint32_t fuse_radix;     // 2: unmasked members; 3: masked ones (digit 2 = the member's zero row; three at a time, 27 rows)
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -359,7 +360,7 @@ struct msc_state {
   std::vector<msc::FeatDesc> desc_fuse_host;
   uint32_t fuse_nfeat = 0, fuse_split = 0;
   bool fuse_any = false;
-  float *fuse_tab = nullptr;          // the fused tables, 16 rows of kpad floats a fused feature
+  float *fuse_tab = nullptr;          // the fused tables, 32 rows of kpad floats a fused feature (16 or 27 used)
   size_t fuse_tab_floats = 0;
   const msc_dataview *bound_view = nullptr;
   uint64_t bound_serial = 0;

@@ -457,12 +457,13 @@ def test_fused_bb_columns_follow_every_table_update(gpu_ctx, nbb, K, monkeypatch
     specs = []
     for i in range(nbb):
         specs += [(orc.BB, 0) if i % 3 else (orc.BBNC, 0), (orc.GP, 0) if i % 2 else (orc.DD, 6)]
-    specs += [(orc.BB, 0), (orc.NICH, 0), (orc.NICH, 0)]            # (the last bb column is masked: not fused)
-    masked_col = len(specs) - 3
+    nmasked = {2: 1, 3: 2, 5: 3, 9: 4, 16: 7}[nbb]                  # masked bb columns: one alone stays unfused; 2 / 3 / 4 / 7
+    specs += [(orc.BB, 0)] * nmasked + [(orc.NICH, 0), (orc.NICH, 0)]   # fuse three states a value, three (two) at a time
     feats = [make_feature(f, N, K, rng, d) for f, d in specs]
     z = rng.integers(0, K - 1, N).astype(np.int32)
     masks = [np.zeros(N, dtype=bool) for _ in feats]
-    masks[masked_col] = rng.random(N) < 0.25
+    for c in range(len(specs) - 2 - nmasked, len(specs) - 2):
+        masks[c] = rng.random(N) < 0.25
     dev = gpu_ctx.torch_device
     cols = [torch.from_numpy(np.ascontiguousarray(f["values"])).to(dev) for f in feats]
     mts = [torch.from_numpy(m.astype(np.uint8)).to(dev) if m.any() else None for m in masks]
