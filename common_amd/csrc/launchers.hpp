@@ -61,7 +61,7 @@ struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 constexpr uint32_t kTailMaxGroups = 128;
-constexpr uint64_t kTailMinRows = 16384;     // score passes: fewer rows stay with the tile kernels (same bits)
+constexpr uint64_t kTailMinRows = 16384;     // score passes: fewer rows (or fewer than 1536 a group) stay with the tile kernels (same bits)
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {

@@ -93,13 +93,14 @@ def test_fully_masked_row_scores_zero_and_samples_from_the_prior(gpu_ctx, monkey
 
 
 @pytest.mark.parametrize("K,masked_cols", [(90, {0, 1, 3}), (300, {0, 3}), (120, {0, 2, 7})])
-def test_masked_lookup_columns_keep_the_tile_kernels_fast_path(gpu_ctx, K, masked_cols):
+def test_masked_lookup_columns_keep_the_tile_kernels_fast_path(gpu_ctx, K, masked_cols, monkeypatch):
     """Masked bb / gp / dd columns reach the tile kernels with the mask folded in (a masked row holds the index of the
     family's zero table row: abi.cpp bind_view / plan_groups), so such a state keeps the lookup runs and the role-split
     kernels; a masked nich column (third case, column 2) still takes the generic path.  40k rows against the oracle,
     against short slices (other launch shapes: same bits), plain and leave-one-out + prior, and -- K <= 256 -- as a fused
     sweep against the same sweep in three shards; accumulate sees the original column and mask."""
     import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")      # (40k rows: the lane <-> row kernel takes the partly filled tile)
     specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.BB, 0), (orc.DD, 40), (orc.NICH, 0), (orc.GP, 0),
              (orc.NICH, 0), (orc.BBNC, 0)]
     N = 40_000

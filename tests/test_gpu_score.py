@@ -233,7 +233,7 @@ TAIL_PLANS = {
 
 @pytest.mark.parametrize("plan", sorted(TAIL_PLANS))
 @pytest.mark.parametrize("K", [40, 100, 128, 257, 270, 285, 300, 320, 321, 345, 384])
-def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
+def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K, monkeypatch):
     """A last tile of at most 128 groups (K <= 128: the whole state; 256 < K <= 384: the groups beyond the first tile) comes
     from k_score_tail_rows when the rows are many (lane <-> row; launches of 16 / 32 / 48 groups: every register tiling
     of it), whatever the plan holds: lookup features and nich features, one kind only, more table rows than one stage of its
@@ -243,6 +243,7 @@ def test_partly_filled_last_tile_on_the_narrow_kernel(gpu_ctx, plan, K):
     import common_amd
     if plan == "many_nich" and K not in (100, 300):
         pytest.skip("the wide plan at two table sizes")
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")       # (the library's own mark grows with the groups: ~1000 rows a group)
     N = 17_000
     rng = np.random.default_rng(K + len(plan))
     specs = TAIL_PLANS[plan]
@@ -281,6 +282,7 @@ def test_narrow_kernel_gives_the_tile_kernels_bits(gpu_ctx, plan, K, monkeypatch
     last -- so the choice between it and the tile kernels is free to depend on the row count: the same state planned with
     and without it (MSC_NO_NARROW_TAIL, read when a state plans its kernels) scores every entry to the same bits."""
     import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
     N = 16_400
     rng = np.random.default_rng(K)
     specs = TAIL_PLANS[plan]
@@ -452,6 +454,7 @@ def test_fused_bb_columns_follow_every_table_update(gpu_ctx, nbb, K, monkeypatch
     sweep step (k_commit_prepare) and after set_ss; few rows (tile kernels) and many (the lane <-> row kernel where it
     applies) agree to the bit; the unfused plan (MSC_NO_BB_FUSE) agrees within the gate."""
     import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
     rng = np.random.default_rng(nbb * 1000 + K)
     N = 17_000
     specs = []
