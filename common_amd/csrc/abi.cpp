@@ -1829,6 +1829,15 @@ static bool sweep_is_niw1(const msc_state *st) {
   return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && (int)st->K <= sweep_niw1_max_groups(st->feats[0].dim);
 }
 
+// the lane <-> row kernel fills the chip from ~260k rows on; with fewer than ~1500 rows a group the tile kernels' round of
+// 128-row chunks is shorter (launchers.hpp kTailMinRows, tools/scans/tail_threshold.py).  Decided on the bound view's
+// row count, so every row range of it takes the same kernels.
+static bool sweep_rows_pays(const msc_state *st) {
+  const uint64_t rows = st->bound_view ? st->bound_view->nrows : 0;
+  if (const char *forced = std::getenv("MSC_TAIL_MIN_ROWS")) return rows >= (uint64_t)std::atoll(forced);
+  return rows >= std::max<uint64_t>(kTailMinRows, 1536ull * st->K);
+}
+
 static bool sweep_is_fused(const msc_state *st) {
   if (sweep_is_niw1(st)) return true;
   const bool nich1 = st->nfeat == 1 && st->feats[0].family == MSC_NICH;
@@ -1890,11 +1899,12 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
     else if (refresh_fused_tables(st)) return MSC_EHIP;    // (everything below walks the fused plan)
-    else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr) {
+    else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr &&
+             sweep_rows_pays(st)) {
       // at most 128 groups on a plan of lookup + plain nich features: the lane <-> row kernel, whose cost follows the
       // groups (a tile pass costs what 256 cost).  Up to 64: scores and draw in one launch, a lane draws its own row.
-      // Beyond: the scores into 128 floats per row, then the row sampler.  Whatever the row count (a shard draws what
-      // the whole draws).
+      // Beyond: the scores into 128 floats per row, then the row sampler.  The choice looks at the VIEW's rows, not the
+      // call's (a shard draws what the whole draws).
       TailPlan tail;
       MSC_TRY(tail_plan(st, tail));
       tail.exact = false;
