@@ -1832,10 +1832,12 @@ static bool sweep_is_niw1(const msc_state *st) {
 // the lane <-> row kernel fills the chip from ~260k rows on; with fewer than ~1500 rows a group the tile kernels' round of
 // 128-row chunks is shorter (launchers.hpp kTailMinRows, tools/scans/tail_threshold.py).  Decided on the bound view's
 // row count, so every row range of it takes the same kernels.
-static bool sweep_rows_pays(const msc_state *st) {
+// (sweeps cross earlier than score passes: the fused tile sweep kernel's round is ~100 us -- tools/scans/small_n.py, C3's
+// columns: K = 32 the lane <-> row sweep wins from ~15k rows, K = 100 from ~80k, a 44-group tail from ~40k)
+static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t rows = st->bound_view ? st->bound_view->nrows : 0;
   if (const char *forced = std::getenv("MSC_TAIL_MIN_ROWS")) return rows >= (uint64_t)std::atoll(forced);
-  return rows >= std::max<uint64_t>(kTailMinRows, 1536ull * st->K);
+  return rows >= std::max<uint64_t>(kTailMinRows, 768ull * groups);
 }
 
 static bool sweep_is_fused(const msc_state *st) {
@@ -1900,7 +1902,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
     else if (refresh_fused_tables(st)) return MSC_EHIP;    // (everything below walks the fused plan)
     else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr &&
-             sweep_rows_pays(st)) {
+             sweep_rows_pays(st, st->K)) {
       // at most 128 groups on a plan of lookup + plain nich features: the lane <-> row kernel, whose cost follows the
       // groups (a tile pass costs what 256 cost).  Up to 64: scores and draw in one launch, a lane draws its own row.
       // Beyond: the scores into 128 floats per row, then the row sampler.  The choice looks at the VIEW's rows, not the
@@ -1934,9 +1936,10 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
   // included) into 64 or 128 floats per row, then the fused kernel over the tile draws over both -- nothing materialised
-  // but that.  Whatever the row count, so that a shard draws from the same bits as the whole.
+  // but that.  Where it pays (sweep_rows_pays: by the view's row count, so that a shard draws from the same bits as the whole).
   if (rc == -2 && !nich1 && !has_dm && st->tile_roles_ok && st->tile_narrow_tail_ok && tile_roles_enabled() && st->K > 256 &&
-      st->K <= (uint32_t)kGroupTile + kTailMaxGroups && std::getenv("MSC_NO_FUSED_TAIL") == nullptr) {
+      st->K <= (uint32_t)kGroupTile + kTailMaxGroups && std::getenv("MSC_NO_FUSED_TAIL") == nullptr &&
+      sweep_rows_pays(st, st->K - kGroupTile)) {
     const uint64_t tail_ld = st->K <= (uint32_t)kGroupTile + 64 ? 64 : 128;
     bool plain = true;
     for (uint32_t f = 0; f < st->nfeat; f++) plain &= st->feats[f].family != MSC_NIW && !gp_beyond_table(st, f);

@@ -1367,7 +1367,9 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     const bool dm = path == MSC_PATH_TILE_DM;
     const uint64_t round = (uint64_t)num_cus / ktiles;
     static const uint64_t rounds4 = std::getenv("MSC_TILE_R4_ROUNDS") ? std::atoi(std::getenv("MSC_TILE_R4_ROUNDS")) : 1;
-    const bool small4 = !dm && (nrows + 127) / 128 < round * rounds4, small2 = small4 && (nrows + 31) / 32 <= round;
+    // (4 rows per wave only while the 64-row workgroups themselves fit one round: 20000 rows made 313 of them -- two
+    // rounds, 0.113 ms -- where 157 workgroups of 128 rows take one)
+    const bool small4 = !dm && (nrows + 63) / 64 <= round * rounds4, small2 = small4 && (nrows + 31) / 32 <= round;
     const uint64_t rows_per_wg = dm ? 64 : small2 ? 32 : small4 ? 64 : 128;
     const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
     uint64_t gx = nchunks;

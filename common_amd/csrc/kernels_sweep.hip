@@ -1656,7 +1656,8 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   const int R = tile_rows_per_wave();
   // few rows: 2 rows per wave instead of 8, so that the chunks -- each a serial chain of feature lookups and R
   // draws -- spread over the chip instead of queueing in a quarter of it (N = 10k, 12 features: 26 -> ? us)
-  const bool small = !has_dm && (nrows + 127) / 128 < (uint64_t)num_cus;
+  // (and 4 rows per wave only while the 64-row workgroups fit one round themselves)
+  const bool small = !has_dm && (nrows + 63) / 64 <= (uint64_t)num_cus;
   const bool small4 = small && (nrows + 31) / 32 > (uint64_t)num_cus;      // (2 rows per wave would need a second round)
   const uint64_t rows_per_wg = has_dm ? 64 : small4 ? 64 : small ? 32 : 128;
   uint64_t gx = (nrows + rows_per_wg - 1) / rows_per_wg;

@@ -500,13 +500,14 @@ def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
 
 
 @pytest.mark.parametrize("K,empty", [(257, 0), (300, 3), (320, 40), (321, 0), (350, 5), (384, 70)])
-def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty):
+def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty, monkeypatch):
     """256 < K <= 384 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
     (k_score_tail_rows: 64 or 128 floats per row, leave-one-out value and prior included) and the role-split sweep kernel
     draws over tile + tail (k_sweep_tile_roles<1 | 2>, sample_tile_and_tail) -- whatever the row count.  Against the oracle's sweep
     (every disagreeing draw on a CDF step), rows whose own group lies in the tail and empty tail groups included; and the
     same sweep in three shards draws the same assignments."""
     import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "1")            # (3000 and 20k rows here; the library's own mark: ~770 rows a tail group)
     specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 9), (orc.NICH, 0), (orc.BB, 0), (orc.BNB, 0)]
     got, want, scores, z = _run(gpu_ctx, specs, 3000, K, seed=40 + K, sweep_idx=2, alpha=0.8, empty=empty)
     assert (z >= 256).any() or K - empty <= 256
