@@ -1829,15 +1829,28 @@ static bool sweep_is_niw1(const msc_state *st) {
   return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && (int)st->K <= sweep_niw1_max_groups(st->feats[0].dim);
 }
 
-// the lane <-> row kernel fills the chip from ~260k rows on; with fewer than ~1500 rows a group the tile kernels' round of
-// 128-row chunks is shorter (launchers.hpp kTailMinRows, tools/scans/tail_threshold.py).  Decided on the bound view's
-// row count, so every row range of it takes the same kernels.
-// (sweeps cross earlier than score passes: the fused tile sweep kernel's round is ~100 us -- tools/scans/small_n.py, C3's
-// columns: K = 32 the lane <-> row sweep wins from ~15k rows, K = 100 from ~80k, a 44-group tail from ~40k)
+// the lane <-> row kernel fills the chip from ~260k rows on; with fewer the tile kernels' rounds of 128-row chunks can be
+// shorter.  Decided on the bound view's row count, so every row range of it takes the same kernels.
+// (priced with the cost model of launchers.hpp: the lane <-> row launches -- plus, beyond 64 groups, the trip through
+// 128 floats per row and the row sampler -- against the rounds of the fused tile sweep kernel; for a tail beyond a full
+// tile, against one more tile pass, the materialised matrix and the sampler)
 static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t rows = st->bound_view ? st->bound_view->nrows : 0;
   if (const char *forced = std::getenv("MSC_TAIL_MIN_ROWS")) return rows >= (uint64_t)std::atoll(forced);
-  return rows >= std::max<uint64_t>(kTailMinRows, 768ull * groups);
+  if (rows < kTailMinRows) return false;
+  const int cus = st->ctx->num_cus;
+  const uint64_t c128 = (rows + 127) / 128;
+  const bool tail = groups < st->K;                       // the groups beyond a full first tile
+  const double sample_us = [&](uint64_t floats_per_row) { return 30.0 + (double)rows * floats_per_row * 4.0 / 2.0e6; }(tail ? st->K : 128);
+  double rows_us = tail_rows_us(groups, false, rows, cus), tile_us;
+  if (tail) {
+    rows_us *= 1.15;                                      // (the tile kernel's instantiation that reads the tail is that much slower)
+    tile_us = tile_rounds_us(c128, cus, false) + sample_us;                    // one more tile pass, then the sampler over K floats a row
+  } else {
+    if (groups > 64) rows_us += sample_us;
+    tile_us = tile_rounds_us(c128, cus, true);
+  }
+  return rows_us < tile_us;
 }
 
 static bool sweep_is_fused(const msc_state *st) {

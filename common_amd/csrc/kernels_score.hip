@@ -1379,12 +1379,14 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     // the last tile alone on the lane <-> row kernel when it is partly filled and the plan allows (flag from abi.cpp) and
     // the rows are many: its bits are the tile kernels', so the choice is free; few rows (a per-entity call's one) are
     // better off with lanes as groups.  A state of at most kTailMaxGroups groups is all "last tile".
-    // (it fills the chip from ~260k rows on, 512 a workgroup; with fewer, its one chunk per workgroup takes ~30 us + 1.7 us
-    // a group where the tile kernels' round of 128-row chunks takes ~60 us: measured on C3's columns the crossing lies at
-    // ~1500 rows a group -- K = 16 / 64 / 128: below 16k / near 90k / near 200k rows, tools/scans/tail_threshold.py)
+    // (it fills the chip from ~260k rows on, 512 a workgroup, where the tile kernels run in rounds of 128 rows a CU:
+    // whichever the cost model of launchers.hpp prices lower for these rows -- the last tile's share of the tile pass
+    // against the launches of the lane <-> row kernel)
     const char *forced = std::getenv("MSC_TAIL_MIN_ROWS");          // (tests: the kernel on a few thousand rows)
+    const uint64_t c128 = (nrows + 127) / 128;
+    const double tile_us = tile_rounds_us(c128 * ktiles, num_cus, false) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false) : 0.0);
     const bool many_rows = forced ? nrows >= (uint64_t)std::atoll(forced)
-                                  : nrows >= std::max<uint64_t>(kTailMinRows, 1536ull * (K - (ktiles - 1) * kGroupTile));
+                                  : nrows >= kTailMinRows && tail_rows_us(K - (ktiles - 1) * kGroupTile, true, nrows, num_cus) < tile_us;
     const bool tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
                                                      (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
     if (tail && ktiles == 1) return;

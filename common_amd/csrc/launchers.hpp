@@ -61,7 +61,20 @@ struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 constexpr uint32_t kTailMaxGroups = 128;
-constexpr uint64_t kTailMinRows = 16384;     // score passes: fewer rows (or fewer than 1536 a group) stay with the tile kernels (same bits)
+constexpr uint64_t kTailMinRows = 16384;     // fewer rows always stay with the tile kernels (lanes as groups)
+// What a pass over `nrows` rows costs, in microseconds, on either kind of kernel (measured on C3's 64 columns, MI355X:
+// tools/scans/tail_threshold.py, small_n.py, n_scan.py) -- only to choose between them:
+//   tile kernels: one workgroup of 128 rows per CU and round, ~60 us a round of a scoring pass, ~100 us of a fused sweep;
+//   lane <-> row kernel: a launch of g groups takes ~30 + 1.7 g us per round of 1024 rows a CU (two workgroups of 512).
+inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep) {
+  return (sweep ? 100.0 : 60.0) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
+}
+inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus) {
+  const uint32_t widest = exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
+  const uint32_t per = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
+  const uint64_t rounds = (nrows + 1024ull * num_cus - 1) / (1024ull * num_cus);
+  return (double)nblk * (30.0 + 1.7 * per) * (double)(rounds ? rounds : 1);
+}
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {
