@@ -1685,7 +1685,7 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// 256 < K <= 384, whatever the row count (so that a shard draws from the same bits as the whole): the role-split kernel
+// 256 < K <= 384 (abi.cpp decides on the bound view's row count, so that a shard draws from the same bits as the whole): the role-split kernel
 // over the full tile, the tail's scores from `tail` (k_score_tail_rows wrote them)
 int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                             uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,

@@ -80,7 +80,7 @@ inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_
 struct TailPlan {
   bool ok = false;
   bool exact = true;          // the tile kernels' bits (two sums per group: score passes, where the row count picks the kernel);
-                              // false: one sum per group, faster (the fused sweep's tail, which takes this kernel whatever the row count)
+                              // false: one sum per group, faster (sweeps: the choice of kernel follows the bound view's row count, not the call's)
   bool masked_nich = false;   // the first phase holds masked nich columns (the kernel's instantiation that evaluates them)
   uint32_t max_rows = 0;      // the largest lookup table (rows a value may select)
   uint32_t pack_rows = 0;     // all lookup tables together

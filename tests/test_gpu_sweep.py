@@ -503,7 +503,7 @@ def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
 def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty, monkeypatch):
     """256 < K <= 384 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
     (k_score_tail_rows: 64 or 128 floats per row, leave-one-out value and prior included) and the role-split sweep kernel
-    draws over tile + tail (k_sweep_tile_roles<1 | 2>, sample_tile_and_tail) -- whatever the row count.  Against the oracle's sweep
+    draws over tile + tail (k_sweep_tile_roles<1 | 2>, sample_tile_and_tail) -- for every row range of a view.  Against the oracle's sweep
     (every disagreeing draw on a CDF step), rows whose own group lies in the tail and empty tail groups included; and the
     same sweep in three shards draws the same assignments."""
     import common_amd
