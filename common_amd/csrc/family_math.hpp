@@ -42,6 +42,16 @@ MSC_DEV void log1p_parts(float t, float &l2, float &r) {
   l2 = hw_log2(u);
   r = (t - (u - 1.0f)) * hw_rcp(u);
 }
+// The same parts of log(1 + a^2), from a: u = fma(a, a, 1) is 1 + a^2 rounded once, and fma(a, a, -(u - 1)) is what that
+// rounding dropped (u - 1 is exact) -- four plain instructions + two transcendental where log1p_parts(a * a) takes five,
+// and the remainder now carries the rounding of a^2 itself as well.  The nich evaluations spend their issue slots on
+// exactly this: one in ten fewer.
+MSC_DEV void log1p_sq_parts(float a, float &l2, float &r) {
+#pragma clang fp contract(off)   // same bits from every kernel that inlines this, whatever surrounds it
+  const float u = fmaf(a, a, 1.0f);
+  l2 = hw_log2(u);
+  r = fmaf(a, a, -(u - 1.0f)) * hw_rcp(u);
+}
 MSC_DEV float log1p_acc(float t) {
   float l2, r;
   log1p_parts(t, l2, r);
@@ -305,7 +315,7 @@ MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1l
 #pragma clang fp contract(off)   // explicit fmaf only: a row's score must not depend on the code path that scored it
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
   float l2, r;
-  log1p_parts(a * a, l2, r);
+  log1p_sq_parts(a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, c0));
 }
 // The tile kernels' second phase sums the nich features of a row WITHOUT a separate addition per evaluation: the
@@ -317,7 +327,7 @@ MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
   float l2, r;
-  log1p_parts(a * a, l2, r);
+  log1p_sq_parts(a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, acc));
 }
 // The sweep kernels' form, in log2 units: c0' - c1 log2(1 + t), with log2(1 + t) = log2(u) + log2e (t - (u - 1)) / u
@@ -327,7 +337,7 @@ MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, floa
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
   float l2, r;
-  log1p_parts(a * a, l2, r);
+  log1p_sq_parts(a, l2, r);
   return fmaf(-c1, fmaf(r, 1.44269504088896340736f, l2), c0);
 }
 // The transposed sweep kernel's form of the same: the compensation term (t - (u - 1)) / u is at most 2^-24, so 1 / u is
@@ -337,9 +347,9 @@ MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, floa
 MSC_DEV float nich_eval_log2_est(float x, float smu_hi, float smu_lo, float c0, float c1, float s) {
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
-  const float t = a * a, u = 1.0f + t;
+  const float u = fmaf(a, a, 1.0f);                        // (log1p_sq_parts' steps, the reciprocal estimated)
   const float ru = __uint_as_float(0x7EF311C7u - __float_as_uint(u));
-  const float r = (t - (u - 1.0f)) * ru;
+  const float r = fmaf(a, a, -(u - 1.0f)) * ru;
   return fmaf(-c1, fmaf(r, 1.44269504088896340736f, hw_log2(u)), c0);
 }
 // Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:

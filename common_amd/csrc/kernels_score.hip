@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
             float &a = SPLIT ? accn[gb + j] : acc[gb + j];
             a = nich_accum(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
           }
-          if (NB == 4) __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);             // (a block's temporaries at a time: left to interleave the blocks, some instantiations spill)
         }
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
       }
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
       float m = -INFINITY;
 #pragma unroll
       for (int g = 0; g < TGP; g++) {
-        const float sg = gown == g ? ownv : acc[g] + prh[g];
+        const float sg = gown == g ? ownv : (SPLIT && nsplit < nfeat ? acc[g] + accn[g] : acc[g]) + prh[g];
         acc[g] = (uint32_t)g < K ? sg : -INFINITY;
         m = fmaxf(m, acc[g]);
       }
@@ -1295,7 +1295,8 @@ int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const
   const uint32_t tgp = (K + 15u) / 16u * 16u;
 #define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
   if (tgp == 16) MSC_SWEEP_ROWS(16);
-  else if (tgp == 32) MSC_SWEEP_ROWS(32);
+  else if (tgp == 32)        // (two sums per group here: the one-sum instantiation of 32 spills -- the register allocator's quirk)
+    launch_tail_rows_t<32, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero);
   else if (tgp == 48) MSC_SWEEP_ROWS(48);
   else MSC_SWEEP_ROWS(64);
 #undef MSC_SWEEP_ROWS
@@ -1327,7 +1328,7 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
       else MSC_TAIL_ROWS(48, true);
     } else {
       if (tgp == 16) MSC_TAIL_ROWS(16, false);
-      else if (tgp == 32) MSC_TAIL_ROWS(32, false);
+      else if (tgp == 32) MSC_TAIL_ROWS(32, true);          // (as above: the one-sum instantiation of 32 spills)
       else if (tgp == 48) MSC_TAIL_ROWS(48, false);
       else MSC_TAIL_ROWS(64, false);
     }

@@ -30,3 +30,21 @@ def test_compensated_log1p_with_the_estimate_keeps_the_error_far_below_the_hardw
     with_est = l2 + (r * _recip_estimate(u)).astype(np.float64) * 1.4426950408889634
     assert np.abs(l2 - exact).max() > 5e-8                         # what the term is there for
     assert np.abs(with_est - exact).max() < 4.4e-9
+
+
+def test_compensated_log1p_of_a_square_through_two_fused_multiply_adds():
+    """family_math.hpp log1p_sq_parts / nich_eval_log2_est: u = fma(a, a, 1) is 1 + a^2 rounded once and fma(a, a, -(u - 1)) is
+    what that rounding dropped (u - 1 is exact), the rounding of a^2 included -- one instruction fewer than t = a * a,
+    u = 1 + t, t - (u - 1), and no less accurate: emulated in float64 (a^2 is exact there), with either reciprocal"""
+    rng = np.random.default_rng(2)
+    a = (np.exp(rng.uniform(-20.0, np.log(2.0 ** 11.4), 2_000_000)) * rng.choice([-1.0, 1.0], 2_000_000)).astype(np.float32)
+    a64 = a.astype(np.float64)
+    u = (1.0 + a64 * a64).astype(np.float32)                       # fma(a, a, 1): one rounding
+    r = (a64 * a64 - (u.astype(np.float64) - 1.0)).astype(np.float32)
+    exact = np.log2(1.0 + a64 * a64)
+    l2 = np.log2(u.astype(np.float64))
+    with_rcp = l2 + (r.astype(np.float64) / u.astype(np.float64)) * 1.4426950408889634
+    with_est = l2 + (r * _recip_estimate(u)).astype(np.float64) * 1.4426950408889634
+    assert np.abs(l2 - exact).max() > 5e-8
+    assert np.abs(with_rcp - exact).max() < 1e-9
+    assert np.abs(with_est - exact).max() < 4.4e-9
