@@ -340,17 +340,19 @@ MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, floa
   log1p_sq_parts(a, l2, r);
   return fmaf(-c1, fmaf(r, 1.44269504088896340736f, l2), c0);
 }
-// The transposed sweep kernel's form of the same: the compensation term (t - (u - 1)) / u is at most 2^-24, so 1 / u is
-// needed to a few bits only -- the exponent-flip estimate bits(1/u) ~ 0x7EF311C7 - bits(u) (within 5.1% for every
-// u >= 1; tests/test_host_numerics.py pins it) instead of v_rcp_f32, two issue slots of the entry's twelve.  What is left of
-// the term's error, <= 4.4e-9 in log2 units, is a twentieth of v_log_f32's own.
+// The transposed sweep kernel's form of the same: the compensation term log2e (1 + a^2 - u) / u is at most 2^-24 log2e, so
+// log2e / u is needed to a few bits only -- the exponent-flip estimate bits(log2e / u) ~ kLog2eOverU - bits(u) (within
+// 1.6 % for every u >= 1: with the factor log2e folded into the constant the piecewise-linear error straddles zero better
+// than the plain reciprocal's 0x7EF311C7, 5.1 %; tests/test_host_numerics.py pins both) instead of v_rcp_f32 and a
+// multiplication: the term enters with ONE fused multiply-add, eight plain + two transcendental instructions an entry.  What
+// is left of the term's error, <= 1.4e-9 in log2 units, is a sixtieth of v_log_f32's own.
+constexpr uint32_t kLog2eOverU = 0x7F35D5C7u;
 MSC_DEV float nich_eval_log2_est(float x, float smu_hi, float smu_lo, float c0, float c1, float s) {
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
-  const float u = fmaf(a, a, 1.0f);                        // (log1p_sq_parts' steps, the reciprocal estimated)
-  const float ru = __uint_as_float(0x7EF311C7u - __float_as_uint(u));
-  const float r = fmaf(a, a, -(u - 1.0f)) * ru;
-  return fmaf(-c1, fmaf(r, 1.44269504088896340736f, hw_log2(u)), c0);
+  const float u = fmaf(a, a, 1.0f);                        // (log1p_sq_parts' steps, log2e / u estimated)
+  const float ru = __uint_as_float(kLog2eOverU - __float_as_uint(u));
+  return fmaf(-c1, fmaf(fmaf(a, a, -(u - 1.0f)), ru, hw_log2(u)), c0);
 }
 // Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:
 //   n = count - 1, m2 = (mean count - x) / n, v2 = ctv - (x - mean)(x - m2), then the posterior and the

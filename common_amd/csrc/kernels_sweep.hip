@@ -634,14 +634,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 MSC_DEV f32x2 rows_eval2(f32x2 x, f32x4 e0, float c2) {
 #pragma clang fp contract(off)
   const f32x2 mh = {e0.x, e0.x}, ml = {e0.y, e0.y}, c0 = {e0.z, e0.z}, nc1 = {-e0.w, -e0.w}, sc = {c2, c2};
-  const f32x2 one = {1.0f, 1.0f}, l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+  const f32x2 one = {1.0f, 1.0f};
   const f32x2 a = __builtin_elementwise_fma(x, sc, -mh) - ml;
   const f32x2 u = __builtin_elementwise_fma(a, a, one);
-  const u32x2 magic = {0x7EF311C7u, 0x7EF311C7u};
+  const u32x2 magic = {kLog2eOverU, kLog2eOverU};
   const f32x2 ru = __builtin_bit_cast(f32x2, magic - __builtin_bit_cast(u32x2, u));
-  const f32x2 r = __builtin_elementwise_fma(a, a, -(u - one)) * ru;
   const f32x2 lg = {hw_log2(u.x), hw_log2(u.y)};
-  const f32x2 s = __builtin_elementwise_fma(nc1, __builtin_elementwise_fma(r, l2e, lg), c0);
+  const f32x2 s = __builtin_elementwise_fma(nc1, __builtin_elementwise_fma(__builtin_elementwise_fma(a, a, -(u - one)), ru, lg), c0);
   return f32x2{__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
 }
 // one row against one table entry (unnormalised log2 probability)

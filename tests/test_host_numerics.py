@@ -3,8 +3,26 @@ import numpy as np
 
 
 def _recip_estimate(u):
-    """family_math.hpp nich_eval_log2_est: bits(1/u) ~ 0x7EF311C7 - bits(u)"""
+    """the plain exponent-flip reciprocal: bits(1/u) ~ 0x7EF311C7 - bits(u)"""
     return (np.uint32(0x7EF311C7) - u.view(np.uint32)).view(np.float32)
+
+
+def _log2e_over_u_estimate(u):
+    """family_math.hpp nich_eval_log2_est: bits(log2e / u) ~ kLog2eOverU - bits(u)"""
+    return (np.uint32(0x7F35D5C7) - u.view(np.uint32)).view(np.float32)
+
+
+def test_exponent_flip_log2e_over_u_is_within_1_6_percent_for_every_u_above_one():
+    """with log2e folded into the constant the estimate's piecewise-linear error straddles zero better than the plain
+    reciprocal's (5.1 %): one multiplication fewer AND a third of the error"""
+    rng = np.random.default_rng(0)
+    mant = np.concatenate([1.0 + rng.random(1_000_000), 1.0 + np.arange(4096) / 4096.0]).astype(np.float32)
+    worst = 0.0
+    for e in (0, 1, 2, 7, 23, 24, 60, 100, 120):
+        u = np.ldexp(mant, e).astype(np.float32)
+        rel = _log2e_over_u_estimate(u).astype(np.float64) * u.astype(np.float64) / 1.4426950408889634 - 1.0
+        worst = max(worst, np.abs(rel).max())
+    assert worst < 0.016, worst
 
 
 def test_exponent_flip_reciprocal_is_within_5_percent_for_every_u_above_one():
@@ -45,6 +63,8 @@ def test_compensated_log1p_of_a_square_through_two_fused_multiply_adds():
     l2 = np.log2(u.astype(np.float64))
     with_rcp = l2 + (r.astype(np.float64) / u.astype(np.float64)) * 1.4426950408889634
     with_est = l2 + (r * _recip_estimate(u)).astype(np.float64) * 1.4426950408889634
+    with_folded = l2 + (r * _log2e_over_u_estimate(u)).astype(np.float64)          # one fused multiply-add on the device
     assert np.abs(l2 - exact).max() > 5e-8
     assert np.abs(with_rcp - exact).max() < 1e-9
     assert np.abs(with_est - exact).max() < 4.4e-9
+    assert np.abs(with_folded - exact).max() < 1.5e-9
