@@ -46,6 +46,17 @@ MSC_DEV void log1p_parts(float t, float &l2, float &r) {
 // rounding dropped (u - 1 is exact) -- four plain instructions + two transcendental where log1p_parts(a * a) takes five,
 // and the remainder now carries the rounding of a^2 itself as well.  The nich evaluations spend their issue slots on
 // exactly this: one in ten fewer.
+// log2(1 + a^2) in one go: v_log_f32 of u plus the remainder times log2e / u, the latter from the exponent-flip estimate
+// bits(log2e / u) ~ kLog2eOverU - bits(u) (within 1.6 % for every u >= 1, tests/test_host_numerics.py; the remainder is at
+// most 2^-24, so what the estimate leaves, <= 1.4e-9, is a sixtieth of v_log_f32's own error): five plain instructions
+// and ONE transcendental.
+constexpr uint32_t kLog2eOverU = 0x7F35D5C7u;
+MSC_DEV float log2_1p_sq(float a) {
+#pragma clang fp contract(off)   // same bits from every kernel that inlines this, whatever surrounds it
+  const float u = fmaf(a, a, 1.0f);
+  const float ru = __uint_as_float(kLog2eOverU - __float_as_uint(u));
+  return fmaf(fmaf(a, a, -(u - 1.0f)), ru, hw_log2(u));
+}
 MSC_DEV void log1p_sq_parts(float a, float &l2, float &r) {
 #pragma clang fp contract(off)   // same bits from every kernel that inlines this, whatever surrounds it
   const float u = fmaf(a, a, 1.0f);
@@ -323,9 +334,16 @@ MSC_DEV float nich_eval(float x, float smu_hi, float smu_lo, float c0, float c1l
 // fused multiply-adds below on it -- 9 plain + 2 transcendental instructions where `acc += nich_eval(...)` is 10 + 2, and
 // the nich phase runs at the issue rate of exactly that mix.  Same mathematics, another
 // association of the float sum: every tile kernel uses this form for its plain (unmasked) nich features.
+// EST (the SWEEP kernels' instantiations): c1 ln2 times log2_1p_sq -- the remainder through the exponent-flip estimate
+// of log2e / u, one transcendental and one constant fewer an evaluation (C3 sweep step 2.03 -> 1.93 ms).  What the
+// estimate leaves, <= 1.4e-9 c1 ln2, is far inside what a draw notices (the oracle tests place every disagreeing draw on
+// a CDF step) but not inside the 1e-6 gate of score_value for groups of thousands of rows (c1 ln2 ~ 1400 at C2: 1.9e-6
+// measured): the score kernels keep v_rcp_f32.
+template <bool EST = false>
 MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c1ln2, float c1, float s) {
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
+  if (EST) return fmaf(-c1ln2, log2_1p_sq(a), acc);
   float l2, r;
   log1p_sq_parts(a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, acc));
@@ -336,9 +354,7 @@ MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c
 MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, float c1, float s) {
 #pragma clang fp contract(off)
   const float a = fmaf(x, s, -smu_hi) - smu_lo;
-  float l2, r;
-  log1p_sq_parts(a, l2, r);
-  return fmaf(-c1, fmaf(r, 1.44269504088896340736f, l2), c0);
+  return fmaf(-c1, log2_1p_sq(a), c0);
 }
 // The transposed sweep kernel's form of the same: the compensation term log2e (1 + a^2 - u) / u is at most 2^-24 log2e, so
 // log2e / u is needed to a few bits only -- the exponent-flip estimate bits(log2e / u) ~ kLog2eOverU - bits(u) (within
@@ -346,13 +362,8 @@ MSC_DEV float nich_eval_log2(float x, float smu_hi, float smu_lo, float c0, floa
 // than the plain reciprocal's 0x7EF311C7, 5.1 %; tests/test_host_numerics.py pins both) instead of v_rcp_f32 and a
 // multiplication: the term enters with ONE fused multiply-add, eight plain + two transcendental instructions an entry.  What
 // is left of the term's error, <= 1.4e-9 in log2 units, is a sixtieth of v_log_f32's own.
-constexpr uint32_t kLog2eOverU = 0x7F35D5C7u;
 MSC_DEV float nich_eval_log2_est(float x, float smu_hi, float smu_lo, float c0, float c1, float s) {
-#pragma clang fp contract(off)
-  const float a = fmaf(x, s, -smu_hi) - smu_lo;
-  const float u = fmaf(a, a, 1.0f);                        // (log1p_sq_parts' steps, log2e / u estimated)
-  const float ru = __uint_as_float(kLog2eOverU - __float_as_uint(u));
-  return fmaf(-c1, fmaf(fmaf(a, a, -(u - 1.0f)), ru, hw_log2(u)), c0);
+  return nich_eval_log2(x, smu_hi, smu_lo, c0, c1, s);    // (one form everywhere since the estimate took log2e in)
 }
 // Leave-one-out (remove_value, i.e. the Welford downdate, then score_value), all in double:
 //   n = count - 1, m2 = (mean count - x) / n, v2 = ctv - (x - mean)(x - m2), then the posterior and the

@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ 
 // so it draws the row's new group by itself (maximum, exponentials, running sum against the dart: sample_discrete's CDF
 // order, no cross-lane step) and writes it to z; (seed, sweep) from `rng`, the uniform of global row row_id0 + r.
 // MNICH: the first phase may hold masked nich columns (an instantiation of its own: the branch costs the others registers)
-template <int TGP, bool SPLIT, bool DRAW = false, bool MNICH = false>
+// EST: the sweeps' nich form (family_math.hpp nich_accum<true>)
+template <int TGP, bool SPLIT, bool DRAW = false, bool MNICH = false, bool EST = false>
 __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
     uint64_t nrows, int32_t *z, const float *__restrict__ own, const float *__restrict__ crp,
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
 #pragma unroll
           for (int j = 0; j < NB; j++) {
             float &a = SPLIT ? accn[gb + j] : acc[gb + j];
-            a = nich_accum(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
+            a = nich_accum<EST>(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
           }
           __builtin_amdgcn_sched_barrier(0);             // (a block's temporaries at a time: left to interleave the blocks, some instantiations spill)
         }
@@ -1245,24 +1246,24 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
   }
 }
 
-template <int TGP, bool SPLIT, bool DRAW, bool MNICH>
+template <int TGP, bool SPLIT, bool DRAW, bool MNICH, bool EST>
 static void launch_tail_rows_m(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
                                const uint64_t *rng, uint64_t row_id0, ZeroSpans zero) {
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW, MNICH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW, MNICH>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
                      row0, nrows, const_cast<int32_t *>(z), own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
 }
-template <int TGP, bool SPLIT, bool DRAW = false>
+template <int TGP, bool SPLIT, bool DRAW = false, bool EST = false>
 static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, bool mnich, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
                                const uint64_t *rng = nullptr, uint64_t row_id0 = 0, ZeroSpans zero = ZeroSpans()) {
-  if (mnich) launch_tail_rows_m<TGP, SPLIT, DRAW, true>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
-  else launch_tail_rows_m<TGP, SPLIT, DRAW, false>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  if (mnich) launch_tail_rows_m<TGP, SPLIT, DRAW, true, EST>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  else launch_tail_rows_m<TGP, SPLIT, DRAW, false, EST>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
 }
 
 // the geometry the launches of one pass share; false: not for this kernel
@@ -1293,10 +1294,10 @@ int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const
   if (K > 64 || crp == nullptr || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
   if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, 0u, tp.pack);
   const uint32_t tgp = (K + 15u) / 16u * 16u;
-#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
+#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
   if (tgp == 16) MSC_SWEEP_ROWS(16);
   else if (tgp == 32)        // (two sums per group here: the one-sum instantiation of 32 spills -- the register allocator's quirk)
-    launch_tail_rows_t<32, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero);
+    launch_tail_rows_t<32, true, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero);
   else if (tgp == 48) MSC_SWEEP_ROWS(48);
   else MSC_SWEEP_ROWS(64);
 #undef MSC_SWEEP_ROWS
@@ -1321,16 +1322,16 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
     const uint32_t kend = std::min<uint32_t>(K, kb + blk), tgp = (kend - kb + 15u) / 16u * 16u;
     // (the packed tables are this launch's: the stream orders the next block's k_tail_pack behind it)
     if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, kb, tp.pack);
-#define MSC_TAIL_ROWS(T, S) launch_tail_rows_t<T, S>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
+#define MSC_TAIL_ROWS(T, S, E) launch_tail_rows_t<T, S, false, E>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
     if (tp.exact) {
-      if (tgp == 16) MSC_TAIL_ROWS(16, true);
-      else if (tgp == 32) MSC_TAIL_ROWS(32, true);
-      else MSC_TAIL_ROWS(48, true);
+      if (tgp == 16) MSC_TAIL_ROWS(16, true, false);
+      else if (tgp == 32) MSC_TAIL_ROWS(32, true, false);
+      else MSC_TAIL_ROWS(48, true, false);
     } else {
-      if (tgp == 16) MSC_TAIL_ROWS(16, false);
-      else if (tgp == 32) MSC_TAIL_ROWS(32, true);          // (as above: the one-sum instantiation of 32 spills)
-      else if (tgp == 48) MSC_TAIL_ROWS(48, false);
-      else MSC_TAIL_ROWS(64, false);
+      if (tgp == 16) MSC_TAIL_ROWS(16, false, true);
+      else if (tgp == 32) MSC_TAIL_ROWS(32, true, true);    // (as above: the one-sum instantiation of 32 spills)
+      else if (tgp == 48) MSC_TAIL_ROWS(48, false, true);
+      else MSC_TAIL_ROWS(64, false, true);
     }
 #undef MSC_TAIL_ROWS
   }

@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
     const bool tail_only = nsplit == 0;                    // (score_tile, SPLIT: the prior is added afterwards then)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = tail_only ? make_float4(0, 0, 0, 0) : crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile<R, W, DM, true>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
+    score_tile<R, W, DM, true, true>(feats, nfeat, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);   // (EST: the sweeps' nich form)
     if (tail_only) {
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], crp_prior4(logcnt, lane_bcast(erow, r)));
@@ -1089,10 +1089,10 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const float x = lane_bcast(xv, r);
-          acc[r].x = nich_accum(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
-          acc[r].y = nich_accum(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-          acc[r].z = nich_accum(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-          acc[r].w = nich_accum(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+          acc[r].x = nich_accum<true>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+          acc[r].y = nich_accum<true>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+          acc[r].z = nich_accum<true>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+          acc[r].w = nich_accum<true>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time
         }
       }

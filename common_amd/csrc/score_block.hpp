@@ -369,7 +369,7 @@ MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat
   return s;
 }
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
-template <int R, int W>
+template <int R, int W, bool EST = false>
 MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t ktile,
                                   int lane, int wave, uint64_t myrow, bool has_row, float4 *__restrict__ lds,
                                   float4 (&acc)[R]) {
@@ -392,10 +392,10 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const float x = lane_bcast(xv, r);
-        acc[r].x = nich_accum(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
-        acc[r].y = nich_accum(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-        acc[r].z = nich_accum(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-        acc[r].w = nich_accum(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+        acc[r].x = nich_accum<EST>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+        acc[r].y = nich_accum<EST>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+        acc[r].z = nich_accum<EST>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+        acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
       }
     }
     f0 = f1;
@@ -515,7 +515,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
 // split the two phases between them (k_score_tile_roles) and the ones that run them one after the other give a row
 // the same bits.  A state of unmasked nich features only (nsplit == 0) has nothing in the first sum: its caller
 // starts acc at zero and adds what it would have started from afterwards (the same sum, one accumulator alive).
-template <int R, int W, bool DM, bool SPLIT = false>
+template <int R, int W, bool DM, bool SPLIT = false, bool EST = false>
 MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nsplit, uint32_t kpad, uint32_t ktile,
                         int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds, float4 (&acc)[R]) {
   score_tile_groups<R, W, DM>(feats, nsplit, kpad, ktile, lane, row_abs0, nr, row_safe, lds, acc);
@@ -523,10 +523,10 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nspli
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     static_assert(SPLIT, "the second phase is always summed on its own (score_tile_nich_tail sets its accumulators)");
     if (nsplit == 0) {                                    // (the caller passed zeros and adds the prior afterwards)
-      score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
+      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
     } else {
       float4 accn[R];
-      score_tile_nich_tail<R, W>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, accn);
+      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, accn);
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], accn[r]);
     }
