@@ -57,7 +57,8 @@ def parse():
                          "msc_device_alloc_probed (--probe-alloc candidates, all probed), or a plain torch.empty")
     ap.add_argument("--probe-alloc", type=int, default=24, help="candidates of msc_device_alloc_probed (--alloc probed)")
     ap.add_argument("--min-region-ms", type=float, default=10.0,
-                    help="a timed region shorter than this is re-run with more steps (reported as steps, with steps_requested)")
+                    help="a timed region shorter than this gets a longer one measured beside it (config.long_region); "
+                         "`value` is always the --steps region")
     return ap.parse_args()
 
 
@@ -195,7 +196,28 @@ def main():
         backend = os.environ.get("MSC_BENCH_BACKEND", "nccl")
         if backend != "nccl":
             local = 0
-        torch.cuda.set_device(local)
+        dry = os.environ.get("MSC_BENCH_DRYRUN", "0") not in ("", "0")
+        if not dry:
+            torch.cuda.set_device(local)
+    if (world > 1 or force_c5) and dry:
+        # the launch plumbing alone, on the CPU (tests/test_bench_launch_cpu.py): ranks, rendezvous, one sum over the
+        # process group, the line on stdout and nothing else there -- no GPU call, no measurement, and the line says so
+        dist.init_process_group("gloo")
+        seen = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d pid %d" % (rank, os.getpid()))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": "Gibbs-sweep rows/sec", "value": None, "n_gpus": world,
+                              "ranks_seen": int(seen.item()), "rank_devices": names, "steps": a.steps, "warmup": a.warmup,
+                              "config": {"backend": "gloo", "workload": "none (MSC_BENCH_DRYRUN: launch plumbing only)"}}), flush=True)
+        os.dup2(2, 1)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     ctx = common_amd.Context(device=local)
     if world > 1 or force_c5:
         # the one-rank reference of the weak-scaling ratio, in this very job: rank 0 runs its shard's sweep step alone,
@@ -341,7 +363,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_
         "ms_per_step_ranks": {"max": ms, "min": dt_min / a.steps * 1e3},
         "one_rank_reference": ref,
         "weak_scaling_eff": (value / (world * ref["value"])) if ref else None,
-        "steps": a.steps, "warmup": prewarm + a.warmup, "warmup_requested": a.warmup, "ms_per_step": ms,
+        "steps": a.steps, "warmup": a.warmup, "preconditioning_steps": prewarm, "ms_per_step": ms,
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C5 NICH N=%d rows (%d per GPU) x K=%d groups, row-sharded synchronous Gibbs sweep: fused "
@@ -371,7 +393,8 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     st.accumulate(view, z)                                   # suff-stats from the true components
     # the [N, K] matrix is caller-owned; where the driver places it decides between ~5.5 and ~7.0 TB/s for the same
     # kernel (profiles/r02_placement_study.txt).  The headline uses the library's DEFAULT allocator (msc_device_alloc:
-    # from 64 MiB on a buffer mapped from 32 MiB chunks, up to six candidates tried until one fills at 6.6 TB/s); the
+    # from 64 MiB on a buffer mapped from 32 MiB chunks, up to twelve candidates tried until one fills at 6.65 TB/s, six
+    # when they all fill alike -- include/microscopes_hip.h); the
     # same pass into a plain torch.empty is measured beside it (roofline.frac_caller_alloc)
     if a.alloc == "torch":
         out = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -388,12 +411,14 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     if a.tune:
         tuned = st.score_tune(view, out)                     # explicit and synchronous; never inside msc_score_value
     st.score_value(view, out=out)                            # derived tables (k_prepare) are built here, once
-    # the clocks need ~100 launches (~15 ms) after an idle stretch (profiles/r02_launch_transient.txt): the warm-up is
-    # never shorter than 200 passes, and `warmup` in the line is what actually ran (`warmup_requested` what was asked)
-    warmup_run = max(a.warmup, 200)
-    for _ in range(warmup_run):
+    # the clocks need ~100 launches (~15 ms) after an idle stretch (profiles/r02_launch_transient.txt).  That is the
+    # device's state, not the bench's warm-up: 200 conditioning passes run first and are reported as such
+    # (config.preconditioning_passes); then EXACTLY --warmup untimed passes and EXACTLY --steps timed ones, as asked --
+    # `steps` / `warmup` in the line are the command line's
+    precondition = 200
+    for _ in range(precondition + a.warmup):
         st.score_value(view, out=out)
-    launched = 1 + warmup_run + (7 * 8 if a.tune else 0)        # launches of the headline kernel so far (for the trace summary)
+    launched = 1 + precondition + a.warmup + (7 * 8 if a.tune else 0)   # launches of the headline kernel so far (for the trace summary)
 
     def region(buf, steps):
         """HIP events over the timed region, on the stream the library launches on: ONE pair around the launches (a
@@ -408,16 +433,18 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         ev1.record()
         sync_all()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
-    steps_requested = a.steps
     dt, kern_avg_ms = region(out, a.steps)
-    short_region = None
+    timed_from = launched
+    launched += a.steps
+    long_region = None
     if dt * 1e3 < a.min_region_ms:
-        # a 3 ms region is a handful of clock ticks of the driver's sampling: the line reports a region of >= 200 steps
-        # (and what the short one read, for the record)
-        short_region = {"steps": a.steps, "ms_per_step": dt / a.steps * 1e3, "kernel_avg_ms": kern_avg_ms}
-        launched += a.steps
-        a.steps = max(200, int(a.min_region_ms / (dt / a.steps * 1e3)) + 1)
-        dt, kern_avg_ms = region(out, a.steps)
+        # a 3 ms region is a handful of clock ticks of whoever samples it from outside: a region of >= 200 steps is
+        # measured BESIDE the one that was asked for (config.long_region); `value` stays with the steps asked for
+        lsteps = max(200, int(a.min_region_ms / (dt / a.steps * 1e3)) + 1)
+        ldt, lkern = region(out, lsteps)
+        long_region = {"steps": lsteps, "ms_per_step": ldt / lsteps * 1e3, "kernel_avg_ms": lkern,
+                       "value": float(N) * K / (ldt / lsteps),
+                       "frac": (4.0 * N + 4.0 * N * K) / (lkern * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # (per-launch spread, outside the timed region)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 50))]
     for s_, e_ in ev:
@@ -444,8 +471,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         del tbuf
     line = {
         "metric": "score_value evals/sec", "value": evals / (dt / a.steps), "unit": "evals/s",
-        "n_gpus": 1, "steps": a.steps, "steps_requested": steps_requested, "warmup": warmup_run,
-        "warmup_requested": a.warmup, "ms_per_step": ms,
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "C2 NICH scalar-Gaussian score_value pass, N=%d rows/GPU x K=%d groups x D=1, "
@@ -453,7 +479,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                                "9 us, runs when suff-stats change)" % (N, K),
                    "rows_per_gpu": N, "groups": K, "features": 1, "parallelism": "row-shard x1",
                    "launch_shape": "msc_score_tune -> %s" % (tuned,) if tuned else "default (4 rows x 2 visits)",
-                   "short_region": short_region,
+                   "preconditioning_passes": precondition, "long_region": long_region,
                    "score_matrix": placement},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
@@ -461,7 +487,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                      "traffic": traffic if (N, K) == (1_000_000, 256) else None,
                      "traffic_source": traffic_src,
                      "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
-                     "timed_region_launches": [launched, launched + a.steps],      # of this kernel, in launch order
+                     "timed_region_launches": [timed_from, timed_from + a.steps],   # of this kernel, in launch order
 
                      "kernel_min_ms_single_launch_events": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes,
                      "out_va": "%#x" % out.data_ptr()},

@@ -61,6 +61,7 @@ _SIGS = {
                                                    C.c_uint32, C.POINTER(C.c_void_p),
                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "msc_dataview_destroy": (C.c_int, [C.c_void_p]),
+    "msc_dataview_invalidate": (C.c_int, [C.c_void_p]),
     "msc_dataview_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "msc_dataview_column": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                       C.POINTER(RuntimeType)]),
@@ -95,6 +96,9 @@ _SIGS = {
     "msc_state_reduce_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "msc_state_commit_reduce": (C.c_int, [C.c_void_p]),
+    "msc_state_reduce_pack": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "msc_state_reduce_unpack": (C.c_int, [C.c_void_p]),
+    "msc_state_set_sweep_rows": (C.c_int, [C.c_void_p, C.c_uint64]),
     "msc_comm_unique_id_bytes": (C.c_size_t, []),
     "msc_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "msc_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -93,13 +93,15 @@ static int device_error_check(msc_context *ctx) {
   std::atomic_thread_fence(std::memory_order_acquire);
   const uint32_t code = w[0], detail = w[1];
   w[0] = 0;
-  const char *what = (code & 1u) ? "a wave-subset barrier of a tile kernel timed out (workgroup %u): rows of that launch are wrong"
-                     : (code & 2u) ? "msc_entity_op: leave from a group the row is not in / an empty group, or join of an assigned row (group %u)"
-                     : (code & 4u) ? "msc_relation_slice_scores: a block offset beyond the score row (cell %u)"
-                                   : "unknown device-side error (detail %u)";
-  char buf[256];
-  std::snprintf(buf, sizeof buf, what, detail);
-  return fail(MSC_EDEVICE, "reported by an earlier kernel on device %d: %s; rebuild the affected state's tables", ctx->device, buf);
+  // (code bits: every kind that was reported since the last check is named; `detail` belongs to the first)
+  std::string what;
+  auto add = [&](const char *t) { if (!what.empty()) what += "; "; what += t; };
+  if (code & 1u) add("a wave-subset barrier of a tile kernel timed out (detail: workgroup): rows of that launch are wrong");
+  if (code & 2u) add("msc_entity_op: leave from a group the row is not in / an empty group, or join of an assigned row (detail: group)");
+  if (code & 4u) add("msc_relation_slice_scores: a block offset beyond the score row (detail: cell)");
+  if (code & ~7u) add("unknown device-side error");
+  return fail(MSC_EDEVICE, "reported by an earlier kernel on device %d: %s [detail of the first: %u]; rebuild the affected state's tables",
+              ctx->device, what.c_str(), detail);
 }
 
 extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
@@ -134,7 +136,11 @@ extern "C" int msc_context_create(int device, void *stream, msc_context **out) {
     (void)hipGetLastError();
     ctx->sync_word_host = nullptr;
   }
-  MSC_TRY(device_error_word(device, &ctx->err_host));
+  if (const int rc = device_error_word(device, &ctx->err_host)) {      // (nothing pinned is left behind)
+    if (ctx->mailbox_host) (void)hipHostFree(ctx->mailbox_host);
+    if (ctx->sync_word_host) (void)hipHostFree(ctx->sync_word_host);
+    return rc;
+  }
   *out = ctx.release();
   return MSC_OK;
 }
@@ -244,12 +250,17 @@ static void vmm_free(msc_context::VmmAlloc &a) {
 // from separately created 32 MiB chunks land in the upper band more often than hipMalloc'ed ones.  So a candidate is
 // mapped from chunks, stream-filled a few times with the score kernels' store pattern, and kept when it takes the stream
 // at `accept_gbps` or better; otherwise the next candidate is tried while the rejected ones are still held (released
-// first, the driver would hand the same pages back), up to `max_candidates`, and the fastest wins.  Per-chunk selection
-// was tried and does not work: a chunk's rate inside a fill follows its position in the launch, not the chunk
-// (tools/microbench/placement_chunks.hip, profiles/r03_placement_chunks.txt).  Synchronous (about 1 ms per candidate
-// and GB).
-static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates, float accept_gbps, void **out,
-                        float *rates_gbps, uint32_t *chosen) {
+// first, the driver would hand the same pages back), and the fastest wins.  Three things end the search early:
+//   * `max_candidates` (msc_device_alloc: 12);
+//   * the candidates held side by side would exceed HALF of what the device had free when the call began (the transient
+//     footprint is the caller's memory too: torch's caching allocator, other tenants);
+//   * a FLAT box: after `flat_after` candidates whose fill rates lie within 6 % of each other and below the mark there is
+//     no fast stretch to find here (the round-3 driver's box: 24 of 24 at 5.40-5.67 TB/s) -- stop, keep the best.
+// Per-chunk selection was tried and does not work: a chunk's rate inside a fill follows its position in the launch, not
+// the chunk (tools/microbench/placement_chunks.hip, profiles/r03_placement_chunks.txt).  Synchronous (about 1 ms per
+// candidate and GB).
+static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates, float accept_gbps, uint32_t flat_after,
+                        void **out, float *rates_gbps, uint32_t *chosen) {
   static const bool no_vmm = std::getenv("MSC_ALLOC_NO_VMM") != nullptr;       // (A/B knob: plain hipMalloc candidates)
   struct Cand { void *p; bool vmm; msc_context::VmmAlloc v; };
   std::vector<Cand> bufs;
@@ -266,12 +277,25 @@ static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates
   int rc = MSC_OK;
   const int reps = nbytes >= (256u << 20) ? 5 : 8;
   const bool want_vmm = !no_vmm && nbytes >= (64u << 20);                      // small buffers: not worth 32 MiB chunks
+  size_t free_at_start = 0;
+  {
+    size_t total_b = 0;
+    if (hipMemGetInfo(&free_at_start, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      free_at_start = 0;
+    }
+  }
   for (uint32_t i = 0; i < max_candidates; i++) {
-    if (i > 0) {                                                               // never take the device's last memory for a probe
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * nbytes + (1ull << 30)) {
+    if (i > 0) {                                                               // never take the device's last memory for a probe,
+      size_t free_b = 0, total_b = 0;                                          // nor more than half of what was free for all of them
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * nbytes + (1ull << 30) ||
+          (flat_after != 0 && (size_t)(i + 1) * nbytes > free_at_start / 2)) {
         (void)hipGetLastError();
         break;
+      }
+      if (flat_after != 0 && i >= flat_after && rate.size() == i) {            // a flat box: nothing to find
+        const float hi = *std::max_element(rate.begin(), rate.end()), lo = *std::min_element(rate.begin(), rate.end());
+        if (hi > 0.f && (hi - lo) <= 0.06f * hi) break;
       }
     }
     Cand c{nullptr, false, {}};
@@ -329,18 +353,20 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
   MSC_REQUIRE(ctx && out, "null argument");
   *out = nullptr;
   MSC_HIP(hipSetDevice(ctx->device));
-  // MSC_ALLOC_CANDIDATES (default 24; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6650: a
+  // MSC_ALLOC_CANDIDATES (default 12; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6650: a
   // candidate that fills at 6.7 TB/s takes the C2 pass at 0.87-0.88 of the HBM roof, one at 6.5 at 0.83-0.87, one at 6.2
-  // at 0.80-0.83; when none reaches the mark the best of all is kept, ~1 ms a candidate).  Candidates
-  // held side by side walk through physical memory, and where the fast stretches lie differs from box to box: one box
-  // offered one within six candidates in ten processes of ten, another none within twelve in one process of twelve
-  // (profiles/r03_alloc_distribution.jsonl)
-  static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 24;
+  // at 0.80-0.83; when none reaches the mark the best of all is kept, ~1 ms a candidate and GB) / MSC_ALLOC_FLAT_AFTER
+  // (default 6: candidates after which a box whose rates all lie within 6 % is taken to have no fast stretch).
+  // Candidates held side by side walk through physical memory, and where the fast stretches lie differs from box to
+  // box: one box offered one within six candidates in ten processes of ten, another none within twelve in one process
+  // of twelve (profiles/r03_alloc_distribution.jsonl), the round-3 driver's none within 24
+  static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 12;
   static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6650.f;
+  static const int flat = std::getenv("MSC_ALLOC_FLAT_AFTER") ? std::atoi(std::getenv("MSC_ALLOC_FLAT_AFTER")) : 6;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if (nbytes >= (64u << 20) && cand >= 1 && !capturing)
-    return alloc_placed(ctx, nbytes, (uint32_t)std::min(cand, 64), accept, out, nullptr, nullptr);
+    return alloc_placed(ctx, nbytes, (uint32_t)std::min(cand, 64), accept, (uint32_t)std::max(flat, 2), out, nullptr, nullptr);
   void *p = nullptr;
   MSC_HIP(hipMalloc(&p, nbytes ? nbytes : 1));
   const hipError_t e = hipMemsetAsync(p, 0, nbytes ? nbytes : 1, ctx->stream);
@@ -361,7 +387,7 @@ extern "C" int msc_device_alloc_probed(msc_context *ctx, size_t nbytes, uint32_t
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
     return fail(MSC_EINVAL, "msc_device_alloc_probed waits for the device: not on a capturing stream");
-  return alloc_placed(ctx, nbytes, candidates, 1e30f, out, rates_gbps, chosen);     // every candidate is probed, the best kept
+  return alloc_placed(ctx, nbytes, candidates, 1e30f, 0u, out, rates_gbps, chosen);     // every candidate is probed, the best kept
 }
 extern "C" int msc_device_alloc_stats(msc_context *ctx, float *rates_gbps, uint32_t capacity, uint32_t *ntried, uint32_t *chosen) {
   MSC_REQUIRE(ctx, "null context");
@@ -434,6 +460,42 @@ extern "C" int msc_device_download(msc_context *ctx, void *dst_host, const void 
 static uint64_t next_view_serial() {
   static std::atomic<uint64_t> n{0};
   return ++n;
+}
+// The serials of the views that exist.  A state remembers the view it last bound by pointer AND serial and keeps no
+// reference to it (the reference's dataviews are borrowed the same way, recarray/_dataview.pxd:24-27); before it looks at
+// that view again outside a call that was handed one -- msc_state_set_hp re-plans, msc_sweep_* price kernels by its row
+// count -- it asks here whether the view is still there (bound_view_of).  A destroyed view's serial never comes back, so
+// a new view at the old address does not pass for it.
+static std::mutex g_views_mu;
+static std::vector<uint64_t> g_live_views;
+static void view_register(uint64_t serial) {
+  std::lock_guard<std::mutex> lock(g_views_mu);
+  g_live_views.push_back(serial);
+}
+static void view_unregister(uint64_t serial) {
+  std::lock_guard<std::mutex> lock(g_views_mu);
+  g_live_views.erase(std::remove(g_live_views.begin(), g_live_views.end(), serial), g_live_views.end());
+}
+static bool view_alive(uint64_t serial) {
+  std::lock_guard<std::mutex> lock(g_views_mu);
+  return std::find(g_live_views.begin(), g_live_views.end(), serial) != g_live_views.end();
+}
+// the view the state last bound, if it still exists and is the one that was bound (msc_dataview_invalidate moves a
+// view's serial on); otherwise the binding is dropped: no column pointer of it is dereferenced again, the next call
+// that brings a view binds afresh
+static const msc_dataview *bound_view_of(msc_state *st) {
+  if (st->bound_view == nullptr) return nullptr;
+  if (view_alive(st->bound_serial) && st->bound_view->serial == st->bound_serial) return st->bound_view;
+  st->bound_view = nullptr;
+  st->bound_serial = 0;
+  st->bound_cols.clear();
+  for (FeatDesc &d : st->desc_host) {
+    d.col = nullptr;
+    d.mask = nullptr;
+    d.col_sentinel = nullptr;
+    d.dm_tot = nullptr;
+  }
+  return nullptr;
 }
 
 static void free_all(std::vector<void *> &owned) {
@@ -510,6 +572,7 @@ extern "C" int msc_dataview_from_records(msc_context *ctx, const void *host_reco
     if (e != hipSuccess) return cleanup(fail(MSC_EHIP, "k_unpack failed: %s", hipGetErrorString(e)));
   }
   cleanup(MSC_OK);
+  view_register(v->serial);
   *out = v.release();
   return MSC_OK;
 }
@@ -539,16 +602,43 @@ extern "C" int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows
   v->col_max.assign(ntypes, -1);
   v->dm_max.assign(ntypes, std::vector<uint32_t>());
   v->dm_tot.assign(ntypes, nullptr);
+  view_register(v->serial);
   *out = v.release();
   return MSC_OK;
 }
 
 extern "C" int msc_dataview_destroy(msc_dataview *view) {
   if (!view) return MSC_OK;
+  view_unregister(view->serial);                          // (states that had it bound drop the binding: bound_view_of)
   (void)hipSetDevice(view->ctx->device);
+  (void)hipStreamSynchronize(view->ctx->stream);
   free_all(view->owned);
   free_all(view->owned_lazy);
   delete view;
+  return MSC_OK;
+}
+
+// What the library derives from a view's columns and keeps WITH the view -- a column converted to a model's value type
+// (column_as), a masked lookup column with the mask folded in (sentinel_column), bool columns packed four to a byte
+// (packed_column), the maxima of count columns and dm row totals that size the exact tables -- is a SNAPSHOT of the
+// columns' contents.  A view made by msc_dataview_from_records owns its columns and nothing else can write them; a view
+// over the caller's device columns (msc_dataview_from_device_columns) must be told when the caller has rewritten them in
+// place (the usual minibatch pattern): this call drops every derived copy and moves the view's serial on, so that every
+// state binds -- and derives -- afresh at its next call.  Synchronises the context's stream.
+extern "C" int msc_dataview_invalidate(msc_dataview *view) {
+  MSC_REQUIRE(view, "null view");
+  MSC_HIP(hipSetDevice(view->ctx->device));
+  MSC_HIP(hipStreamSynchronize(view->ctx->stream));
+  view_unregister(view->serial);
+  free_all(view->owned_lazy);
+  view->converted.clear();
+  view->sentinels.clear();
+  view->packed_bits.clear();
+  view->col_max.assign(view->cols.size(), -1);
+  view->dm_max.assign(view->cols.size(), std::vector<uint32_t>());
+  view->dm_tot.assign(view->cols.size(), nullptr);
+  view->serial = next_view_serial();
+  view_register(view->serial);
   return MSC_OK;
 }
 
@@ -731,6 +821,7 @@ static int packed_column(const msc_dataview *view, const void *const *cols, int 
 }
 
 static int plan_groups(msc_state *st) {
+  const msc_dataview *const bview = bound_view_of(st);    // (null: no column pointer survives in desc_host either)
   auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
   std::vector<FeatDesc> &t = st->desc_tile_host;
   t.clear();
@@ -783,7 +874,9 @@ static int plan_groups(msc_state *st) {
   std::vector<FeatDesc> &tf = st->desc_fuse_host;
   std::vector<uint32_t> extra_f;
   tf.clear();
-  const bool may_fuse = st->bound_view != nullptr && std::getenv("MSC_NO_BB_FUSE") == nullptr;
+  // (the view is only looked at while it exists: a plan made after its view is gone -- msc_state_set_hp on a dd feature
+  // re-plans -- fuses nothing and holds no column; the next call that brings a view binds and plans again)
+  const bool may_fuse = bview != nullptr && std::getenv("MSC_NO_BB_FUSE") == nullptr;
   // (columns with a mask: their mask-folded copies, three states a value -- 0, 1, masked = the member's zero row --,
   // three at a time against 27 rows)
   std::vector<uint32_t> members[2];                        // [0] unmasked, [1] masked: the fusable features, in plan order
@@ -826,7 +919,7 @@ static int plan_groups(msc_state *st) {
       d.fuse_src[j] = mj.tab;
       taken[mem[fq.first + j]] = true;
     }
-    MSC_TRY(packed_column(st->bound_view, cols, (int)fq.m, fq.radix, &d.col));
+    MSC_TRY(packed_column(bview, cols, (int)fq.m, fq.radix, &d.col));
     d.fuse_n = fq.m;
     d.fuse_radix = fq.radix;
     d.col_type = MSC_TYPE_U8;
@@ -1316,6 +1409,7 @@ static int bind_view(msc_state *st, const msc_dataview *view, const uint32_t *co
   MSC_REQUIRE(row0 + nrows <= view->nrows, "rows [%llu,%llu) outside the view (%llu rows)",
               (unsigned long long)row0, (unsigned long long)(row0 + nrows),
               (unsigned long long)view->nrows);
+  (void)bound_view_of(st);                                  // (a binding to a view that is gone, or was invalidated, is dropped first)
   bool same = st->bound_view == view && st->bound_serial == view->serial && st->bound_cols.size() == st->nfeat;
   for (uint32_t f = 0; f < st->nfeat && same; f++) same = st->bound_cols[f] == (cols ? cols[f] : f);
   if (same) {
@@ -1480,8 +1574,9 @@ static int tail_plan(msc_state *st, TailPlan &tp) {
   return MSC_OK;
 }
 
+// (called inside calls that have just bound their view: bind_view leaves bound_view current)
 static bool gp_beyond_table(const msc_state *st, uint32_t f) {
-  if (!st->bound_view) return false;
+  if (!st->bound_view || f >= st->bound_cols.size()) return false;
   const uint32_t c = st->bound_cols[f];
   if (is_count_family(st->feats[f].family)) return st->bound_view->col_max[c] >= (long long)kGpMaxTable;
   if (st->feats[f].family == MSC_DM)      // a row goes to the double path when its total is beyond the tables
@@ -1835,7 +1930,7 @@ static bool sweep_is_niw1(const msc_state *st) {
 // 128 floats per row and the row sampler -- against the rounds of the fused tile sweep kernel; for a tail beyond a full
 // tile, against one more tile pass, the materialised matrix and the sampler)
 static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
-  const uint64_t rows = st->bound_view ? st->bound_view->nrows : 0;
+  const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
   if (const char *forced = std::getenv("MSC_TAIL_MIN_ROWS")) return rows >= (uint64_t)std::atoll(forced);
   if (rows < kTailMinRows) return false;
   const int cus = st->ctx->num_cus;
@@ -2172,6 +2267,38 @@ extern "C" int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n
   if (n_i64) *n_i64 = st->n_i64;
   if (dev_f64) *dev_f64 = st->red_f64;
   if (n_f64) *n_f64 = st->n_f64;
+  return MSC_OK;
+}
+
+// the same tables as ONE float64 buffer, for a collective that takes one dtype (counts ride along as doubles: exact
+// below 2^53): pack -> all-reduce *pack_dev -> unpack -> msc_state_commit_reduce.  One launch each.
+extern "C" int msc_state_reduce_pack(msc_state *st, void **pack_dev, size_t *n_f64) {
+  MSC_REQUIRE(st && pack_dev, "null argument");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  if (!st->red_pack) MSC_TRY(dev_alloc(st->owned, &st->red_pack, st->n_i64 + st->n_f64));
+  if (launch_pack64(st->ctx->stream, false, st->red_i64, st->n_i64, st->red_f64, st->n_f64, st->red_pack))
+    return fail(MSC_EHIP, "k_pack64 launch failed");
+  *pack_dev = st->red_pack;
+  if (n_f64) *n_f64 = st->n_i64 + st->n_f64;
+  return MSC_OK;
+}
+extern "C" int msc_state_reduce_unpack(msc_state *st) {
+  MSC_REQUIRE(st, "null state");
+  MSC_REQUIRE(st->red_pack, "msc_state_reduce_unpack before msc_state_reduce_pack");
+  MSC_HIP(hipSetDevice(st->ctx->device));
+  if (launch_pack64(st->ctx->stream, true, st->red_i64, st->n_i64, st->red_f64, st->n_f64, st->red_pack))
+    return fail(MSC_EHIP, "k_unpack64 launch failed");
+  return MSC_OK;
+}
+
+// A sweep chooses between the lane <-> row kernel and the tile kernels by ROW COUNT (sweep_rows_pays), and the two sum a
+// row's features in different float associations: a shard must choose what the whole would, or a dart may cross a CDF
+// step.  By default the count is the bound view's -- right for row ranges of one view.  A driver that gives every rank a
+// view of its own shard (common_amd/dist.py ShardedSweep, msc_sweep_step_sharded callers) states the rows of the WHOLE
+// here, once; 0 = back to the view's count.
+extern "C" int msc_state_set_sweep_rows(msc_state *st, uint64_t global_rows) {
+  MSC_REQUIRE(st, "null state");
+  st->sweep_rows_hint = global_rows;
   return MSC_OK;
 }
 

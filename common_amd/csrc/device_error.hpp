@@ -21,8 +21,9 @@ static __device__ uint32_t *g_dev_error = nullptr;
 MSC_DEV void report_device_error(uint32_t code, uint32_t detail) {
   uint32_t *w = g_dev_error;
   if (w == nullptr) return;
-  __hip_atomic_store(w + 1, detail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(w, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // code BITS: a second error adds its bit, the detail stays the first one's (the host reads and clears both)
+  const uint32_t before = __hip_atomic_fetch_or(w, code, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (before == 0u) __hip_atomic_store(w + 1, detail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the body of every translation unit's bind_error_word_*(): point this unit's copy at the device's word

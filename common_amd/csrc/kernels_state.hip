@@ -765,6 +765,29 @@ __global__ void k_zero64(unsigned long long *__restrict__ a, size_t na, unsigned
     else b[i - na] = 0ull;
   }
 }
+// The additive tables as ONE float64 buffer for an all-reduce that wants one dtype (common_amd/dist.py: the payload is a
+// few KB, so the exchange costs the collective's latency -- one collective, not two): counts as doubles (integers below
+// 2^53 add exactly and in any order, so they come back bit-exact) followed by the float64 sums; and back.
+__global__ void k_pack64(const long long *__restrict__ i64, size_t ni, const double *__restrict__ f64, size_t nf, double *__restrict__ pack) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni + nf; i += stride)
+    pack[i] = i < ni ? (double)i64[i] : f64[i - ni];
+}
+__global__ void k_unpack64(long long *__restrict__ i64, size_t ni, double *__restrict__ f64, size_t nf, const double *__restrict__ pack) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni + nf; i += stride) {
+    if (i < ni) i64[i] = (long long)pack[i];
+    else f64[i - ni] = pack[i];
+  }
+}
+int launch_pack64(hipStream_t stream, bool unpack, long long *i64, size_t ni, double *f64, size_t nf, double *pack) {
+  if (ni + nf == 0) return 0;
+  const unsigned blocks = (unsigned)std::min<size_t>((ni + nf + 255) / 256, 2048);
+  if (unpack) hipLaunchKernelGGL(k_unpack64, dim3(blocks), dim3(256), 0, stream, i64, ni, f64, nf, pack);
+  else hipLaunchKernelGGL(k_pack64, dim3(blocks), dim3(256), 0, stream, i64, ni, f64, nf, pack);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_zero64(hipStream_t stream, void *a, size_t na, void *b, size_t nb) {
   if (na + nb == 0) return 0;
   const unsigned blocks = (unsigned)std::min<size_t>((na + nb + 255) / 256, 2048);

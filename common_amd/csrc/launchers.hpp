@@ -159,6 +159,7 @@ int launch_commit(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint
 int launch_commit_prepare(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad,
                           const long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, uint64_t *rng_bump,
                           uint32_t value_slices);
+int launch_pack64(hipStream_t stream, bool unpack, long long *i64, size_t ni, double *f64, size_t nf, double *pack);
 int launch_zero64(hipStream_t stream, void *a, size_t na, void *b, size_t nb);   // 8-byte words
 int launch_stream_fill(hipStream_t stream, int num_cus, void *buf, size_t nbytes);   // the score kernels' store pattern, zeros
 int launch_lift(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t kpad,

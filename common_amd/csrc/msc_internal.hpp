@@ -343,6 +343,8 @@ struct msc_state {
   long long *red_i64 = nullptr;   // [cnt[kpad] | feature slices]
   double *red_f64 = nullptr;
   size_t n_i64 = 0, n_f64 = 0;
+  double *red_pack = nullptr;     // both tables as one float64 buffer (msc_state_reduce_pack), made at the first call
+  uint64_t sweep_rows_hint = 0;   // msc_state_set_sweep_rows: the rows of the WHOLE a sharded sweep's kernel choice goes by
   uint32_t *cnt_u32 = nullptr;    // group sizes (group_manager counts), [kpad]
   float *logpc = nullptr;         // log pseudocount per group, [kpad] (+ loo variants, see prepare)
   bool cnt_additive_valid = false;

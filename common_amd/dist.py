@@ -51,20 +51,37 @@ def allreduce_tables(red_i64, red_f64, group=None, pack=None):
 
 
 class ShardedSweep(object):
-    """state + this rank's shard of the rows; sweep() = assign -> accumulate -> all-reduce -> commit."""
+    """state + this rank's shard of the rows; sweep() = assign -> accumulate -> all-reduce -> commit.
 
-    def __init__(self, state, view, z, first_global_row, group=None):
+    The exchange is pack (one launch of the library: both tables into one float64 buffer) -> ONE all_reduce -> unpack
+    (one launch) -> commit: the launch count of the C / C++ driver (msc_sweep_step_sharded) plus the two copies a
+    one-dtype collective needs.  The kernels a sweep takes are chosen by the rows of the WHOLE dataset (the shards'
+    sum, told to the state once), so that the shards draw what an unsharded sweep draws."""
+
+    def __init__(self, state, view, z, first_global_row, group=None, global_rows=None):
         self.state, self.view, self.z = state, view, z
         self.row_id0 = int(first_global_row)
         self.group = group
         self.red_i64, self.red_f64 = state.reduce_buffers()
-        self._pack = torch.empty(self.red_i64.numel() + self.red_f64.numel(), dtype=torch.float64,
-                                 device=self.red_f64.device)
+        if global_rows is None:
+            global_rows = int(view.nrows)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                t = torch.tensor([global_rows], dtype=torch.int64, device=self.red_f64.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                global_rows = int(t.item())
+        self.global_rows = int(global_rows)
+        state.set_sweep_rows(self.global_rows)
+
+    def _exchange(self):
+        pack = self.state.reduce_pack()
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)
+        self.state.reduce_unpack()
 
     def rebuild_tables(self):
         """suff-stats of the global assignment: local accumulate, sum across ranks, commit."""
         self.state.accumulate(self.view, self.z, reset=True, commit=False)
-        allreduce_tables(self.red_i64, self.red_f64, self.group, self._pack)
+        if not self._alone():
+            self._exchange()
         self.state.commit_reduce()
 
     def _alone(self):
@@ -77,5 +94,5 @@ class ShardedSweep(object):
             self.state.sweep_step(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
             return
         self.state.sweep_step_begin(self.view, self.z, seed=seed, sweep=sweep_index, row_id0=self.row_id0)
-        allreduce_tables(self.red_i64, self.red_f64, self.group, self._pack)
+        self._exchange()
         self.state.commit_reduce()

@@ -236,6 +236,10 @@ class DataView(object):
     def size(self):
         return self.nrows
 
+    def invalidate(self):
+        """the adopted tensors were rewritten in place: drop what the library derived from them (msc_dataview_invalidate)"""
+        L.check(self.ctx.lib.msc_dataview_invalidate(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self.ctx.lib.msc_dataview_destroy(self._h)
@@ -356,6 +360,7 @@ class State(object):
     def score_value(self, view, out=None, row0=0, nrows=None, z=None, crp_prior=False, cols=None,
                     niw_f32=False):
         """[nrows, K] float32 device tensor of summed score_value (see msc_score_value)."""
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if out is None:
             out = torch.empty((n, self.K), dtype=torch.float32, device=self.ctx.torch_device)
@@ -376,6 +381,7 @@ class State(object):
     def score_tune(self, view, out, row0=0, nrows=None, cols=None):
         """Settle the single-nich pass's launch shape for passes like this one (synchronous, ~10 ms; msc_score_tune).
         -> (shape index or -1, ms per pass)."""
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[0] < n:
             raise ValueError("out must be a row-major float32 [nrows, >=K] tensor")
@@ -385,6 +391,7 @@ class State(object):
         return shape.value, ms.value
 
     def accumulate(self, view, z, row0=0, nrows=None, reset=True, subtract=False, commit=True, cols=None):
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
             raise ValueError("z must be a contiguous int32 tensor of nrows entries")
@@ -395,6 +402,7 @@ class State(object):
 
     def entity_op(self, view, row, group, join=True, z=None, cols=None):
         """one entity joins / leaves one group, the group by value (msc_entity_op): every table stays current"""
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         zp = None
         if z is not None:
             if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] <= row:
@@ -409,6 +417,7 @@ class State(object):
         return out
 
     def sweep_assign(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
             raise ValueError("z must be a contiguous int32 tensor of nrows entries")
@@ -418,6 +427,7 @@ class State(object):
 
     def sweep_step(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
         """sweep_assign + accumulate(reset) in one call; repeated steps replay as a HIP graph (msc_sweep_step)."""
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
             raise ValueError("z must be a contiguous int32 tensor of nrows entries")
@@ -427,6 +437,7 @@ class State(object):
 
     def sweep_step_begin(self, view, z, seed, sweep, row0=0, nrows=None, row_id0=None, cols=None):
         """the sharded step up to the exchange: follow with all-reduce of reduce_buffers() and commit_reduce()"""
+        self._bound_view = view          # (the library keeps no reference to a view: this object does, for the last one bound)
         n = view.nrows - row0 if nrows is None else nrows
         if z.dtype != torch.int32 or not z.is_contiguous() or z.shape[0] < n:
             raise ValueError("z must be a contiguous int32 tensor of nrows entries")
@@ -450,6 +461,20 @@ class State(object):
 
     def commit_reduce(self):
         L.check(self.ctx.lib.msc_state_commit_reduce(self._h))
+
+    def reduce_pack(self):
+        """both additive tables as ONE float64 tensor (a copy the state owns; one launch): all_reduce it in place, then
+        reduce_unpack() and commit_reduce()"""
+        p, n = C.c_void_p(), C.c_size_t()
+        L.check(self.ctx.lib.msc_state_reduce_pack(self._h, C.byref(p), C.byref(n)))
+        return _alias_tensor(p.value, n.value, torch.float64, self.ctx.torch_device)
+
+    def reduce_unpack(self):
+        L.check(self.ctx.lib.msc_state_reduce_unpack(self._h))
+
+    def set_sweep_rows(self, global_rows):
+        """rows of the WHOLE dataset when this state sweeps a shard through a view of its own (msc_state_set_sweep_rows)"""
+        L.check(self.ctx.lib.msc_state_set_sweep_rows(self._h, int(global_rows)))
 
     def close(self):
         if getattr(self, "_h", None):

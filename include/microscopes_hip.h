@@ -101,9 +101,12 @@ int msc_context_synchronize(msc_context *ctx);
  * most allocations and 7.0 TB/s into some, decided by where the driver put the pages (profiles/r02_placement_study.txt),
  * and no allocator argument selects that.  A candidate is mapped from 32 MiB physical chunks through the virtual-memory
  * API (such buffers land in the upper band more often than hipMalloc'ed ones), stream-filled a few times on the
- * context's stream, and kept when it takes the stream at 6.5 TB/s or better; otherwise the next candidate is tried, up
- * to 24 (while the device has room), and the fastest is kept (SYNCHRONOUS, 2-3 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
- * MSC_ALLOC_ACCEPT_GBPS in the environment change the bounds, MSC_ALLOC_CANDIDATES=0 is plain hipMalloc).
+ * context's stream, and kept when it takes the stream at 6.65 TB/s or better; otherwise the next candidate is tried, up
+ * to 12, and the fastest is kept.  The search also ends when the candidates held side by side would exceed half of what
+ * the device had free at the call, and after six candidates whose rates lie within 6 % of each other (a box without a
+ * fast stretch: nothing to find).  SYNCHRONOUS, about 1 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
+ * MSC_ALLOC_ACCEPT_GBPS / MSC_ALLOC_FLAT_AFTER in the environment change the bounds, MSC_ALLOC_CANDIDATES=0 is plain
+ * hipMalloc.
  * msc_device_alloc_probed is the same with the bounds given by the caller: all `candidates` are probed and the fastest
  * is returned; rates_gbps (nullable, `candidates` floats) receives every candidate's fill rate, *chosen (nullable) the
  * index kept.  msc_device_alloc_stats reports the same for the context's most recent placed allocation.
@@ -150,6 +153,15 @@ int msc_dataview_from_device_columns(msc_context *ctx, uint64_t nrows,
                                      void *const *dev_columns, void *const *dev_masks,
                                      msc_dataview **out);
 int msc_dataview_destroy(msc_dataview *view);
+/*
+ * What the library derives from a view's columns and keeps with the view (a column converted to a model's value type,
+ * a masked column with the mask folded in, bool columns packed four to a byte, the maxima that size the exact count
+ * tables) is a snapshot of the columns' CONTENTS.  After rewriting columns adopted by msc_dataview_from_device_columns
+ * in place (minibatches through fixed buffers), call this: every derived copy is dropped and every state binds and
+ * derives afresh at its next call.  Synchronises the context's stream.  (A view made from records owns its columns:
+ * nothing can rewrite them.)
+ */
+int msc_dataview_invalidate(msc_dataview *view);
 int msc_dataview_size(const msc_dataview *view, uint64_t *nrows, uint32_t *nfeatures);
 int msc_dataview_column(const msc_dataview *view, uint32_t feature, void **dev_ptr,
                         msc_runtime_type *type);
@@ -315,6 +327,22 @@ int msc_sweep_step_stats(const msc_state *st, uint64_t *eager_steps, uint64_t *g
  */
 int msc_state_reduce_buffers(msc_state *st, void **dev_i64, size_t *n_i64, void **dev_f64,
                              size_t *n_f64);
+/*
+ * The same two tables as ONE float64 buffer, for a collective that takes one dtype (the payload is a few KB, so an
+ * exchange costs the collective's latency: one all-reduce, not two): msc_state_reduce_pack copies counts (as doubles --
+ * integers below 2^53 add exactly and in any order, so they come back bit-exact) and float sums into a buffer the state
+ * owns and returns it; sum-all-reduce *pack_dev in place; msc_state_reduce_unpack copies both back; then
+ * msc_state_commit_reduce.  One small launch each (common_amd/dist.py drives torch.distributed this way).
+ */
+int msc_state_reduce_pack(msc_state *st, void **pack_dev, size_t *n_f64);
+int msc_state_reduce_unpack(msc_state *st);
+/*
+ * The rows of the WHOLE dataset, for a state whose sweeps run on a SHARD of it through a view of its own: a sweep picks
+ * between two kernels by row count, and they associate a row's float sum differently, so a shard must pick what the
+ * unsharded sweep would (it then draws identical assignments).  Row ranges of ONE view need nothing (the default is the
+ * bound view's row count); 0 restores that default.
+ */
+int msc_state_set_sweep_rows(msc_state *st, uint64_t global_rows);
 int msc_state_commit_reduce(msc_state *st);
 
 /*

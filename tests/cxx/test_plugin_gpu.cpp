@@ -12,6 +12,7 @@
 #include <random>
 
 #include "../../oracle/msc_oracle.h"
+#include "audit.hpp"
 
 using namespace distributions;
 using namespace microscopes;
@@ -31,6 +32,64 @@ static bool close(double got, double want, double tol = 1e-6) {
   return ok;
 }
 
+// The double twin's record built from the FLOAT state the group itself holds (repr_, the reference's own fields,
+// distributions.hpp:21-56): what a score of that group is answerable to (audit.hpp).  Layouts: oracle/msc_oracle.h.
+template <typename T> static const typename T::Group &repr_of(const models::group &g) {
+  return static_cast<const models::distributions_group<T> &>(g).repr_;
+}
+static std::vector<uint8_t> fed(const BetaBernoulli::Group &r) {
+  std::vector<uint8_t> o(8);
+  std::memcpy(o.data(), &r.heads, 4); std::memcpy(o.data() + 4, &r.tails, 4);
+  return o;
+}
+static std::vector<uint8_t> fed(const GammaPoisson::Group &r) {
+  struct { uint32_t count, sum; double log_prod; } t = {r.count, r.sum, double(r.log_prod)};
+  std::vector<uint8_t> o(sizeof t);
+  std::memcpy(o.data(), &t, sizeof t);
+  return o;
+}
+static std::vector<uint8_t> fed(const NormalInverseChiSq::Group &r) {
+  struct { uint32_t count, pad; double mean, ctv; } t = {r.count, 0u, double(r.mean), double(r.count_times_variance)};
+  std::vector<uint8_t> o(sizeof t);
+  std::memcpy(o.data(), &t, sizeof t);
+  return o;
+}
+static std::vector<uint8_t> fed(const NormalInverseWishartV::Group &r) {
+  std::vector<double> t(1 + r.sum_x.size() + r.sum_xxT.size(), 0.0);
+  std::memcpy(t.data(), &r.count, 4);
+  for (size_t i = 0; i < r.sum_x.size(); i++) t[1 + i] = double(r.sum_x[i]);
+  for (size_t i = 0; i < r.sum_xxT.size(); i++) t[1 + r.sum_x.size() + i] = double(r.sum_xxT[i]);
+  std::vector<uint8_t> o(8 * t.size());
+  std::memcpy(o.data(), t.data(), o.size());
+  return o;
+}
+static std::vector<uint8_t> fed(const distributions::DirichletMultinomial::Group &r) {
+  const size_t off = (4 * r.counts.size() + 7) / 8 * 8;
+  std::vector<uint8_t> o(off + 8, 0);
+  std::memcpy(o.data(), r.counts.data(), 4 * r.counts.size());
+  const double ratio = double(r.ratio);
+  std::memcpy(o.data() + off, &ratio, 8);
+  return o;
+}
+// the float fields of the group against the all-double chain `oss` after n per-value updates (n half-ulps each), the
+// integer ones bit for bit
+static bool state_follows_chain(const char *fam, const GammaPoisson::Group &r, const void *oss, int n) {
+  struct T { uint32_t count, sum; double log_prod; } t;
+  std::memcpy(&t, oss, sizeof t);
+  return r.count == t.count && r.sum == t.sum && audit::field(std::string("plugin.float_field.") + fam + ".log_prod", r.log_prod, t.log_prod, n);
+}
+static bool state_follows_chain(const char *fam, const NormalInverseChiSq::Group &r, const void *oss, int n) {
+  struct T { uint32_t count, pad; double mean, ctv; } t;
+  std::memcpy(&t, oss, sizeof t);
+  return r.count == t.count && audit::field(std::string("plugin.float_field.") + fam + ".mean", r.mean, t.mean, n) &&
+         audit::field(std::string("plugin.float_field.") + fam + ".count_times_variance", r.count_times_variance, t.ctv, n);
+}
+static bool state_follows_chain(const char *, const BetaBernoulli::Group &r, const void *oss, int) {
+  uint32_t t[2];
+  std::memcpy(t, oss, 8);
+  return r.heads == t[0] && r.tails == t[1];
+}
+
 // drive one scalar family through the API and the oracle side by side
 template <typename Tag, typename V, typename Gen>
 static void run_scalar(int fam, unsigned dim, models::model &m, const std::vector<float> &hp,
@@ -41,25 +100,32 @@ static void run_scalar(int fam, unsigned dim, models::model &m, const std::vecto
   auto g = h->create_group(r);
   std::vector<uint8_t> oss(orc_f64_ss_size(fam, dim));
   orc_f64_init(fam, dim, hp.data(), oss.data());
+  const char *fname = fam == ORC_BB ? "bb" : fam == ORC_GP ? "gp" : "nich";
+  // a score against the twin fed the group's own float state (1e-6); the state itself against the all-double chain
+  // `oss` (integers exact, float fields at one half-ulp per update so far)
+  auto scores_follow = [&](const V &probe, const char *when) {
+    const std::vector<uint8_t> own = fed(repr_of<Tag>(*g));
+    return audit::score(std::string("plugin.score_value.") + fname + "." + when, g->score_value(*h, value_accessor(&probe), r),
+                        orc_f64_score_value(fam, dim, hp.data(), own.data(), &probe)) &&
+           audit::score(std::string("plugin.score_data.") + fname + "." + when, g->score_data(*h, r),
+                        orc_f64_score_data(fam, dim, hp.data(), own.data()));
+  };
   V vals[25];   // (not std::vector: vector<bool> has no addressable elements)
   for (int i = 0; i < 25; i++) {
     vals[i] = gen(r);
     g->add_value(*h, value_accessor(&vals[i]), r);
     orc_f64_add_value(fam, dim, hp.data(), oss.data(), &vals[i]);
-    if (i % 6 == 0) {
-      const V probe = gen(r);
-      CHECK(close(g->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), oss.data(), &probe)));
-      CHECK(close(g->score_data(*h, r), orc_f64_score_data(fam, dim, hp.data(), oss.data())));
-    }
+    CHECK(state_follows_chain(fname, repr_of<Tag>(*g), oss.data(), i + 1));
+    if (i % 6 == 0) CHECK(scores_follow(gen(r), "after_add"));
   }
   // remove half again
   for (int i = 0; i < 12; i++) {
     g->remove_value(*h, value_accessor(&vals[i]), r);
     orc_f64_remove_value(fam, dim, hp.data(), oss.data(), &vals[i]);
+    CHECK(state_follows_chain(fname, repr_of<Tag>(*g), oss.data(), 26 + i));
   }
   const V probe = gen(r);
-  CHECK(close(g->score_value(*h, value_accessor(&probe), r), orc_f64_score_value(fam, dim, hp.data(), oss.data(), &probe), 2e-6));
-  CHECK(close(g->score_data(*h, r), orc_f64_score_data(fam, dim, hp.data(), oss.data()), 2e-6));
+  CHECK(scores_follow(probe, "after_remove"));                // (round 1-3: 2e-6 against the chain twin)
   // bags round-trip, copies keep scoring identically
   auto g2 = h->create_group(r);
   g2->set_ss(g->get_ss());
@@ -155,11 +221,33 @@ static void test_dd_and_niw() {
     std::vector<float> probe(d);
     for (auto &x : probe) x = nd(r);
     const value_accessor pa(reinterpret_cast<const uint8_t *>(probe.data()), nullptr, vt);
-    CHECK(close(g->score_value(*h, pa, r), orc_f64_score_value(ORC_NIW, d, hp.data(), oss.data(), probe.data()), 5e-6));
-    CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_NIW, d, hp.data(), oss.data()), 5e-6));
+    // (rounds 1-3 held these against the chain twin `oss` at 5e-6 / 2e-5: what they measured was the float STATE --
+    // sum_xxT after 15 float updates, then a downdate -- not the evaluation.  The evaluation, on the state the group
+    // holds: the plain gate.  The state, against the chain: one half-ulp per update of the field's largest entry.)
+    auto niw_checks = [&](const char *when, int nupd) {
+      const NormalInverseWishartV::Group &own = repr_of<NormalInverseWishartV>(*g);
+      const std::vector<uint8_t> rec = fed(own);
+      const std::string tag = std::string("plugin.niw_d") + std::to_string(d) + "." + when;
+      bool ok = audit::score(tag + ".score_value", g->score_value(*h, pa, r), orc_f64_score_value(ORC_NIW, d, hp.data(), rec.data(), probe.data())) &&
+                audit::score(tag + ".score_data", g->score_data(*h, r), orc_f64_score_data(ORC_NIW, d, hp.data(), rec.data()));
+      const double *chain = reinterpret_cast<const double *>(oss.data());
+      double big_x = 1.0, big_xx = 1.0;
+      for (unsigned i = 0; i < d; i++) big_x = std::fmax(big_x, std::fabs(chain[1 + i]));
+      for (unsigned i = 0; i < d * d; i++) big_xx = std::fmax(big_xx, std::fabs(chain[1 + d + i]));
+      double ex = 0, exx = 0;
+      for (unsigned i = 0; i < d; i++) ex = std::fmax(ex, std::fabs(double(own.sum_x[i]) - chain[1 + i]));
+      for (unsigned i = 0; i < d * d; i++) exx = std::fmax(exx, std::fabs(double(own.sum_xxT[i]) - chain[1 + d + i]));
+      ok = ok && audit::check(tag + ".sum_x_vs_chain", ex / (std::ldexp(big_x, -24) * nupd), 1.0) &&
+           audit::check(tag + ".sum_xxT_vs_chain", exx / (std::ldexp(big_xx, -24) * nupd), 1.0);
+      uint32_t cnt;
+      std::memcpy(&cnt, oss.data(), 4);
+      return ok && own.count == cnt;
+    };
+    const int nadd = int(xs.size());
+    CHECK(niw_checks("after_add", nadd));
     g->remove_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(xs[0].data()), nullptr, vt), r);
     orc_f64_remove_value(ORC_NIW, d, hp.data(), oss.data(), xs[0].data());
-    CHECK(close(g->score_value(*h, pa, r), orc_f64_score_value(ORC_NIW, d, hp.data(), oss.data(), probe.data()), 2e-5));
+    CHECK(niw_checks("after_remove", nadd + 1));
     auto g2 = h->create_group(r);
     g2->set_ss(g->get_ss());
     CHECK(g2->score_value(*h, pa, r) == g->score_value(*h, pa, r));
@@ -257,9 +345,20 @@ static void test_dm() {
   }
   const int32_t probes[3][C] = {{0, 0, 0, 0, 0}, {1, 0, 3, 0, 2}, {40, 2, 0, 7, 1500}};
   for (const auto &pr : probes)
-    CHECK(close(g->score_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(pr), nullptr, vt), r),
-                orc_f64_score_value(ORC_DM, C, alphas, oss.data(), pr)));
-  CHECK(close(g->score_data(*h, r), orc_f64_score_data(ORC_DM, C, alphas, oss.data()), 2e-5));   // float `ratio` field
+    CHECK(audit::score("plugin.score_value.dm", g->score_value(*h, value_accessor(reinterpret_cast<const uint8_t *>(pr), nullptr, vt), r),
+                       orc_f64_score_value(ORC_DM, C, alphas, oss.data(), pr)));
+  {
+    // score_data = the float `ratio` field (dm.hpp:86-88) + lgamma terms of the exact counts: against the twin on the
+    // group's own ratio the plain gate; the ratio itself after 16 float updates against the double chain (round 1-3: 2e-5
+    // on the sum of both)
+    const auto &own = static_cast<const models::dm_group &>(*g).repr_;
+    const std::vector<uint8_t> rec = fed(own);
+    CHECK(audit::score("plugin.score_data.dm", g->score_data(*h, r), orc_f64_score_data(ORC_DM, C, alphas, rec.data())));
+    double chain_ratio;
+    std::memcpy(&chain_ratio, oss.data() + (4 * C + 7) / 8 * 8, 8);
+    CHECK(audit::field("plugin.float_field.dm.ratio", own.ratio, chain_ratio, 16));
+    CHECK(std::memcmp(rec.data(), oss.data(), 4 * C) == 0);   // counts: bit-exact
+  }
   // bags are the in-tree schema.proto:21-30 messages
   auto g2 = h->create_group(r);
   g2->set_ss(g->get_ss());
@@ -299,6 +398,7 @@ int main() {
   }
   test_bb_mutators_write_through();
   test_dd_and_niw();
+  audit::dump();
   std::puts("test_plugin_gpu ok");
   return 0;
 }

@@ -12,6 +12,19 @@ LINK = ["-L" + LIBDIR, "-lmicroscopes_hip", "-Wl,-rpath," + LIBDIR, "-L/opt/rocm
         "-Wl,-rpath,/opt/rocm/lib"]
 
 
+def _audited(output):
+    """the C++ tests print one "AUDIT name max_error gate checks" line per gate (tests/cxx/audit.hpp): folded into the
+    session's tolerance audit beside the Python gates (tests/gpu_helpers.py)"""
+    from tests.gpu_helpers import audit
+    n = 0
+    for line in output.splitlines():
+        if line.startswith("AUDIT "):
+            _, name, err, gate, _checks = line.split()
+            audit("cxx." + name, float(err), float(gate))
+            n += 1
+    return n
+
+
 def _cxx(src, out, extra=()):
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, out)
@@ -94,14 +107,16 @@ def test_plugin_api_on_device_matches_oracle():
     exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_plugin_gpu.cpp"), "test_plugin_gpu",
                LINK + ["-L" + os.path.join(ROOT, "oracle"), "-lmsc_oracle",
                        "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
-    assert "test_plugin_gpu ok" in subprocess.check_output([exe]).decode()
+    out = subprocess.check_output([exe]).decode()
+    assert "test_plugin_gpu ok" in out and _audited(out) >= 10
 
 
 @pytest.mark.gpu
 def test_relation_dataviews_on_device():
     exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_relation_gpu.cpp"), "test_relation_gpu",
                ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"] + LINK)
-    assert "test_relation_gpu ok" in subprocess.check_output([exe]).decode()
+    out = subprocess.check_output([exe]).decode()
+    assert "test_relation_gpu ok" in out and _audited(out) >= 1
 
 
 @pytest.mark.gpu
@@ -128,7 +143,8 @@ def test_mixture_state_builds_against_the_reference_interface_names():
 @pytest.mark.gpu
 def test_mixture_state_per_entity_gibbs_and_batched_sweep():
     exe = _cxx(os.path.join(ROOT, "tests", "cxx", "test_mixture_state_gpu.cpp"), "test_mixture_state_gpu", LINK)
-    assert "test_mixture_state_gpu ok" in subprocess.check_output([exe]).decode()
+    out = subprocess.check_output([exe]).decode()
+    assert "test_mixture_state_gpu ok" in out and _audited(out) >= 8
 
 
 def test_sample_value_draws_from_the_posterior_predictive():

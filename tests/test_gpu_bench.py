@@ -32,19 +32,28 @@ def test_single_gpu_line_has_every_object_and_no_error(gpu_ctx):
     assert r["metric"] == "score_value evals/sec" and r["n_gpus"] == 1
     for name in ("sweep", "c3", "c4", "c5_shard"):
         assert name in r and "error" not in r[name], (name, r.get(name))
-    # the driver's short command is stretched to a region the sampler can see, and says so
-    assert r["steps_requested"] == 20 and r["steps"] >= 200 and r["warmup"] >= 200 and r["warmup_requested"] == 5
-    assert r["config"]["short_region"]["steps"] == 20
+    # `value` is the region that was asked for -- exactly --steps after exactly --warmup; a region long enough for an
+    # outside sampler is measured beside it, and the clock-conditioning passes before both are named
+    assert r["steps"] == 20 and r["warmup"] == 5
+    assert r["config"]["preconditioning_passes"] >= 100
+    lr = r["config"]["long_region"]
+    assert lr["steps"] >= 200 and 0.5 < lr["ms_per_step"] / r["ms_per_step"] < 1.5
+    assert r["roofline"]["timed_region_launches"][1] - r["roofline"]["timed_region_launches"][0] == 20
     roof = r["roofline"]
     assert roof["bound"] == "hbm" and 0.4 < roof["frac"] < 1.0 and 0.4 < roof["frac_caller_alloc"] < 1.0
-    assert r["config"]["score_matrix"]["allocator"].startswith("msc_device_alloc") and r["config"]["score_matrix"]["candidates_fill_GBps"]
+    sm = r["config"]["score_matrix"]
+    assert sm["allocator"].startswith("msc_device_alloc") and sm["candidates_fill_GBps"]
+    # a box without a fast stretch is recognised after a few candidates (abi.cpp alloc_placed): never the whole cap
+    assert len(sm["candidates_fill_GBps"]) <= 12
 
 
-def test_gpus_2_launches_two_ranks_by_itself(gpu_ctx):
-    rc, out, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--c5-rows", "20000"], MSC_BENCH_BACKEND="gloo")
+@pytest.mark.parametrize("ranks", [2, 4])      # (four ranks + this process on the one card: the box allows six)
+def test_gpus_n_launches_its_ranks_by_itself(gpu_ctx, ranks):
+    rc, out, err = _run(["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--c5-rows", "20000"], MSC_BENCH_BACKEND="gloo")
     assert rc == 0, err[-2000:]
     r = _line(out)
-    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and len(r["rank_devices"]) == 2
+    assert r["n_gpus"] == ranks and r["ranks_seen"] == ranks and len(r["rank_devices"]) == ranks
+    assert r["steps"] == 2 and r["warmup"] == 1
     assert r["metric"] == "Gibbs-sweep rows/sec" and r["scaling"] == "weak" and r["config"]["backend"] == "gloo"
     assert r["one_rank_reference"]["value"] > 0 and r["weak_scaling_eff"] > 0
 

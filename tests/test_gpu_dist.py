@@ -52,6 +52,15 @@ def test_two_ranks_mixed_features_sweeps_equal_the_unsharded_run(gpu_ctx, tmp_pa
     _check(_launch(tmp_path, "mixed", 200_000, 48, 2))      # bb + gp + dd + nich, K = 48 (k_narrow), int64 + f64 tables
 
 
+@pytest.mark.parametrize("K", [100, 300])
+def test_two_ranks_choose_the_kernels_the_whole_would(gpu_ctx, tmp_path, K):
+    """a sweep picks the lane <-> row kernel or the tile kernels by ROW COUNT, and the two associate a row's float sum
+    differently.  24000 rows with the threshold forced between a shard (12000) and the whole: each rank's view holds its
+    shard only, so ShardedSweep tells the state the rows of the whole (msc_state_set_sweep_rows) -- same kernels, same
+    draws.  K = 100: a state of at most 128 groups; K = 300: the groups beyond the first tile."""
+    _check(_launch(tmp_path, "mixed", 24_000, K, 2, MSC_TAIL_MIN_ROWS="16000"))
+
+
 def test_one_rank_over_nccl_runs_the_exchange_path_on_rccl(gpu_ctx, tmp_path):
     """the nccl (= RCCL) branch on the box's one GPU: a single rank forced through msc_sweep_step_begin -> all_reduce
     (RCCL, on the library's own reduce buffers) -> msc_state_commit_reduce must equal msc_sweep_step"""

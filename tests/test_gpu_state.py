@@ -418,3 +418,87 @@ def test_default_allocator_places_large_buffers(gpu_ctx):
     with pytest.raises(RuntimeError):
         gpu_ctx.close()                                           # live buffers: refused
     del t, small
+
+
+def test_a_state_outlives_the_view_it_last_bound(gpu_ctx):
+    """The library keeps no reference to a dataview (neither does the reference: recarray/_dataview.pxd:24-27 borrows).
+    A state that scored against a view remembers it by pointer and serial, and what re-plans outside a call that was
+    handed a view -- msc_state_set_hp on a dd feature -- must not look at a view that has since been destroyed (round 3:
+    plan_groups walked bound_view->packed_bits there: a use after free).  Afterwards a new view binds and scores as if
+    nothing had happened."""
+    import common_amd
+    rng = np.random.default_rng(11)
+    N, K = 5000, 40
+    specs = [(orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.DD, 6), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    first = st.score_value(view).cpu().numpy()
+    st._bound_view = None                                         # (the Python State would keep it alive: take that away)
+    view.close()                                                  # msc_dataview_destroy
+    del view
+    junk = [torch.full((N,), 7, dtype=torch.uint8, device=gpu_ctx.torch_device) for _ in range(8)]   # reuse the freed pages
+    hp = dict(alphas=[0.5, 1.0, 1.5, 2.0, 2.5, 3.0])
+    st.set_hp(3, hp)                                              # re-plans: no view to look at
+    feats[3]["hp"] = hp
+    fs = state_from_assignment(feats, K, z)
+    view2 = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    got = st.score_value(view2).cpu().numpy()
+    want = sum(F.score_matrix(ss64, f["values"]) for f, (F, ss64, _) in zip(feats, fs))
+    mag = sum(np.maximum(1.0, np.abs(F.score_matrix(ss64, f["values"]))) for f, (F, ss64, _) in zip(feats, fs))
+    audit("state.rebind_after_view_destroyed", (np.abs(got - want) / mag).max(), TOL)
+    assert np.abs(got - first).max() > 1e-3                       # (the new alphas took effect)
+    del junk
+
+
+def test_columns_rewritten_in_place_need_invalidate(gpu_ctx):
+    """A view over the caller's tensors (msc_dataview_from_device_columns) caches what it derives from them -- bool columns
+    packed four to a byte, masked columns with the mask folded in, converted copies, column maxima.  After the caller
+    refills the tensors in place (minibatches through fixed buffers) msc_dataview_invalidate drops all of it: scores and
+    suff-stats follow the new contents."""
+    import common_amd
+    rng = np.random.default_rng(12)
+    N, K = 6000, 70
+    specs = [(orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.GP, 0), (orc.NICH, 0)]
+    dev = gpu_ctx.torch_device
+
+    def batch(seed):
+        r = np.random.default_rng(seed)
+        feats = [make_feature(f, N, K, r, d) for f, d in specs]
+        feats[4]["values"] = (feats[4]["values"] % (9 + 40 * seed)).astype(np.uint32)     # (another maximum per batch)
+        return feats
+    feats = batch(0)
+    cols = [torch.from_numpy(f["values"].copy()).to(dev) for f in feats]
+    mask3 = torch.from_numpy(rng.random(N) < 0.2).to(dev)
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols, masks=[None, None, None, mask3, None, None])
+    z = rng.integers(0, K, N).astype(np.int32)
+    zt = torch.from_numpy(z).to(dev)
+    st = common_amd.State(gpu_ctx, specs, K)
+
+    def check(feats, tag):
+        m3 = mask3.cpu().numpy()
+        st.accumulate(view, zt)
+        got = st.score_value(view).cpu().numpy()
+        total, mag = 0.0, 0.0
+        for i, f in enumerate(feats):
+            F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+            zz = z.copy()
+            if i == 3:
+                zz[m3] = -1                                       # a masked value takes no part in the suff-stats
+            ss = orc.widen_ss(f["family"], orc.narrow_ss(f["family"], F.accumulate(K, f["values"], zz), f["dim"]), f["dim"])
+            m = F.score_matrix(ss, f["values"])
+            if i == 3:
+                m[m3] = 0.0                                       # ... nor in the scores
+            total, mag = total + m, mag + np.maximum(1.0, np.abs(m))
+        audit("state.invalidate." + tag, (np.abs(got - total) / mag).max(), TOL)
+        return got
+    a = check(feats, "first_batch")
+    feats2 = batch(1)
+    for c, f in zip(cols, feats2):
+        c.copy_(torch.from_numpy(f["values"].copy()).to(dev))     # in place: the view's pointers stay what they were
+    view.invalidate()
+    b = check(feats2, "second_batch")
+    assert np.abs(a - b).max() > 1e-2
