@@ -348,6 +348,58 @@ MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c
   log1p_sq_parts(a, l2, r);
   return fmaf(-c1, r, fmaf(-c1ln2, l2, acc));
 }
+// ---- nich BLOCKS: the plain nich features of a state that share c1 --------------------------------------------------
+// A mixture state's unmasked nich columns with the same nu prior have, per group, the same c1 = (nu + n_g + 1) / 2 (the
+// group's size is every such column's count), so over a block of M <= kNichBlock of them
+//     sum_f c1 log(1 + t_f) = c1 log(1 + P),   1 + P = prod_f (1 + t_f),   t_f = a_f^2,
+// and P is carried RELATIVE to P -- (1 + p)(1 + q) - 1 = p q + (p + q), one fused multiply-add and one addition, nothing
+// rounds at 1 -- pairwise, so four factors are two levels of rounding.  Per evaluation: a (2 instructions), t = a a (1),
+// 3/4 of a join (1.5), and a QUARTER of the compensated log1p that `acc -= c1 log1p(P)` costs (6 plain + 2 transcendental
+// per block): 6 plain + 0.5 transcendental where nich_accum is 9 + 2 (the mixed kernels run at the
+// issue rate of exactly this mix).  What it needs:
+//   * c1 bit-equal over the block for every group -- the host groups features by their nu prior (abi.cpp plan_groups),
+//     the head kernel of every scoring / sweep call (kernels_state.hip k_fuse_tables) compares the c1 ln2 rows the
+//     suff-stats actually produced and clears the block's flag when they differ (suff-stats set feature by feature need
+//     not agree on the counts): such a block is evaluated feature by feature, nich_accum;
+//   * the product inside the float range: four factors below 2^30 each.  |a| <= s |x| + |s mu|, so a row whose values all
+//     satisfy |x_f| <= xlim_f = (2^15 - max_g |s mu|) / max_g s (head kernel, per feature) cannot overflow whatever the
+//     group; a row with a value beyond -- 32768 posterior scales from some group -- is a "far" row and takes nich_accum
+//     for all its plain nich features.  The decision is the row's, so a row's bits do not depend on what shares its wave.
+// Error: t_f carries 2.5 eps relative (a: two roundings; the square: one half), the joins add at most one eps a level,
+// so P is within ~4.5 eps and c1 log1p(P) within 4.5 eps P / ((1 + P) log1p(P)) <= 4.5 eps of ITSELF; nich_accum's
+// per-feature term is within ~2 eps of itself.  Against the gate on a sum of D features, 1e-6 sum_f max(1, |score_f|)
+// = 16.8 eps per feature, both are small; tests/test_host_numerics.py replays the float arithmetic against double.
+// (kNichBlock, kNichFarA, NichPlanInfo: msc_internal.hpp)
+MSC_DEV float nich_t(float x, float smu_hi, float smu_lo, float s) {
+#pragma clang fp contract(off)
+  const float a = fmaf(x, s, -smu_hi) - smu_lo;
+  return a * a;
+}
+MSC_DEV float nich_join(float p, float q) {              // (1 + p)(1 + q) - 1
+#pragma clang fp contract(off)
+  return fmaf(p, q, p + q);
+}
+// acc - c1 log(1 + P), as c1 ln2 times log2(1 + P) = log2(u) + log2e (P - (u - 1)) / u, u = fl(1 + P): the remainder
+// through v_rcp_f32 (score kernels: 6 plain + 2 transcendental) or through the exponent-flip estimate of log2e / u (EST,
+// the sweeps: 6 + 1), as in log1p_parts / log2_1p_sq
+template <bool EST>
+MSC_DEV float nich_block_finish(float acc, float P, float c1ln2) {
+#pragma clang fp contract(off)
+  const float u = 1.0f + P;
+  const float e = P - (u - 1.0f);
+  float w;
+  if (EST) w = fmaf(e, __uint_as_float(kLog2eOverU - __float_as_uint(u)), hw_log2(u));
+  else w = fmaf(e * hw_rcp(u), 1.44269504088896340736f, hw_log2(u));
+  return fmaf(-c1ln2, w, acc);
+}
+template <int M>
+MSC_DEV float nich_block_product(const float (&t)[M]) {
+  static_assert(M >= 2 && M <= kNichBlock, "blocks of two to four features");
+  if constexpr (M == 2) return nich_join(t[0], t[1]);
+  else if constexpr (M == 3) return nich_join(nich_join(t[0], t[1]), t[2]);
+  else return nich_join(nich_join(t[0], t[1]), nich_join(t[2], t[3]));
+}
+
 // The sweep kernels' form, in log2 units: c0' - c1 log2(1 + t), with log2(1 + t) = log2(u) + log2e (t - (u - 1)) / u
 // assembled first -- the same accuracy (the product with c1 rounds at the term's own size either way) with one
 // per-group constant fewer to keep in registers than nich_eval's two factors.

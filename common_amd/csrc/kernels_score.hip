@@ -16,6 +16,7 @@
 // the critical path).  Row values are loaded coalesced (lane r <- row r of the block) and
 // broadcast with v_readlane.
 #include <cstdlib>
+#include <type_traits>
 
 #include "commit_ops.hpp"
 #include "family_math.hpp"
@@ -760,30 +761,10 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
     float4 acc[R];
     if (!looker) {
-      // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over ----
-      {
-        const float4 c0s = nich_c0_sum(feats, nsplit, nfeat, kpad, kb);      // (the sums start from the features' c0: nich_accum)
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = c0s;
-      }
+      // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over; block by block
+      // (score_block.hpp nich_phase_global: the steps every tile kernel takes) ----
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      for (int f = nsplit; f < nfeat; f++) {
-        const FeatDesc &fd = feats[f];
-        const float *t = fd.tab + kb;
-        const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
-                     c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
-                     c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
-        const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          const float x = lane_bcast(xv, r);
-          acc[r].x = nich_accum(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
-          acc[r].y = nich_accum(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-          acc[r].z = nich_accum(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-          acc[r].w = nich_accum(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time: 64 registers are the sums
-        }
-      }
+      nich_phase_global<R, false>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);
       __syncthreads();                                    // every lookup wave is done with the slot
       float4 *mine = lds + (size_t)pair * R * 64 + lane;
 #pragma unroll
@@ -1166,10 +1147,14 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;    // (the batch's values pass through w0: no indexed register)
       }
     }
-    // ---- second phase: plain nich features.  Their accumulator starts from the features' summed c0 and every evaluation is
-    // nich_accum's two fused multiply-adds on it (as in the tile kernels' second phase); the groups' constants are SCALAR
-    // operands but for s*mu (hi), which an instruction needs beside s (one scalar operand an instruction on this chip):
-    // that one comes from LDS, a broadcast read.  9 plain + 2 transcendental instructions an evaluation, no copy.
+    // ---- second phase: plain nich features, in the plan's BLOCKS (family_math.hpp "nich BLOCKS"; the steps of
+    // score_block.hpp nich_features, so that SPLIT gives the tile kernels' bits).  The accumulator starts from the
+    // features' summed c0; a block whose c1 the head kernel found equal is ONE compensated log1p of the product of its
+    // members' 1 + t per group, every other feature nich_accum's two fused multiply-adds.  The groups' constants are
+    // SCALAR operands but for s*mu (hi), which an instruction needs beside s (one scalar operand an instruction on this
+    // chip): that one comes from LDS, a broadcast read.  A FAR row (a value beyond its feature's xlim) takes nich_accum
+    // for every feature: the lane decides for its row (a divergent region, never entered with data that sits where its
+    // groups are).
     if (SPLIT) {
 #pragma unroll
       for (int g = 0; g < TGP; g++) accn[g] = c0s[g];
@@ -1177,35 +1162,85 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
 #pragma unroll
       for (int g = 0; g < TGP; g++) acc[g] += c0s[g];
     }
+    bool far = false;
     for (int fb = nsplit; fb < nfeat; fb += 8) {
-      uint32_t w0 = load_value(fb, rr), w1 = load_value(fb + 1, rr), w2 = load_value(fb + 2, rr), w3 = load_value(fb + 3, rr),
-               w4 = load_value(fb + 4, rr), w5 = load_value(fb + 5, rr), w6 = load_value(fb + 6, rr), w7 = load_value(fb + 7, rr);
-#pragma unroll 1
-      for (int i = 0; i < 8; i++) {
-        const int f = fb + i;
-        if (f >= nfeat) break;
-        const float x = __uint_as_float(w0);
-        const scalar_f tab = (scalar_f)(feats[f].tab) + k0;
-        const float *mhf = mhl + (size_t)(f - nsplit) * 64;
-        // NB groups' constants at a time, 4 NB scalar registers (volatile: left to itself the compiler merges the loads of
-        // sixteen groups, holds hundreds of registers' worth at once and spills them through vector lanes); four at a
-        // time where two sums per group leave few registers for the evaluations' temporaries
-        constexpr int NB = (!SPLIT || TGP <= 32) ? 8 : 4;
-        typedef float f32xn __attribute__((ext_vector_type(NB)));
-        typedef const volatile __attribute__((address_space(4))) f32xn *scalar_fn;
+      const uint32_t w0 = load_value(fb, rr), w1 = load_value(fb + 1, rr), w2 = load_value(fb + 2, rr), w3 = load_value(fb + 3, rr),
+                     w4 = load_value(fb + 4, rr), w5 = load_value(fb + 5, rr), w6 = load_value(fb + 6, rr), w7 = load_value(fb + 7, rr);
+      auto lim = [&](int f) { return feats[f < nfeat ? f : nfeat - 1].nich_info->xlim; };     // (load_value clamps the same way)
+      far |= !(__builtin_fabsf(__uint_as_float(w0)) <= lim(fb)) | !(__builtin_fabsf(__uint_as_float(w1)) <= lim(fb + 1)) |
+             !(__builtin_fabsf(__uint_as_float(w2)) <= lim(fb + 2)) | !(__builtin_fabsf(__uint_as_float(w3)) <= lim(fb + 3)) |
+             !(__builtin_fabsf(__uint_as_float(w4)) <= lim(fb + 4)) | !(__builtin_fabsf(__uint_as_float(w5)) <= lim(fb + 5)) |
+             !(__builtin_fabsf(__uint_as_float(w6)) <= lim(fb + 6)) | !(__builtin_fabsf(__uint_as_float(w7)) <= lim(fb + 7));
+    }
+    // one feature, nich_accum: NB groups' constants at a time, 4 NB scalar registers (volatile: left to itself the compiler
+    // merges the loads of sixteen groups, holds hundreds of registers' worth at once and spills them through vector
+    // lanes); four at a time where two sums per group leave few registers for the evaluations' temporaries
+    auto plain_feature = [&](int f, float x) {
+      const scalar_f tab = (scalar_f)(feats[f].tab) + k0;
+      const float *mhf = mhl + (size_t)(f - nsplit) * 64;
+      constexpr int NB = (!SPLIT || TGP <= 32) ? 8 : 4;
+      typedef float f32xn __attribute__((ext_vector_type(NB)));
+      typedef const volatile __attribute__((address_space(4))) f32xn *scalar_fn;
 #pragma unroll
-        for (int gb = 0; gb < TGP; gb += NB) {
-          const f32xn ml = *(scalar_fn)(tab + (size_t)NICH_MU_LO * kpad + gb), c1l = *(scalar_fn)(tab + (size_t)NICH_C1LN2 * kpad + gb),
-                      c1 = *(scalar_fn)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_fn)(tab + (size_t)NICH_C2 * kpad + gb);
+      for (int gb = 0; gb < TGP; gb += NB) {
+        const f32xn ml = *(scalar_fn)(tab + (size_t)NICH_MU_LO * kpad + gb), c1l = *(scalar_fn)(tab + (size_t)NICH_C1LN2 * kpad + gb),
+                    c1 = *(scalar_fn)(tab + (size_t)NICH_C1 * kpad + gb), c2 = *(scalar_fn)(tab + (size_t)NICH_C2 * kpad + gb);
 #pragma unroll
-          for (int j = 0; j < NB; j++) {
-            float &a = SPLIT ? accn[gb + j] : acc[gb + j];
-            a = nich_accum<EST>(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
-          }
-          __builtin_amdgcn_sched_barrier(0);             // (a block's temporaries at a time: left to interleave the blocks, some instantiations spill)
+        for (int j = 0; j < NB; j++) {
+          float &a = SPLIT ? accn[gb + j] : acc[gb + j];
+          a = nich_accum<EST>(a, x, mhf[gb + j], ml[j], c1l[j], c1[j], c2[j]);
         }
-        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
+        __builtin_amdgcn_sched_barrier(0);               // (a block's temporaries at a time: left to interleave the blocks, some instantiations spill)
       }
+    };
+    // a block of M features: four groups' constants at a time, (2 M + 1) x 4 scalar registers
+    auto product_block = [&](int f, auto mtag, const float (&x)[kNichBlock]) {
+      constexpr int M = decltype(mtag)::value;
+      typedef float f32x4s __attribute__((ext_vector_type(4)));
+      typedef const volatile __attribute__((address_space(4))) f32x4s *scalar_f4;
+      scalar_f tab[M];
+      const float *mhf[M];
+#pragma unroll
+      for (int j = 0; j < M; j++) {
+        tab[j] = (scalar_f)(feats[f + j].tab) + k0;
+        mhf[j] = mhl + (size_t)(f + j - nsplit) * 64;
+      }
+#pragma unroll
+      for (int gb = 0; gb < TGP; gb += 4) {
+        f32x4s ml[M], sc[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          ml[j] = *(scalar_f4)(tab[j] + (size_t)NICH_MU_LO * kpad + gb);
+          sc[j] = *(scalar_f4)(tab[j] + (size_t)NICH_C2 * kpad + gb);
+        }
+        const f32x4s c1l = *(scalar_f4)(tab[0] + (size_t)NICH_C1LN2 * kpad + gb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float t[M];
+#pragma unroll
+          for (int j = 0; j < M; j++) t[j] = nich_t(x[j], mhf[j][gb + i], ml[j][i], sc[j][i]);
+          float &a = SPLIT ? accn[gb + i] : acc[gb + i];
+          a = nich_block_finish<EST>(a, nich_block_product<M>(t), c1l[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int f = nsplit; f < nfeat;) {
+      const bool ok = feats[f].nich_info->blk_ok != 0u;    // (set at a block's first feature only, and only for blocks of two or more)
+      const int m = ok ? (int)feats[f].blk_end - f : 1;
+      const float x[kNichBlock] = {__uint_as_float(load_value(f, rr)), __uint_as_float(load_value(f + 1, rr)),
+                                   __uint_as_float(load_value(f + 2, rr)), __uint_as_float(load_value(f + 3, rr))};
+      const bool prod = ok && !far;
+      if (prod) {
+        if (m == 2) product_block(f, std::integral_constant<int, 2>(), x);
+        else if (m == 3) product_block(f, std::integral_constant<int, 3>(), x);
+        else product_block(f, std::integral_constant<int, 4>(), x);
+      }
+      if (!prod) {
+#pragma unroll 1
+        for (int j = 0; j < m; j++) plain_feature(f + j, j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3]);
+      }
+      f += m;
     }
     const float *prh = pr[single ? 3 : 2];
     if (DRAW) {

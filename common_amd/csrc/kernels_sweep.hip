@@ -1073,29 +1073,8 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
     float4 acc[R];
     if (!looker) {
-      {
-        const float4 c0s = nich_c0_sum(feats, nsplit, nfeat, kpad, kb);      // (the sums start from the features' c0: nich_accum)
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = c0s;
-      }
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      for (int f = nsplit; f < nfeat; f++) {
-        const FeatDesc &fd = feats[f];
-        const float *t = fd.tab + kb;
-        const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
-                     c1l = ld4(t + (size_t)NICH_C1LN2 * kpad),
-                     c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
-        const float xv = reinterpret_cast<const float *>(fd.col)[myrow];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          const float x = lane_bcast(xv, r);
-          acc[r].x = nich_accum<true>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
-          acc[r].y = nich_accum<true>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-          acc[r].z = nich_accum<true>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-          acc[r].w = nich_accum<true>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time
-        }
-      }
+      nich_phase_global<R, true>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
       __syncthreads();                                    // every lookup wave is done with the slot
       float4 *mine = lds + (size_t)pair * R * 64 + lane;
 #pragma unroll

@@ -79,6 +79,14 @@ inline size_t crp_floats(uint32_t kpad) { return 4 * (size_t)kpad + 4; }
 //   niw  i64 {count}                 f64 group-major {sum_x[d]}, {sum_xxT[d*d]}
 //   bnb  i64 {count, sum}
 //   dm   i64 {counts[dim]}           f64 {ratio}
+// nich blocks (family_math.hpp): up to kNichBlock plain nich features of the plan's second phase that share c1
+constexpr int kNichBlock = 4;
+constexpr float kNichFarA = 32768.0f;                    // |a| beyond this: the row is "far" (see NichPlanInfo::xlim)
+struct NichPlanInfo {                                    // per feature of the plan's second phase (FeatDesc::nich_info)
+  float xlim;                                            // |x| <= xlim: no group's |a| = |s x - s mu| exceeds kNichFarA
+  uint32_t blk_ok;                                       // at a block's FIRST feature: c1 ln2 is bit-equal over the block
+};
+
 struct FeatDesc {
   // -- what the tile kernels' lookup runs read per feature: one 32-byte block, one scalar load (score_block.hpp) --
   const void *col;         // bound dataview column (device), null until bound
@@ -140,6 +148,14 @@ struct FeatDesc {
   const float *fuse_src[4];
   uint32_t fuse_n;
   uint32_t fuse_radix;     // 2: unmasked members; 3: masked ones (digit 2 = the member's zero row; three at a time, 27 rows)
+  // nich BLOCKS of the plan's second phase (abi.cpp plan_groups; family_math.hpp): the plan's features
+  // [blk_first, blk_end) are one block -- consecutive plain nich features with the same nu prior, at most kNichBlock, never
+  // across an LDS feature group -- scored as ONE log1p of their product where the head kernel found their c1 ln2 rows
+  // bit-equal (nich_info[0].blk_ok of the block's first feature), feature by feature otherwise.  nich_info: this
+  // feature's own record (device; k_fuse_tables fills it at the head of every scoring / sweep call); null outside the
+  // second phase.
+  uint32_t blk_first, blk_end;
+  NichPlanInfo *nich_info;
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -364,6 +380,8 @@ struct msc_state {
   bool fuse_any = false;
   float *fuse_tab = nullptr;          // the fused tables, 32 rows of kpad floats a fused feature (16 or 27 used)
   size_t fuse_tab_floats = 0;
+  msc::NichPlanInfo *nich_info = nullptr;   // [nfeat]: per feature of the plans' second phase (FeatDesc::nich_info)
+  bool nich_blocks_any = false;       // the plan has a nich block of two or more features
   const msc_dataview *bound_view = nullptr;
   uint64_t bound_serial = 0;
   std::vector<uint32_t> bound_cols;

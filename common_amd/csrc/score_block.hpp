@@ -359,8 +359,17 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
   bar();                                                // ... everyone's
 }
 
-// second phase: the unmasked nich features (the host puts them last, abi.cpp plan_groups), group by group,
-// in a loop that holds nothing else
+// ---------------------------------------------------------------------------
+// second phase: the plain (unmasked) nich features, which the host puts last and in BLOCKS (abi.cpp plan_groups;
+// family_math.hpp "nich BLOCKS").  Every tile kernel forms a row's second-phase sum by the same steps in the same order --
+// the features' summed c0, then block by block either ONE compensated log1p of the block's product (nich_block_finish) or,
+// where the head kernel found the block's c1 differing, nich_accum feature by feature -- so a row gets the same bits from
+// the kernel whose waves split the phases (k_score_tile_roles), from the ones that run them one after the other, and from
+// the lane <-> row kernel (k_score_tail_rows<SPLIT>).  A FAR row (a value beyond its feature's xlim: some group's |a| may
+// exceed 2^15 and a product of four could leave the float range) takes nich_accum for ALL its plain nich features: the
+// hot loops do not look, the rows are found up front (nich_far_rows) and their sums REPLACED afterwards by a call
+// (nich_row_plain, out of line: never taken with data that sits where its groups are).
+// ---------------------------------------------------------------------------
 // the sum of c0 over the second phase's features, for this lane's four groups: what the phase's accumulators start from
 // (family_math.hpp nich_accum); read from the tables in L2, once per chunk
 MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb) {
@@ -368,38 +377,169 @@ MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat
   for (int f = f0; f < nfeat; f++) add4(s, ld4(feats[f].tab + (size_t)NICH_C0 * kpad + kb));
   return s;
 }
+MSC_DEV float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+
+// bit r: the wave's row r (lane r holds it: `myrow`) has a plain nich value beyond its feature's xlim (NaN included)
+MSC_DEV unsigned long long nich_far_rows(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint64_t myrow, bool has_row) {
+  bool far = false;
+  for (int f = f0; f < nfeat; f++) {
+    const float x = reinterpret_cast<const float *>(feats[f].col)[myrow];
+    far |= !(__builtin_fabsf(x) <= feats[f].nich_info->xlim);
+  }
+  return __builtin_amdgcn_ballot_w64(far && has_row);
+}
+// a far row's second-phase sum for this lane's four groups, feature by feature (the steps of a block-less plan)
+template <bool EST>
+static __device__ __attribute__((noinline)) float4 nich_row_plain(const FeatDesc *__restrict__ feats, int f0, int nfeat,
+                                                                   uint32_t kpad, uint32_t kb, uint64_t row) {
+  float4 a = nich_c0_sum(feats, f0, nfeat, kpad, kb);
+  for (int f = f0; f < nfeat; f++) {
+    const FeatDesc &fd = feats[f];
+    const float *t = fd.tab + kb;
+    const float4 mh = ld4(t + (size_t)NICH_MU_HI * kpad), ml = ld4(t + (size_t)NICH_MU_LO * kpad),
+                 c1l = ld4(t + (size_t)NICH_C1LN2 * kpad), c1 = ld4(t + (size_t)NICH_C1 * kpad), c2 = ld4(t + (size_t)NICH_C2 * kpad);
+    const float x = reinterpret_cast<const float *>(fd.col)[row];
+    a.x = nich_accum<EST>(a.x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+    a.y = nich_accum<EST>(a.y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+    a.z = nich_accum<EST>(a.z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+    a.w = nich_accum<EST>(a.w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+  }
+  return a;
+}
+// One block of M features against TWO of the lane's four groups (pair P: components 2P, 2P + 1 of the accumulators) for
+// the wave's R rows: 3 M constants of two groups each in registers (a block of four against all four groups would be 52
+// registers beside 64 of sums -- the kernels run four waves a SIMD), the rows' values broadcast per use.
+template <int M, int R, int P, bool EST>
+MSC_DEV void nich_block_rows(const float (&xv)[M], const float2 (&mh)[M], const float2 (&ml)[M], const float2 (&sc)[M],
+                             const float2 c1l, float4 (&acc)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float t0[M], t1[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+      const float x = lane_bcast(xv[j], r);
+      t0[j] = nich_t(x, mh[j].x, ml[j].x, sc[j].x);
+      t1[j] = nich_t(x, mh[j].y, ml[j].y, sc[j].y);
+    }
+    const float p0 = nich_block_product<M>(t0), p1 = nich_block_product<M>(t1);
+    if (P == 0) {
+      acc[r].x = nich_block_finish<EST>(acc[r].x, p0, c1l.x);
+      acc[r].y = nich_block_finish<EST>(acc[r].y, p1, c1l.y);
+    } else {
+      acc[r].z = nich_block_finish<EST>(acc[r].z, p0, c1l.x);
+      acc[r].w = nich_block_finish<EST>(acc[r].w, p1, c1l.y);
+    }
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows of temporaries at a time
+  }
+}
+// where a block's constants come from: the tables in L2 (the role-split kernels' nich waves) ...
+struct NichFromGlobal {
+  const FeatDesc *__restrict__ feats;
+  uint32_t kpad, kb;
+  MSC_DEV float2 pair(int f, int row, int p) const { return ld2(feats[f].tab + (size_t)row * kpad + kb + 2 * p); }
+  MSC_DEV float4 quad(int f, int row) const { return ld4(feats[f].tab + (size_t)row * kpad + kb); }
+};
+// ... or the staged feature group in LDS (the kernels that run the phases one after the other)
+struct NichFromLds {
+  const FeatDesc *__restrict__ feats;
+  const float4 *__restrict__ lds;
+  int lane;
+  MSC_DEV float2 pair(int f, int row, int p) const {
+    return reinterpret_cast<const float2 *>(lds + ((size_t)feats[f].grp_off + row) * 64 + lane)[p];
+  }
+  MSC_DEV float4 quad(int f, int row) const { return lds[((size_t)feats[f].grp_off + row) * 64 + lane]; }
+};
+template <int M, int R, bool EST, typename Src>
+MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
+  float xv[M];
+#pragma unroll
+  for (int j = 0; j < M; j++) xv[j] = reinterpret_cast<const float *>(feats[f + j].col)[myrow];
+  {
+    float2 mh[M], ml[M], sc[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) mh[j] = src.pair(f + j, NICH_MU_HI, 0), ml[j] = src.pair(f + j, NICH_MU_LO, 0), sc[j] = src.pair(f + j, NICH_C2, 0);
+    nich_block_rows<M, R, 0, EST>(xv, mh, ml, sc, src.pair(f, NICH_C1LN2, 0), acc);
+  }
+  __builtin_amdgcn_sched_barrier(0);                          // (the second pair's constants after the first pair's rows)
+  {
+    float2 mh[M], ml[M], sc[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) mh[j] = src.pair(f + j, NICH_MU_HI, 1), ml[j] = src.pair(f + j, NICH_MU_LO, 1), sc[j] = src.pair(f + j, NICH_C2, 1);
+    nich_block_rows<M, R, 1, EST>(xv, mh, ml, sc, src.pair(f, NICH_C1LN2, 1), acc);
+  }
+}
+// the features [f0, f1) of the second phase (whole blocks), sums in acc; rows of `far` are redone by the caller
+template <int R, bool EST, typename Src>
+MSC_DEV void nich_features(const FeatDesc *__restrict__ feats, int f0, int f1, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
+  int f = f0;
+  while (f < f1) {
+    const int m = (int)feats[f].blk_end - f;
+    if (m >= 2 && feats[f].nich_info->blk_ok != 0u) {
+      if (m == 2) nich_block<2, R, EST>(feats, f, src, myrow, acc);
+      else if (m == 3) nich_block<3, R, EST>(feats, f, src, myrow, acc);
+      else nich_block<4, R, EST>(feats, f, src, myrow, acc);
+      f += m;
+      continue;
+    }
+    // a feature on its own (or a block whose c1 differ): nich_accum, as before there were blocks
+    const float4 mh = src.quad(f, NICH_MU_HI), ml = src.quad(f, NICH_MU_LO), c1l = src.quad(f, NICH_C1LN2),
+                 c1 = src.quad(f, NICH_C1), c2 = src.quad(f, NICH_C2);
+    const float xv = reinterpret_cast<const float *>(feats[f].col)[myrow];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float x = lane_bcast(xv, r);
+      acc[r].x = nich_accum<EST>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+      acc[r].y = nich_accum<EST>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+      acc[r].z = nich_accum<EST>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+      acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time: the sums are the registers
+    }
+    f++;
+  }
+}
+// far rows: their sums replaced (wave-uniform; rows in range only)
+template <int R, bool EST>
+MSC_DEV void nich_redo_far_rows(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb,
+                                uint64_t row_abs0, unsigned long long far, float4 (&acc)[R]) {
+  if (far == 0ull) return;
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if ((far >> r) & 1ull) acc[r] = nich_row_plain<EST>(feats, f0, nfeat, kpad, kb, row_abs0 + r);
+}
+// the whole phase with the constants from L2 (k_score_tile_roles / k_sweep_tile_roles: the nich waves); acc is SET
+template <int R, bool EST>
+MSC_DEV void nich_phase_global(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb,
+                               uint64_t row_abs0, int nr, uint64_t myrow, float4 (&acc)[R]) {
+  const unsigned long long far = nich_far_rows(feats, f0, nfeat, myrow, (threadIdx.x & 63) < nr);
+  {
+    const float4 c0s = nich_c0_sum(feats, f0, nfeat, kpad, kb);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = c0s;
+  }
+  nich_features<R, EST>(feats, f0, nfeat, NichFromGlobal{feats, kpad, kb}, myrow, acc);
+  nich_redo_far_rows<R, EST>(feats, f0, nfeat, kpad, kb, row_abs0, far, acc);
+}
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
 template <int R, int W, bool EST = false>
 MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t ktile,
-                                  int lane, int wave, uint64_t myrow, bool has_row, float4 *__restrict__ lds,
+                                  int lane, int wave, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds,
                                   float4 (&acc)[R]) {
+  const uint32_t kb = ktile * kGroupTile + lane * 4;
+  const uint64_t myrow = lane < nr ? row_abs0 + lane : row_safe;    // (a row of the call's range for idle lanes)
+  const int first = f0;
+  const unsigned long long far = nich_far_rows(feats, f0, nfeat, myrow, lane < nr);
   {
-    const float4 c0s = nich_c0_sum(feats, f0, nfeat, kpad, ktile * kGroupTile + lane * 4);
+    const float4 c0s = nich_c0_sum(feats, f0, nfeat, kpad, kb);
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = c0s;
   }
   while (f0 < nfeat) {
-    const int f1 = (int)feats[f0].grp_end;
+    const int f1 = (int)feats[f0].grp_end;                     // (a block never lies across two groups: abi.cpp plan_layout)
     stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
-    float xv_next = has_row ? reinterpret_cast<const float *>(feats[f0].col)[myrow] : 0.f;
-    for (int f = f0; f < f1; f++) {
-      const FeatDesc &fd = feats[f];
-      const float4 *buf = lds + (size_t)fd.grp_off * 64 + lane;
-      const float xv = xv_next;                          // (fetched one feature ahead, as in the lookup runs)
-      if (f + 1 < f1) xv_next = has_row ? reinterpret_cast<const float *>(feats[f + 1].col)[myrow] : 0.f;
-      const float4 mh = buf[NICH_MU_HI * 64], ml = buf[NICH_MU_LO * 64],
-                   c1l = buf[NICH_C1LN2 * 64], c1 = buf[NICH_C1 * 64], c2 = buf[NICH_C2 * 64];
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const float x = lane_bcast(xv, r);
-        acc[r].x = nich_accum<EST>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
-        acc[r].y = nich_accum<EST>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-        acc[r].z = nich_accum<EST>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-        acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
-      }
-    }
+    nich_features<R, EST>(feats, f0, f1, NichFromLds{feats, lds, lane}, myrow, acc);
     f0 = f1;
   }
+  nich_redo_far_rows<R, EST>(feats, first, nfeat, kpad, kb, row_abs0, far, acc);
 }
 
 // GENERIC = false: the caller knows every feature of the phase to be of a lookup kind (k_score_tile_roles: the host
@@ -523,10 +663,10 @@ MSC_DEV void score_tile(const FeatDesc *__restrict__ feats, int nfeat, int nspli
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     static_assert(SPLIT, "the second phase is always summed on its own (score_tile_nich_tail sets its accumulators)");
     if (nsplit == 0) {                                    // (the caller passed zeros and adds the prior afterwards)
-      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, acc);
+      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0, nr, row_safe, lds, acc);
     } else {
       float4 accn[R];
-      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0 + lane, lane < nr, lds, accn);
+      score_tile_nich_tail<R, W, EST>(feats, nsplit, nfeat, kpad, ktile, lane, wave, row_abs0, nr, row_safe, lds, accn);
 #pragma unroll
       for (int r = 0; r < R; r++) add4(acc[r], accn[r]);
     }

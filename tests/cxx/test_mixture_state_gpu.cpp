@@ -346,7 +346,8 @@ int main() {
     {  // the state's niw sums (one rounding of double sums) against the value-by-value twin's (a float chain): a half-ulp
        // per update of the largest entry
       for (size_t gid : {ga, gb}) {
-        const auto &a = static_cast<models::distributions_group<distributions::NormalInverseWishartV> &>(*fed_group(vh, vs, 0, gid)).repr_;
+        const auto own = fed_group(vh, vs, 0, gid);
+        const auto &a = static_cast<models::distributions_group<distributions::NormalInverseWishartV> &>(*own).repr_;
         const auto &b = static_cast<models::distributions_group<distributions::NormalInverseWishartV> &>(*(gid == ga ? ta : tb)[0]).repr_;
         CHECK(a.count == b.count);
         double big = 1.0, err = 0.0;
