@@ -747,6 +747,8 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
     const uint32_t limit = f < split ? split : n;
     uint32_t used = 0, g = f;
     while (g < limit && used + rows_of(t[g]) + extra[g] <= (uint32_t)kGrpRows) {
+      // (a nich block is staged whole: its members' constants are read side by side)
+      if (t[g].blk_end > g + 1 && t[g].blk_first == g && used > 0 && used + 6u * (t[g].blk_end - g) > (uint32_t)kGrpRows) break;
       t[g].grp_off = used;
       t[g].grp_rows = rows_of(t[g]) + extra[g];
       used += t[g].grp_rows;
@@ -825,9 +827,39 @@ static int plan_groups(msc_state *st) {
   auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
   std::vector<FeatDesc> &t = st->desc_tile_host;
   t.clear();
+  for (FeatDesc &d : st->desc_host) d.blk_first = d.blk_end = 0, d.nich_info = nullptr;
   for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
   st->tile_split = (uint32_t)t.size();
-  for (const FeatDesc &d : st->desc_host) if (nich_tail(d)) t.push_back(d);
+  // The second phase, in BLOCKS (family_math.hpp "nich BLOCKS"): the plain nich features ordered by their nu prior
+  // (stable: the caller's order among equals), runs of an equal nu cut into blocks of at most kNichBlock, as even as they
+  // come (five are 3 + 2, not 4 + 1: a feature on its own pays the full logarithm).  Whether a block's c1 really are equal
+  // is for the head kernel to say (the counts are the suff-stats', not the plan's).
+  {
+    std::vector<uint32_t> tail;
+    for (uint32_t i = 0; i < st->nfeat; i++) if (nich_tail(st->desc_host[i])) tail.push_back(i);
+    auto nu_bits = [&](uint32_t i) { uint32_t b; std::memcpy(&b, &st->feats[i].hp[3], 4); return b; };
+    static const bool no_blocks = std::getenv("MSC_NO_NICH_BLOCKS") != nullptr;       // (A/B knob: every feature on its own)
+    std::stable_sort(tail.begin(), tail.end(), [&](uint32_t a, uint32_t b) { return nu_bits(a) < nu_bits(b); });
+    st->nich_blocks_any = false;
+    for (size_t a = 0; a < tail.size();) {
+      size_t b = a + 1;
+      while (b < tail.size() && nu_bits(tail[b]) == nu_bits(tail[a])) b++;
+      const size_t n = b - a, nb = no_blocks ? n : (n + kNichBlock - 1) / kNichBlock, base = n / nb, rem = n % nb;
+      for (size_t blk = 0, at = a; blk < nb; blk++) {
+        const size_t len = base + (blk < rem ? 1 : 0);
+        for (size_t j = 0; j < len; j++) {
+          FeatDesc d = st->desc_host[tail[at + j]];
+          d.blk_first = (uint32_t)(t.size() - j);
+          d.blk_end = d.blk_first + (uint32_t)len;
+          d.nich_info = st->nich_info + tail[at + j];
+          t.push_back(d);
+        }
+        st->nich_blocks_any |= len >= 2;
+        at += len;
+      }
+      a = b;
+    }
+  }
   // masked lookup columns: the tile plan reads the copy with the mask folded in (bind_view) and sees no mask -- a masked
   // value selects the table's zero row, which the feature stages with the others (one more row: `extra`)
   std::vector<uint32_t> extra(t.size(), 0u);
@@ -938,6 +970,10 @@ static int plan_groups(msc_state *st) {
   st->fuse_any = !fused.empty();
   st->fuse_nfeat = (uint32_t)tf.size();
   st->fuse_split = split - (n - st->fuse_nfeat);
+  for (uint32_t i = st->fuse_split; i < st->fuse_nfeat; i++) {     // (block bounds are indices into the plan they sit in)
+    tf[i].blk_first -= n - st->fuse_nfeat;
+    tf[i].blk_end -= n - st->fuse_nfeat;
+  }
   if (st->fuse_any) facts = plan_layout(tf, st->fuse_split, extra_f);
   st->tile_roles_ok = facts.roles_ok;
   st->tile_narrow_tail_ok = facts.tail_ok;
@@ -1007,6 +1043,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->desc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_fuse_dev, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->nich_info, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
@@ -1547,9 +1584,11 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
 
 // the tables of the plan's fused bb runs follow their members' (whatever updated those -- prepare, commit, an entity op):
 // rebuilt at the head of every call that scores with the fused plan, one small launch
+// ... and so does what the plan's nich blocks go by (NichPlanInfo: is a block's c1 one number per group, how far a value may
+// lie before a product of four could overflow) -- the same launch
 static int refresh_fused_tables(msc_state *st) {
-  if (!st->fuse_any) return MSC_OK;
-  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, st->kpad))
+  if (!st->fuse_any && !st->nich_blocks_any) return MSC_OK;
+  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, st->nich_blocks_any ? (int)st->fuse_nfeat : (int)st->fuse_split, st->kpad))
     return fail(MSC_EHIP, "k_fuse_tables launch failed");
   return MSC_OK;
 }

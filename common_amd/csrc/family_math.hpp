@@ -365,10 +365,11 @@ MSC_DEV float nich_accum(float acc, float x, float smu_hi, float smu_lo, float c
 //     satisfy |x_f| <= xlim_f = (2^15 - max_g |s mu|) / max_g s (head kernel, per feature) cannot overflow whatever the
 //     group; a row with a value beyond -- 32768 posterior scales from some group -- is a "far" row and takes nich_accum
 //     for all its plain nich features.  The decision is the row's, so a row's bits do not depend on what shares its wave.
-// Error: t_f carries 2.5 eps relative (a: two roundings; the square: one half), the joins add at most one eps a level,
-// so P is within ~4.5 eps and c1 log1p(P) within 4.5 eps P / ((1 + P) log1p(P)) <= 4.5 eps of ITSELF; nich_accum's
-// per-feature term is within ~2 eps of itself.  Against the gate on a sum of D features, 1e-6 sum_f max(1, |score_f|)
-// = 16.8 eps per feature, both are small; tests/test_host_numerics.py replays the float arithmetic against double.
+// Error: t_f carries 2.5 eps relative (a: two roundings; the square: one half), the joins add at most one eps a level
+// and the compensated log1p its own, so c1 log1p(P) is within 6 eps P / ((1 + P) log1p(P)) <= 6 eps of ITSELF in the
+// worst case (5.5 seen in 400k draws; the median is below one eps); nich_accum's per-feature term is within ~2.  Against
+// the gate on a sum of D features, 1e-6 sum_f max(1, |score_f|) = 16.8 eps per feature, both are small;
+// tests/test_host_numerics.py replays the float arithmetic against double.
 // (kNichBlock, kNichFarA, NichPlanInfo: msc_internal.hpp)
 MSC_DEV float nich_t(float x, float smu_hi, float smu_lo, float s) {
 #pragma clang fp contract(off)

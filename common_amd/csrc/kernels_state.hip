@@ -491,8 +491,41 @@ int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_
 // the tables of the plan's fused bb runs: row i of a fused feature = its members' rows (i >> j) & 1, summed in member
 // order (floats, one association everywhere: every kernel that scores the run reads this table).  One block per feature
 // of the plan's first phase; the others leave at once.
-__global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict__ feats, uint32_t kpad) {
+// Blocks beyond the first phase (launched only when the plan has a nich block of two or more features): what the block
+// arithmetic of the plain nich features goes by (family_math.hpp "nich BLOCKS"), from the tables as they stand now --
+//   xlim    = (2^15 - max_g |s mu|) / max_g s over ALL kpad groups: a value within it cannot make any group's |a| exceed
+//             2^15 (-1 when the tables hold something that is not a finite number: every row is "far" then);
+//   blk_ok  = at a block's first feature of two or more: every member's c1 ln2 row is bit-equal to the first's (suff-stats
+//             set feature by feature need not agree on the counts); 0 everywhere else.
+__global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict__ feats, int nsplit, uint32_t kpad) {
   const FeatDesc &fd = feats[blockIdx.x];
+  if ((int)blockIdx.x >= nsplit) {
+    if (fd.nich_info == nullptr) return;
+    float smax = 0.f, bmax = 0.f;
+    bool fine = true, same = true;
+    const bool leads = fd.blk_first == blockIdx.x && fd.blk_end > blockIdx.x + 1u;
+    for (uint32_t k = threadIdx.x; k < kpad; k += 256) {
+      const float s = fd.tab[(size_t)NICH_C2 * kpad + k];
+      const float b = __builtin_fabsf(fd.tab[(size_t)NICH_MU_HI * kpad + k]) + __builtin_fabsf(fd.tab[(size_t)NICH_MU_LO * kpad + k]);
+      fine &= s > 0.f && s < INFINITY && b < INFINITY;         // (false for NaN)
+      smax = fmaxf(smax, s);
+      bmax = fmaxf(bmax, b);
+      if (leads) {
+        const uint32_t mine = __float_as_uint(fd.tab[(size_t)NICH_C1LN2 * kpad + k]);
+        for (uint32_t j = blockIdx.x + 1; j < fd.blk_end; j++) same &= __float_as_uint(feats[j].tab[(size_t)NICH_C1LN2 * kpad + k]) == mine;
+      }
+    }
+    __shared__ float s_s[256], s_b[256];
+    s_s[threadIdx.x] = smax;
+    s_b[threadIdx.x] = bmax;
+    const int all_fine = __syncthreads_and(fine ? 1 : 0), all_same = __syncthreads_and(same ? 1 : 0);
+    if (threadIdx.x == 0) {
+      for (int i = 1; i < 256; i++) smax = fmaxf(smax, s_s[i]), bmax = fmaxf(bmax, s_b[i]);
+      fd.nich_info->xlim = (all_fine && bmax < kNichFarA) ? (kNichFarA - bmax) / smax : -1.f;
+      fd.nich_info->blk_ok = (leads && all_same) ? 1u : 0u;
+    }
+    return;
+  }
   const uint32_t m = fd.fuse_n, radix = fd.fuse_radix;
   if (m < 2) return;
   uint32_t rows = 1;
@@ -512,9 +545,10 @@ __global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict_
     }
   }
 }
-int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, uint32_t kpad) {
-  if (nsplit <= 0) return 0;
-  hipLaunchKernelGGL(k_fuse_tables, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad);
+// nblocks: the plan's first phase alone (nsplit) or the whole plan (its nich blocks' records too)
+int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, int nblocks, uint32_t kpad) {
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(k_fuse_tables, dim3((unsigned)nblocks), dim3(256), 0, stream, feats_dev, nsplit, kpad);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

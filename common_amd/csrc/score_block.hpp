@@ -32,6 +32,18 @@ MSC_DEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Loads through pointers that come out of a FeatDesc are FLAT to the compiler (it cannot know the address space of a
+// pointer it loaded): a 64-bit vector address per load, and a wait on the LDS counter as well.  The tables and columns
+// are global memory: said so, a load is the descriptor's scalar base + one 32-bit lane offset shared by all of them.
+typedef const __attribute__((address_space(1))) float *gfloat_p;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2 *gfloat2_p;
+typedef const __attribute__((address_space(1))) f32x4 *gfloat4_p;
+MSC_DEV gfloat_p as_global(const void *p) { return (gfloat_p)(const float *)p; }
+MSC_DEV float gld1(gfloat_p p) { return *p; }
+MSC_DEV float2 gld2(gfloat_p p) { const f32x2 v = *(gfloat2_p)p; return make_float2(v.x, v.y); }
+MSC_DEV float4 gld4(gfloat_p p) { const f32x4 v = *(gfloat4_p)p; return make_float4(v.x, v.y, v.z, v.w); }
+
 
 // 16-byte global -> LDS copy that bypasses the VGPRs (global_load_lds_dwordx4): every lane
 // supplies its own source address, the destination is lds_wave_base + lane * 16.
@@ -374,7 +386,7 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
 // (family_math.hpp nich_accum); read from the tables in L2, once per chunk
 MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb) {
   float4 s = make_float4(0, 0, 0, 0);
-  for (int f = f0; f < nfeat; f++) add4(s, ld4(feats[f].tab + (size_t)NICH_C0 * kpad + kb));
+  for (int f = f0; f < nfeat; f++) add4(s, gld4(as_global(feats[f].tab) + (size_t)NICH_C0 * kpad + kb));
   return s;
 }
 MSC_DEV float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
@@ -383,7 +395,7 @@ MSC_DEV float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p)
 MSC_DEV unsigned long long nich_far_rows(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint64_t myrow, bool has_row) {
   bool far = false;
   for (int f = f0; f < nfeat; f++) {
-    const float x = reinterpret_cast<const float *>(feats[f].col)[myrow];
+    const float x = gld1(as_global(feats[f].col) + myrow);
     far |= !(__builtin_fabsf(x) <= feats[f].nich_info->xlim);
   }
   return __builtin_amdgcn_ballot_w64(far && has_row);
@@ -429,15 +441,15 @@ MSC_DEV void nich_block_rows(const float (&xv)[M], const float2 (&mh)[M], const 
       acc[r].z = nich_block_finish<EST>(acc[r].z, p0, c1l.x);
       acc[r].w = nich_block_finish<EST>(acc[r].w, p1, c1l.y);
     }
-    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows of temporaries at a time
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (one, two or four rows in flight: the same registers, four is the shortest code)
   }
 }
 // where a block's constants come from: the tables in L2 (the role-split kernels' nich waves) ...
 struct NichFromGlobal {
   const FeatDesc *__restrict__ feats;
   uint32_t kpad, kb;
-  MSC_DEV float2 pair(int f, int row, int p) const { return ld2(feats[f].tab + (size_t)row * kpad + kb + 2 * p); }
-  MSC_DEV float4 quad(int f, int row) const { return ld4(feats[f].tab + (size_t)row * kpad + kb); }
+  MSC_DEV float2 pair(int f, int row, int p) const { return gld2(as_global(feats[f].tab) + (size_t)row * kpad + (kb + 2 * p)); }
+  MSC_DEV float4 quad(int f, int row) const { return gld4(as_global(feats[f].tab) + (size_t)row * kpad + kb); }
 };
 // ... or the staged feature group in LDS (the kernels that run the phases one after the other)
 struct NichFromLds {
@@ -453,7 +465,7 @@ template <int M, int R, bool EST, typename Src>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
-  for (int j = 0; j < M; j++) xv[j] = reinterpret_cast<const float *>(feats[f + j].col)[myrow];
+  for (int j = 0; j < M; j++) xv[j] = gld1(as_global(feats[f + j].col) + myrow);
   {
     float2 mh[M], ml[M], sc[M];
 #pragma unroll
@@ -484,7 +496,7 @@ MSC_DEV void nich_features(const FeatDesc *__restrict__ feats, int f0, int f1, c
     // a feature on its own (or a block whose c1 differ): nich_accum, as before there were blocks
     const float4 mh = src.quad(f, NICH_MU_HI), ml = src.quad(f, NICH_MU_LO), c1l = src.quad(f, NICH_C1LN2),
                  c1 = src.quad(f, NICH_C1), c2 = src.quad(f, NICH_C2);
-    const float xv = reinterpret_cast<const float *>(feats[f].col)[myrow];
+    const float xv = gld1(as_global(feats[f].col) + myrow);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const float x = lane_bcast(xv, r);

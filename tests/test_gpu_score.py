@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
-from tests.gpu_helpers import (TOL, crp_prior_matrix, load_state, make_feature, oracle_scores,
+from tests.gpu_helpers import (TOL, audit, crp_prior_matrix, load_state, make_feature, oracle_scores,
                                recarray_of, rel_err, state_from_assignment)
 
 pytestmark = pytest.mark.gpu
@@ -529,3 +529,119 @@ def test_fused_bb_columns_follow_every_table_update(gpu_ctx, nbb, K, monkeypatch
     assert (np.abs(a - b) / np.maximum(1.0, np.abs(a))).max() <= 1e-5
     assert np.array_equal(b, st.score_value(view)[rt].cpu().numpy())
     assert fused.shape == (N, K)
+
+
+# ---- nich BLOCKS (family_math.hpp): plain nich features that share c1 are scored as one log1p of a product -------------
+def _nich_block_state(gpu_ctx, specs, N, K, rng, hp_of=None, z_of=None, edit=None):
+    """state + view of `specs`; hp_of[i]: that feature's hp; z_of[i]: the assignment ITS suff-stats come from (default: z)"""
+    import common_amd
+    feats = [make_feature(f, N, K, rng, d, hp=(hp_of or {}).get(i)) for i, (f, d) in enumerate(specs)]
+    if edit:
+        edit(feats)
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = []
+    for i, f in enumerate(feats):
+        fs.append(state_from_assignment([f], K, (z_of or {}).get(i, z))[0])
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, specs, K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    st.set_alpha(1.1)
+    return feats, fs, z, view, st
+
+
+def _gate_on_sum(got, feats, fs, rows, z=None, prior=None):
+    """|got - sum_f twin_f| <= 1e-6 sum_f max(1, |twin_f|) (+ the prior's magnitude): the per-feature tolerances add"""
+    tw = [F.score_matrix(ss64, f["values"][rows], None if z is None else z[rows]) for f, (F, ss64, _) in zip(feats, fs)]
+    total = sum(tw) + (0.0 if prior is None else prior)
+    mag = sum(np.maximum(1.0, np.abs(t)) for t in tw) + (0.0 if prior is None else np.maximum(1.0, np.abs(prior)))
+    return (np.abs(got - total) / np.maximum(mag, np.abs(total))).max()
+
+
+@pytest.mark.parametrize("K", [48, 100, 256, 300])
+@pytest.mark.parametrize("nnich", [2, 3, 4, 5, 9, 16])
+def test_nich_blocks_of_every_size_against_the_twin(gpu_ctx, K, nnich, monkeypatch):
+    """two to sixteen plain nich columns beside lookup columns (blocks of 2, 3, 4; 5 = 3 + 2; 9 = 3 + 3 + 3; 16 = 4 x 4) on
+    every kernel that walks the plan: few rows (tile kernels, phases one after the other), many (role-split / lane <-> row),
+    leave-one-out + prior.  The gate is the north star's on a sum of features; slices of the whole come out bit for bit."""
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    rng = np.random.default_rng(1000 * K + nnich)
+    N = 40_000
+    specs = [(orc.BB, 0), (orc.GP, 0)] + [(orc.NICH, 0)] * nnich + [(orc.DD, 9)]
+    feats, fs, z, view, st = _nich_block_state(gpu_ctx, specs, N, K, rng)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    rows = np.unique(np.concatenate([[0, N - 1], rng.choice(N, 250, replace=False)]))
+    rt = torch.from_numpy(rows).to(gpu_ctx.torch_device)
+    plain = st.score_value(view)
+    audit("nich_blocks.sum_of_features.n%d" % nnich, _gate_on_sum(plain[rt].cpu().numpy(), feats, fs, rows), TOL)
+    loo = st.score_value(view, z=zt, crp_prior=True)
+    counts = np.bincount(z, minlength=K)
+    audit("nich_blocks.sum_of_features_loo_prior.n%d" % nnich,
+          _gate_on_sum(loo[rt].cpu().numpy(), feats, fs, rows, z=z, prior=crp_prior_matrix(counts, 1.1, z[rows])), TOL)
+    for row0, n in ((0, 300), (N // 2 + 1, 129), (N - 64, 64)):     # (few rows: the tile kernels, one phase after the other)
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True), loo[row0:row0 + n])
+
+
+def test_nich_blocks_follow_the_nu_prior_and_the_counts_the_suffstats_hold(gpu_ctx, monkeypatch):
+    """What makes a block: the same nu prior (the host's plan) AND, per group, the same count (the head kernel looks at the
+    c1 the suff-stats produced).  Columns 2-5 share nu = 1 but column 4's suff-stats come from ANOTHER assignment (set
+    feature by feature, as msc_state_set_ss allows): its block is scored feature by feature; columns 6, 7 have nu = 3.5 and
+    form a block of their own; column 8's nu is its own.  Against the twin, and -- for the features that fell back -- the
+    bits of a plan without blocks (MSC_NO_NICH_BLOCKS)."""
+    import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    K, N = 200, 30_000
+    specs = [(orc.BB, 0), (orc.DD, 5)] + [(orc.NICH, 0)] * 7
+    hp = lambda nu: dict(mu=0.3, kappa=1.5, sigmasq=0.8, nu=nu)    # noqa: E731
+    hp_of = {2: hp(1.0), 3: hp(1.0), 4: hp(1.0), 5: hp(1.0), 6: hp(3.5), 7: hp(3.5), 8: hp(2.25)}
+    seed = 4242
+    z_other = np.random.default_rng(99).integers(0, K, N).astype(np.int32)
+    feats, fs, z, view, st = _nich_block_state(gpu_ctx, specs, N, K, np.random.default_rng(seed), hp_of=hp_of, z_of={4: z_other})
+    got = st.score_value(view)
+    rows = np.unique(np.random.default_rng(5).choice(N, 300, replace=False))
+    audit("nich_blocks.mixed_nu_and_counts", _gate_on_sum(got[torch.from_numpy(rows).to(got.device)].cpu().numpy(), feats, fs, rows), TOL)
+    part = st.score_value(view, row0=1000, nrows=200)              # (the tile kernels on few rows: the same bits)
+    assert torch.equal(part, got[1000:1200])
+    # four nu = 1 columns alone, one of them holding another assignment's counts: the block falls back to nich_accum
+    sub = [(orc.NICH, 0)] * 4
+    f4, s4, z4, v4, st4 = _nich_block_state(gpu_ctx, sub, N, K, np.random.default_rng(seed + 1), hp_of={i: hp(1.0) for i in range(4)},
+                                            z_of={2: z_other})
+    a = st4.score_value(v4)
+    tw = [F.score_matrix(ss64, f["values"]) for f, (F, ss64, _) in zip(f4, s4)]
+    mag = sum(np.maximum(1.0, np.abs(t)) for t in tw)
+    audit("nich_blocks.differing_counts_fall_back", (np.abs(a.cpu().numpy() - sum(tw)) / mag).max(), TOL)
+    assert torch.equal(st4.score_value(v4, row0=500, nrows=100), a[500:600])
+
+
+@pytest.mark.parametrize("K", [64, 256, 290])
+def test_far_rows_take_the_plain_path_for_all_their_nich_features(gpu_ctx, K, monkeypatch):
+    """a value 10^7 posterior scales from the groups (|a| beyond 2^15: four such squares multiplied leave the float range)
+    makes its ROW a far row: nich_accum feature by feature for that row, whatever the other rows of its wave do -- so the
+    row's bits are the same in a slice of 64 rows and in the whole, on the tile kernels and on the lane <-> row kernel, and
+    its scores meet the gate like any other's (they are hugely negative: relative)."""
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    rng = np.random.default_rng(31 * K)
+    N = 20_000
+    specs = [(orc.BB, 0)] + [(orc.NICH, 0)] * 6 + [(orc.GP, 0)]
+    far_rows = np.array([5, 129, 4097, 12_345, N - 1])
+
+    def edit(feats):
+        for j, r in enumerate(far_rows):
+            feats[1 + j % 6]["values"][r] = np.float32((-1.0) ** j * 3.0e7 * (1 + j))
+        feats[3]["values"][777] = np.float32(np.inf)               # (garbage in: the row's scores are not finite, nobody else's change)
+    feats, fs, z, view, st = _nich_block_state(gpu_ctx, specs, N, K, rng, edit=edit)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    plain = st.score_value(view)
+    rows = np.unique(np.concatenate([far_rows, far_rows[:-1] + 1, rng.choice(N, 100, replace=False)]))
+    rows = rows[rows != 777]
+    got = plain[torch.from_numpy(rows).to(plain.device)].cpu().numpy()
+    assert np.isfinite(got).all()
+    audit("nich_blocks.far_rows", _gate_on_sum(got, feats, fs, rows), TOL)
+    assert not bool(torch.isfinite(plain[777]).any())
+    loo = st.score_value(view, z=zt, crp_prior=True)
+    for r in far_rows:
+        row0 = max(0, int(r) - 20)
+        n = min(64, N - row0)
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True), loo[row0:row0 + n])
