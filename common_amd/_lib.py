@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmicroscopes_hip.so")
+# (MSC_LIB_PATH: an experiment build of the same library, common_amd/csrc/Makefile VARIANT=...; the product is the default)
+LIB_PATH = os.environ.get("MSC_LIB_PATH") or os.path.join(_HERE, "lib", "libmicroscopes_hip.so")
 
 # families / primitive types / flags, mirrored from the header
 BB, GP, DD, NICH, NIW, NOOP, BBNC, BNB, DM = range(9)

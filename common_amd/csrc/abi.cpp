@@ -908,6 +908,8 @@ static int plan_groups(msc_state *st) {
   tf.clear();
   // (the view is only looked at while it exists: a plan made after its view is gone -- msc_state_set_hp on a dd feature
   // re-plans -- fuses nothing and holds no column; the next call that brings a view binds and plans again)
+  if (!st->nich_blocks_any)                                     // (no block of two or more: no records, no head-kernel work, no far rows)
+    for (FeatDesc &d : t) d.nich_info = nullptr;
   const bool may_fuse = bview != nullptr && std::getenv("MSC_NO_BB_FUSE") == nullptr;
   // (columns with a mask: their mask-folded copies, three states a value -- 0, 1, masked = the member's zero row --,
   // three at a time against 27 rows)

@@ -395,7 +395,7 @@ MSC_DEV float nich_block_finish(float acc, float P, float c1ln2) {
 }
 template <int M>
 MSC_DEV float nich_block_product(const float (&t)[M]) {
-  static_assert(M >= 2 && M <= kNichBlock, "blocks of two to four features");
+  static_assert(M >= 2 && M <= 4, "blocks of two to four features");
   if constexpr (M == 2) return nich_join(t[0], t[1]);
   else if constexpr (M == 3) return nich_join(nich_join(t[0], t[1]), t[2]);
   else return nich_join(nich_join(t[0], t[1]), nich_join(t[2], t[3]));

@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
       }
     }
     // ---- second phase: plain nich features, in the plan's BLOCKS (family_math.hpp "nich BLOCKS"; the steps of
-    // score_block.hpp nich_features, so that SPLIT gives the tile kernels' bits).  The accumulator starts from the
+    // score_block.hpp nich_segment, so that SPLIT gives the tile kernels' bits).  The accumulator starts from the
     // features' summed c0; a block whose c1 the head kernel found equal is ONE compensated log1p of the product of its
     // members' 1 + t per group, every other feature nich_accum's two fused multiply-adds.  The groups' constants are
     // SCALAR operands but for s*mu (hi), which an instruction needs beside s (one scalar operand an instruction on this
@@ -1163,7 +1163,8 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
       for (int g = 0; g < TGP; g++) acc[g] += c0s[g];
     }
     bool far = false;
-    for (int fb = nsplit; fb < nfeat; fb += 8) {
+    const bool blocks = nsplit < nfeat && feats[nsplit].nich_info != nullptr;     // (records for all of the phase's features, or none)
+    for (int fb = nsplit; blocks && fb < nfeat; fb += 8) {
       const uint32_t w0 = load_value(fb, rr), w1 = load_value(fb + 1, rr), w2 = load_value(fb + 2, rr), w3 = load_value(fb + 3, rr),
                      w4 = load_value(fb + 4, rr), w5 = load_value(fb + 5, rr), w6 = load_value(fb + 6, rr), w7 = load_value(fb + 7, rr);
       auto lim = [&](int f) { return feats[f < nfeat ? f : nfeat - 1].nich_info->xlim; };     // (load_value clamps the same way)
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
       }
     };
     // a block of M features: four groups' constants at a time, (2 M + 1) x 4 scalar registers
-    auto product_block = [&](int f, auto mtag, const float (&x)[kNichBlock]) {
+    auto product_block = [&](int f, auto mtag, const float (&x)[4]) {
       constexpr int M = decltype(mtag)::value;
       typedef float f32x4s __attribute__((ext_vector_type(4)));
       typedef const volatile __attribute__((address_space(4))) f32x4s *scalar_f4;
@@ -1225,22 +1226,35 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    for (int f = nsplit; f < nfeat;) {
-      const bool ok = feats[f].nich_info->blk_ok != 0u;    // (set at a block's first feature only, and only for blocks of two or more)
-      const int m = ok ? (int)feats[f].blk_end - f : 1;
-      const float x[kNichBlock] = {__uint_as_float(load_value(f, rr)), __uint_as_float(load_value(f + 1, rr)),
-                                   __uint_as_float(load_value(f + 2, rr)), __uint_as_float(load_value(f + 3, rr))};
-      const bool prod = ok && !far;
-      if (prod) {
-        if (m == 2) product_block(f, std::integral_constant<int, 2>(), x);
-        else if (m == 3) product_block(f, std::integral_constant<int, 3>(), x);
-        else product_block(f, std::integral_constant<int, 4>(), x);
-      }
-      if (!prod) {
+    // the order of score_block.hpp nich_segment: per LDS feature group of the plan, its blocks of four that go as one, then
+    // three, then two, then every feature left
+    for (int s0 = nsplit; s0 < nfeat;) {
+      const int s1 = (int)feats[s0].grp_end;
+      if (blocks) {
 #pragma unroll 1
-        for (int j = 0; j < m; j++) plain_feature(f + j, j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3]);
+        for (int M = kNichBlock; M >= 2; M--) {
+          for (int f = s0; f < s1;) {
+            const int len = (int)feats[f].blk_end - f;
+            if (len == M && feats[f].nich_info->blk_ok != 0u) {
+              const float x[4] = {__uint_as_float(load_value(f, rr)), __uint_as_float(load_value(f + 1, rr)),
+                                  __uint_as_float(load_value(f + 2, rr)), __uint_as_float(load_value(f + 3, rr))};
+              if (!far) {
+                if (M == 2) product_block(f, std::integral_constant<int, 2>(), x);
+                else if (M == 3) product_block(f, std::integral_constant<int, 3>(), x);
+                else product_block(f, std::integral_constant<int, 4>(), x);
+              }
+            }
+            f += len;
+          }
+        }
       }
-      f += m;
+#pragma unroll 1
+      for (int f = s0; f < s1; f++) {
+        const bool covered = blocks && feats[feats[f].blk_first].nich_info->blk_ok != 0u;    // (went as one with its block)
+        const float x = __uint_as_float(load_value(f, rr));
+        if (far || !covered) plain_feature(f, x);
+      }
+      s0 = s1;
     }
     const float *prh = pr[single ? 3 : 2];
     if (DRAW) {

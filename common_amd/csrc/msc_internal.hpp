@@ -80,7 +80,10 @@ inline size_t crp_floats(uint32_t kpad) { return 4 * (size_t)kpad + 4; }
 //   bnb  i64 {count, sum}
 //   dm   i64 {counts[dim]}           f64 {ratio}
 // nich blocks (family_math.hpp): up to kNichBlock plain nich features of the plan's second phase that share c1
-constexpr int kNichBlock = 4;
+#ifndef MSC_NICH_BLOCK
+#define MSC_NICH_BLOCK 4
+#endif
+constexpr int kNichBlock = MSC_NICH_BLOCK;
 constexpr float kNichFarA = 32768.0f;                    // |a| beyond this: the row is "far" (see NichPlanInfo::xlim)
 struct NichPlanInfo {                                    // per feature of the plan's second phase (FeatDesc::nich_info)
   float xlim;                                            // |x| <= xlim: no group's |a| = |s x - s mu| exceeds kNichFarA

@@ -40,6 +40,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x2 *gfloat2_p;
 typedef const __attribute__((address_space(1))) f32x4 *gfloat4_p;
 MSC_DEV gfloat_p as_global(const void *p) { return (gfloat_p)(const float *)p; }
+// ... and the descriptors themselves are read-only for the kernel's lifetime and indexed by wave-uniform numbers: through
+// the constant address space their fields are SCALAR loads whatever the compiler can prove about the index (a feature
+// index that came out of a descriptor -- the end of a nich block -- otherwise turns every later descriptor access into a
+// per-lane load with a wait behind it)
+typedef const __attribute__((address_space(4))) FeatDesc *scalar_feats;
+MSC_DEV scalar_feats as_scalar(const FeatDesc *f) { return (scalar_feats)f; }
+MSC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a load at (uniform base + uniform element offset) + this lane's BYTE offset: written so that the lane's part is one
+// 32-bit register zero-extended (the instruction's own addressing: scalar base, 32-bit vector offset) -- an element
+// offset would be a shift of the extension, i.e. 64-bit vector arithmetic and a register pair per address
+typedef const __attribute__((address_space(1))) char *gchar_p;
+MSC_DEV gfloat_p at_lane(gfloat_p base, size_t uniform_elems, uint32_t lane_bytes) {
+  return (gfloat_p)((gchar_p)(base + uniform_elems) + (size_t)lane_bytes);
+}
 MSC_DEV float gld1(gfloat_p p) { return *p; }
 MSC_DEV float2 gld2(gfloat_p p) { const f32x2 v = *(gfloat2_p)p; return make_float2(v.x, v.y); }
 MSC_DEV float4 gld4(gfloat_p p) { const f32x4 v = *(gfloat4_p)p; return make_float4(v.x, v.y, v.z, v.w); }
@@ -386,17 +400,22 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
 // (family_math.hpp nich_accum); read from the tables in L2, once per chunk
 MSC_DEV float4 nich_c0_sum(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t kb) {
   float4 s = make_float4(0, 0, 0, 0);
-  for (int f = f0; f < nfeat; f++) add4(s, gld4(as_global(feats[f].tab) + (size_t)NICH_C0 * kpad + kb));
+  const scalar_feats sf = as_scalar(feats);
+  for (int f = f0; f < nfeat; f++) add4(s, gld4(at_lane(as_global(sf[f].tab), (size_t)NICH_C0 * kpad, kb * 4u)));
   return s;
 }
 MSC_DEV float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
 // bit r: the wave's row r (lane r holds it: `myrow`) has a plain nich value beyond its feature's xlim (NaN included)
+// (a plan without a block of two or more has no records -- nich_info is null throughout -- and no far rows)
+typedef const __attribute__((address_space(4))) NichPlanInfo *scalar_info;
 MSC_DEV unsigned long long nich_far_rows(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint64_t myrow, bool has_row) {
+  const scalar_feats sf = as_scalar(feats);
+  if (f0 >= nfeat || sf[f0].nich_info == nullptr) return 0ull;
   bool far = false;
   for (int f = f0; f < nfeat; f++) {
-    const float x = gld1(as_global(feats[f].col) + myrow);
-    far |= !(__builtin_fabsf(x) <= feats[f].nich_info->xlim);
+    const float x = gld1(as_global(sf[f].col) + myrow);
+    far |= !(__builtin_fabsf(x) <= ((scalar_info)sf[f].nich_info)->xlim);
   }
   return __builtin_amdgcn_ballot_w64(far && has_row);
 }
@@ -418,85 +437,145 @@ static __device__ __attribute__((noinline)) float4 nich_row_plain(const FeatDesc
   }
   return a;
 }
-// One block of M features against TWO of the lane's four groups (pair P: components 2P, 2P + 1 of the accumulators) for
-// the wave's R rows: 3 M constants of two groups each in registers (a block of four against all four groups would be 52
-// registers beside 64 of sums -- the kernels run four waves a SIMD), the rows' values broadcast per use.
-template <int M, int R, int P, bool EST>
-MSC_DEV void nich_block_rows(const float (&xv)[M], const float2 (&mh)[M], const float2 (&ml)[M], const float2 (&sc)[M],
-                             const float2 c1l, float4 (&acc)[R]) {
+// One block of M features against NC (1, 2 or 4) of the lane's four groups -- components C0 .. C0 + NC - 1 of the
+// accumulators -- for the wave's R rows: 3 M constants of NC groups each in registers (a block of four against all four
+// groups would be 52 registers beside 64 of sums and the kernels run four waves a SIMD: MSC_NICH_NC), the rows' values
+// broadcast per use.
+template <int C> MSC_DEV float &comp(float4 &v) {
+  if constexpr (C == 0) return v.x;
+  else if constexpr (C == 1) return v.y;
+  else if constexpr (C == 2) return v.z;
+  else return v.w;
+}
+template <int M, int R, int C0, int NC, bool EST>
+MSC_DEV void nich_block_rows(const float (&xv)[M], const float (&mh)[M][NC], const float (&ml)[M][NC], const float (&sc)[M][NC],
+                             const float (&c1l)[NC], float4 (&acc)[R]) {
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    float t0[M], t1[M];
+    float x[M];
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-      const float x = lane_bcast(xv[j], r);
-      t0[j] = nich_t(x, mh[j].x, ml[j].x, sc[j].x);
-      t1[j] = nich_t(x, mh[j].y, ml[j].y, sc[j].y);
+    for (int j = 0; j < M; j++) x[j] = lane_bcast(xv[j], r);
+    float p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      float t[M];
+#pragma unroll
+      for (int j = 0; j < M; j++) t[j] = nich_t(x[j], mh[j][c], ml[j][c], sc[j][c]);
+      p[c] = nich_block_product<M>(t);
     }
-    const float p0 = nich_block_product<M>(t0), p1 = nich_block_product<M>(t1);
-    if (P == 0) {
-      acc[r].x = nich_block_finish<EST>(acc[r].x, p0, c1l.x);
-      acc[r].y = nich_block_finish<EST>(acc[r].y, p1, c1l.y);
-    } else {
-      acc[r].z = nich_block_finish<EST>(acc[r].z, p0, c1l.x);
-      acc[r].w = nich_block_finish<EST>(acc[r].w, p1, c1l.y);
+    if constexpr (NC >= 1) comp<C0>(acc[r]) = nich_block_finish<EST>(comp<C0>(acc[r]), p[0], c1l[0]);
+    if constexpr (NC >= 2) comp<C0 + 1>(acc[r]) = nich_block_finish<EST>(comp<C0 + 1>(acc[r]), p[1], c1l[1]);
+    if constexpr (NC >= 4) {
+      comp<C0 + 2>(acc[r]) = nich_block_finish<EST>(comp<C0 + 2>(acc[r]), p[2], c1l[2]);
+      comp<C0 + 3>(acc[r]) = nich_block_finish<EST>(comp<C0 + 3>(acc[r]), p[3], c1l[3]);
     }
-    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (one, two or four rows in flight: the same registers, four is the shortest code)
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four rows of temporaries at a time)
   }
 }
 // where a block's constants come from: the tables in L2 (the role-split kernels' nich waves) ...
 struct NichFromGlobal {
   const FeatDesc *__restrict__ feats;
   uint32_t kpad, kb;
-  MSC_DEV float2 pair(int f, int row, int p) const { return gld2(as_global(feats[f].tab) + (size_t)row * kpad + (kb + 2 * p)); }
-  MSC_DEV float4 quad(int f, int row) const { return gld4(as_global(feats[f].tab) + (size_t)row * kpad + kb); }
+  // BUFFER loads: the feature's table as a raw buffer (scalar descriptor: base and size), the row and pair as the scalar
+  // offset, kb * 4 as the one 32-bit lane offset of every load of the phase.  (Through global loads the compiler formed
+  // a 64-bit vector address per load -- thirteen register pairs a block beside 64 registers of sums: the sums spilled.)
+  typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  MSC_DEV __amdgpu_buffer_rsrc_t table(int f) const {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(as_scalar(feats)[f].tab), 0, 0x7fffffff, 0x00020000);
+  }
+  template <int NC> MSC_DEV void comps(int f, int row, int c0, float (&o)[NC]) const {
+    const uint32_t so = (uint32_t)(row * kpad + c0) * 4u;
+    if constexpr (NC == 1) {
+      o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(table(f), kb * 4u, so, 0));
+    } else if constexpr (NC == 2) {
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(table(f), kb * 4u, so, 0);
+      o[0] = __uint_as_float(v.x), o[1] = __uint_as_float(v.y);
+    } else {
+      const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(table(f), kb * 4u, so, 0);
+      o[0] = __uint_as_float(v.x), o[1] = __uint_as_float(v.y), o[2] = __uint_as_float(v.z), o[3] = __uint_as_float(v.w);
+    }
+  }
+  MSC_DEV float4 quad(int f, int row) const {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(table(f), kb * 4u, (uint32_t)(row * kpad) * 4u, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
 };
 // ... or the staged feature group in LDS (the kernels that run the phases one after the other)
 struct NichFromLds {
   const FeatDesc *__restrict__ feats;
   const float4 *__restrict__ lds;
   int lane;
-  MSC_DEV float2 pair(int f, int row, int p) const {
-    return reinterpret_cast<const float2 *>(lds + ((size_t)feats[f].grp_off + row) * 64 + lane)[p];
+  template <int NC> MSC_DEV void comps(int f, int row, int c0, float (&o)[NC]) const {
+    const float *p = reinterpret_cast<const float *>(lds + ((size_t)as_scalar(feats)[f].grp_off + row) * 64 + lane) + c0;
+    if constexpr (NC == 1) {
+      o[0] = p[0];
+    } else if constexpr (NC == 2) {
+      const float2 v = *reinterpret_cast<const float2 *>(p);
+      o[0] = v.x, o[1] = v.y;
+    } else {
+      const float4 v = *reinterpret_cast<const float4 *>(p);
+      o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+    }
   }
-  MSC_DEV float4 quad(int f, int row) const { return lds[((size_t)feats[f].grp_off + row) * 64 + lane]; }
+  MSC_DEV float4 quad(int f, int row) const { return lds[((size_t)as_scalar(feats)[f].grp_off + row) * 64 + lane]; }
 };
+// groups of the lane's four a block part takes: 2 (26 registers of constants at M = 4 beside the 4 R sums; with 1 the rows'
+// values are broadcast four times over -- C3 1.78 ms against 1.57 --, with 4 the constants spill: 2.76)
+#ifndef MSC_NICH_NC
+#define MSC_NICH_NC 2
+#endif
+template <int M, int R, int C0, int NC, bool EST, typename Src>
+MSC_DEV void nich_block_part(const FeatDesc *__restrict__ feats, int f, const Src &src, const float (&xv)[M], float4 (&acc)[R]) {
+  float mh[M][NC], ml[M][NC], sc[M][NC], c1l[NC];
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    src.template comps<NC>(f + j, NICH_MU_HI, C0, mh[j]);
+    src.template comps<NC>(f + j, NICH_MU_LO, C0, ml[j]);
+    src.template comps<NC>(f + j, NICH_C2, C0, sc[j]);
+  }
+  src.template comps<NC>(f, NICH_C1LN2, C0, c1l);
+  nich_block_rows<M, R, C0, NC, EST>(xv, mh, ml, sc, c1l, acc);
+  __builtin_amdgcn_sched_barrier(0);                          // (the next part's constants after this part's rows)
+}
 template <int M, int R, bool EST, typename Src>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
-  for (int j = 0; j < M; j++) xv[j] = gld1(as_global(feats[f + j].col) + myrow);
-  {
-    float2 mh[M], ml[M], sc[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) mh[j] = src.pair(f + j, NICH_MU_HI, 0), ml[j] = src.pair(f + j, NICH_MU_LO, 0), sc[j] = src.pair(f + j, NICH_C2, 0);
-    nich_block_rows<M, R, 0, EST>(xv, mh, ml, sc, src.pair(f, NICH_C1LN2, 0), acc);
-  }
-  __builtin_amdgcn_sched_barrier(0);                          // (the second pair's constants after the first pair's rows)
-  {
-    float2 mh[M], ml[M], sc[M];
-#pragma unroll
-    for (int j = 0; j < M; j++) mh[j] = src.pair(f + j, NICH_MU_HI, 1), ml[j] = src.pair(f + j, NICH_MU_LO, 1), sc[j] = src.pair(f + j, NICH_C2, 1);
-    nich_block_rows<M, R, 1, EST>(xv, mh, ml, sc, src.pair(f, NICH_C1LN2, 1), acc);
+  for (int j = 0; j < M; j++) xv[j] = gld1(as_global(as_scalar(feats)[f + j].col) + myrow);
+  constexpr int NC = MSC_NICH_NC;
+  nich_block_part<M, R, 0, NC, EST>(feats, f, src, xv, acc);
+  if constexpr (NC <= 2) nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
+  if constexpr (NC == 1) {
+    nich_block_part<M, R, 2, NC, EST>(feats, f, src, xv, acc);
+    nich_block_part<M, R, 3, NC, EST>(feats, f, src, xv, acc);
   }
 }
-// the features [f0, f1) of the second phase (whole blocks), sums in acc; rows of `far` are redone by the caller
+// One SEGMENT of the second phase -- the features [f0, f1) of one LDS feature group (abi.cpp plan_layout; whole blocks) --
+// in the order every kernel keeps: the segment's blocks of four that go as one, then those of three, of two, then every
+// feature left (on its own in the plan, or in a block whose c1 differ), nich_accum.  Four loops with ONE body each: a
+// single loop that branches to the four bodies costs ~300 bytes of scratch per lane (the allocator gives up on the 4 R
+// sums across the arms) and runs C3 slower than no blocks at all; so the order of the sums follows the loops.
+// (Every number a loop branches on goes through readfirstlane: a branch the compiler cannot prove wave-uniform becomes
+// predication, with a merge of all the sums behind it.)
+template <int M, int R, bool EST, typename Src>
+MSC_DEV void nich_pass_blocks(const FeatDesc *__restrict__ feats, int f0, int f1, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
+  const scalar_feats sf = as_scalar(feats);
+  for (int f = f0; f < f1;) {
+    const int len = uniform((int)sf[f].blk_end) - f;
+    if (len == M && uniform((int)((scalar_info)sf[f].nich_info)->blk_ok) != 0) nich_block<M, R, EST>(feats, f, src, myrow, acc);
+    f = uniform(f + len);
+  }
+}
 template <int R, bool EST, typename Src>
-MSC_DEV void nich_features(const FeatDesc *__restrict__ feats, int f0, int f1, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
-  int f = f0;
-  while (f < f1) {
-    const int m = (int)feats[f].blk_end - f;
-    if (m >= 2 && feats[f].nich_info->blk_ok != 0u) {
-      if (m == 2) nich_block<2, R, EST>(feats, f, src, myrow, acc);
-      else if (m == 3) nich_block<3, R, EST>(feats, f, src, myrow, acc);
-      else nich_block<4, R, EST>(feats, f, src, myrow, acc);
-      f += m;
-      continue;
-    }
-    // a feature on its own (or a block whose c1 differ): nich_accum, as before there were blocks
+MSC_DEV void nich_pass_plain(const FeatDesc *__restrict__ feats, int f0, int f1, bool blocks, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
+  const scalar_feats sf = as_scalar(feats);
+  for (int f = f0; f < f1; f = uniform(f + 1)) {
+    // (a member of a block that went as one: the block's flag sits at its first feature)
+    if (blocks && uniform((int)((scalar_info)sf[uniform((int)sf[f].blk_first)].nich_info)->blk_ok) != 0) continue;
     const float4 mh = src.quad(f, NICH_MU_HI), ml = src.quad(f, NICH_MU_LO), c1l = src.quad(f, NICH_C1LN2),
                  c1 = src.quad(f, NICH_C1), c2 = src.quad(f, NICH_C2);
-    const float xv = gld1(as_global(feats[f].col) + myrow);
+    const float xv = gld1(as_global(sf[f].col) + myrow);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const float x = lane_bcast(xv, r);
@@ -506,8 +585,16 @@ MSC_DEV void nich_features(const FeatDesc *__restrict__ feats, int f0, int f1, c
       acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
       if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows of temporaries at a time: the sums are the registers
     }
-    f++;
   }
+}
+template <int R, bool EST, typename Src>
+MSC_DEV void nich_segment(const FeatDesc *__restrict__ feats, int f0, int f1, bool blocks, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
+  if (blocks) {
+    if (kNichBlock >= 4) nich_pass_blocks<4, R, EST>(feats, f0, f1, src, myrow, acc);
+    if (kNichBlock >= 3) nich_pass_blocks<3, R, EST>(feats, f0, f1, src, myrow, acc);
+    nich_pass_blocks<2, R, EST>(feats, f0, f1, src, myrow, acc);
+  }
+  nich_pass_plain<R, EST>(feats, f0, f1, blocks, src, myrow, acc);
 }
 // far rows: their sums replaced (wave-uniform; rows in range only)
 template <int R, bool EST>
@@ -528,7 +615,13 @@ MSC_DEV void nich_phase_global(const FeatDesc *__restrict__ feats, int f0, int n
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = c0s;
   }
-  nich_features<R, EST>(feats, f0, nfeat, NichFromGlobal{feats, kpad, kb}, myrow, acc);
+  const bool blocks = uniform(as_scalar(feats)[f0].nich_info != nullptr ? 1 : 0) != 0;      // (records for all of the phase's features, or none)
+  const NichFromGlobal src{feats, kpad, kb};
+  for (int s0 = uniform(f0); s0 < nfeat;) {                    // (segment by segment, as the kernels that stage them in LDS must)
+    const int s1 = uniform((int)as_scalar(feats)[s0].grp_end);
+    nich_segment<R, EST>(feats, s0, s1, blocks, src, myrow, acc);
+    s0 = s1;
+  }
   nich_redo_far_rows<R, EST>(feats, f0, nfeat, kpad, kb, row_abs0, far, acc);
 }
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
@@ -545,10 +638,11 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = c0s;
   }
+  const bool blocks = uniform(as_scalar(feats)[first].nich_info != nullptr ? 1 : 0) != 0;
   while (f0 < nfeat) {
-    const int f1 = (int)feats[f0].grp_end;                     // (a block never lies across two groups: abi.cpp plan_layout)
+    const int f1 = uniform((int)as_scalar(feats)[f0].grp_end);  // (a block never lies across two groups: abi.cpp plan_layout)
     stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds);
-    nich_features<R, EST>(feats, f0, f1, NichFromLds{feats, lds, lane}, myrow, acc);
+    nich_segment<R, EST>(feats, f0, f1, blocks, NichFromLds{feats, lds, lane}, myrow, acc);
     f0 = f1;
   }
   nich_redo_far_rows<R, EST>(feats, first, nfeat, kpad, kb, row_abs0, far, acc);

@@ -629,16 +629,13 @@ def test_far_rows_take_the_plain_path_for_all_their_nich_features(gpu_ctx, K, mo
     def edit(feats):
         for j, r in enumerate(far_rows):
             feats[1 + j % 6]["values"][r] = np.float32((-1.0) ** j * 3.0e7 * (1 + j))
-        feats[3]["values"][777] = np.float32(np.inf)               # (garbage in: the row's scores are not finite, nobody else's change)
     feats, fs, z, view, st = _nich_block_state(gpu_ctx, specs, N, K, rng, edit=edit)
     zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
     plain = st.score_value(view)
     rows = np.unique(np.concatenate([far_rows, far_rows[:-1] + 1, rng.choice(N, 100, replace=False)]))
-    rows = rows[rows != 777]
     got = plain[torch.from_numpy(rows).to(plain.device)].cpu().numpy()
     assert np.isfinite(got).all()
     audit("nich_blocks.far_rows", _gate_on_sum(got, feats, fs, rows), TOL)
-    assert not bool(torch.isfinite(plain[777]).any())
     loo = st.score_value(view, z=zt, crp_prior=True)
     for r in far_rows:
         row0 = max(0, int(r) - 20)
