@@ -587,8 +587,13 @@ def extra_c3(a, torch, common_amd, ctx):
     return r
 
 
+MFMA_F32_PEAK_TF = 157.3     # dense f32 matrix peak (the roof BASELINE.md names for C4)
+
+
 def extra_c4(a, torch, common_amd, ctx):
-    """BASELINE configs[3]: NIW dim 32, N=256k, K=128; scoring pass on the f64 matrix pipe (the 1e-6 path)."""
+    """BASELINE configs[3]: NIW dim 32, N=256k, K=128; the scoring pass on the f64 matrix pipe (the default: the 1e-6
+    path) and on the f32 matrix pipe (MSC_SCORE_NIW_F32, the roof BASELINE.md names; ~2e-5 of the twin), each with the
+    fraction on SURVEY 8d's flop count and on the flops the kernel EXECUTES (it skips the zero triangle of the factor)."""
     from tools.bench_configs import make_columns
     N, K, d = 262_144, 128, 32
     spec = [(common_amd.NIW, d)]
@@ -598,15 +603,38 @@ def extra_c4(a, torch, common_amd, ctx):
     st.accumulate(view, z)
     out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
     steps = max(3, min(a.steps, 20))
-    wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 10)
     flops = 2.0 * d * d * N * K                 # SURVEY 8d's count (the full d x d contraction per pair)
-    tf = flops / (avg * 1e-3) / 1e12
-    return {"workload": "C4 NIW dim=32, N=256k, K=128, scoring pass (f64 MFMA)", "ms": avg, "ms_min": mn,
-            "evals_per_s": float(N) * K / (avg * 1e-3), "kernel": "k_score_niw64",
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": tf / MFMA_F64_PEAK_TF, "algorithmic_flops_per_launch": flops,
-                         "note": "flops counted as SURVEY 8d does (2 d^2 per pair); the kernel skips the zero "
-                                 "upper-right block of the triangular factor, so the matrix pipe executes fewer"}}
+    nb = (d + 15) // 16
+    executed = flops * (nb + 1) / (2.0 * nb)    # blocks on or below the diagonal of the triangular factor (3/4 at dim 32)
+
+    def leg(f32, peak, kernel):
+        wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out, niw_f32=f32), steps, 10)
+        tf = flops / (avg * 1e-3) / 1e12
+        busy, src = pmc_entry(kernel, "SQ_VALU_MFMA_BUSY_CYCLES")
+        waves_cycles, _ = pmc_entry(kernel, "SQ_BUSY_CYCLES")
+        r = {"ms": avg, "ms_min": mn, "kernel": kernel, "tflops_survey_count": tf, "peak": peak, "unit": "TFLOP/s",
+             "frac_survey_count": tf / peak,
+             "frac_executed": (executed if not f32 else flops) / (avg * 1e-3) / 1e12 / peak,
+             "flops_executed_per_launch": executed if not f32 else flops}
+        if busy is not None and waves_cycles:
+            r["mfma_busy"] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "source": src,
+                              "note": "committed PMC pass of this kernel; busy cycles / (4 SIMDs x 256 CUs x kernel cycles) in DESIGN.md section 5"}
+        return r
+    f64 = leg(False, MFMA_F64_PEAK_TF, "k_score_niw64")
+    ref = out.clone()
+    f32 = leg(True, MFMA_F32_PEAK_TF, "k_score_niw")
+    # what the f32 pipe costs in accuracy, against the f64 kernel's own output on the same state (the f64 kernel is the
+    # one held to the twin at 1e-6: tests/test_gpu_score.py)
+    diff = (out - ref).abs() / ref.abs().clamp_min(1.0)
+    f32["max_rel_err_vs_f64_kernel"] = float(diff.max().item())
+    return {"workload": "C4 NIW dim=32, N=256k, K=128, scoring pass", "ms": f64["ms"], "ms_min": f64["ms_min"],
+            "evals_per_s": float(N) * K / (f64["ms"] * 1e-3), "kernel": "k_score_niw64",
+            "roofline": {"bound": "mfma", "achieved": f64["tflops_survey_count"], "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": f64["frac_survey_count"], "frac_executed": f64["frac_executed"],
+                         "algorithmic_flops_per_launch": flops,
+                         "note": "frac counts flops as SURVEY 8d does (2 d^2 per pair); the kernel skips the zero "
+                                 "upper-right block of the triangular factor and executes 3/4 of them: frac_executed"},
+            "f64": f64, "f32": f32}
 
 
 def extra_c5(a, torch, common_amd, ctx):

@@ -828,7 +828,9 @@ static int plan_groups(msc_state *st) {
   std::vector<FeatDesc> &t = st->desc_tile_host;
   t.clear();
   for (FeatDesc &d : st->desc_host) d.blk_first = d.blk_end = 0, d.nich_info = nullptr;
-  for (const FeatDesc &d : st->desc_host) if (!nich_tail(d)) t.push_back(d);
+  std::vector<uint32_t> t_src;                              // t[i] is the caller's feature t_src[i]
+  for (uint32_t i = 0; i < st->nfeat; i++)
+    if (!nich_tail(st->desc_host[i])) t.push_back(st->desc_host[i]), t_src.push_back(i);
   st->tile_split = (uint32_t)t.size();
   // The second phase, in BLOCKS (family_math.hpp "nich BLOCKS"): the plain nich features ordered by their nu prior
   // (stable: the caller's order among equals), runs of an equal nu cut into blocks of at most kNichBlock, as even as they
@@ -853,6 +855,7 @@ static int plan_groups(msc_state *st) {
           d.blk_end = d.blk_first + (uint32_t)len;
           d.nich_info = st->nich_info + tail[at + j];
           t.push_back(d);
+          t_src.push_back(tail[at + j]);
         }
         st->nich_blocks_any |= len >= 2;
         at += len;
@@ -968,6 +971,29 @@ static int plan_groups(msc_state *st) {
       tf.push_back(t[i]);
       extra_f.push_back(extra[i]);
     }
+  // the accumulate pass's list: a fused feature reads z and its byte column once for all its members (their additive
+  // tables: fuse_acc); everything else as the caller gave it.  (Histograms of 2 m K counters: while they fit LDS.)
+  {
+    std::vector<FeatDesc> &ta = st->desc_acc_host;
+    ta.clear();
+    std::vector<bool> covered(n, false);
+    static const bool no_acc_fuse = std::getenv("MSC_NO_ACC_FUSE") != nullptr;       // (A/B knob)
+    for (size_t q = 0; q < quads.size() && !no_acc_fuse; q++) {
+      const Fused &fq = quads[q];
+      if ((size_t)st->K * 8u * fq.m * 4u > 64u * 1024u) continue;
+      const std::vector<uint32_t> &mem = members[fq.radix - 2];
+      FeatDesc d = tf[q];
+      for (uint32_t j = 0; j < 4; j++) d.fuse_acc[j] = nullptr;
+      for (uint32_t j = 0; j < fq.m; j++) {
+        const uint32_t src = t_src[mem[fq.first + j]];
+        d.fuse_acc[j] = st->desc_host[src].acc_i64;
+        covered[src] = true;
+      }
+      ta.push_back(d);
+    }
+    for (uint32_t i = 0; i < n; i++)
+      if (!covered[i]) ta.push_back(st->desc_host[i]);
+  }
   const std::vector<Fused> &fused = quads;
   st->fuse_any = !fused.empty();
   st->fuse_nfeat = (uint32_t)tf.size();
@@ -992,6 +1018,8 @@ static int upload_desc(msc_state *st) {
   MSC_HIP(hipMemcpyAsync(st->desc_tile_dev, st->desc_tile_host.data(), sizeof(FeatDesc) * st->nfeat,
                          hipMemcpyHostToDevice, st->ctx->stream));
   MSC_HIP(hipMemcpyAsync(st->desc_fuse_dev, st->desc_fuse_host.data(), sizeof(FeatDesc) * st->fuse_nfeat,
+                         hipMemcpyHostToDevice, st->ctx->stream));
+  MSC_HIP(hipMemcpyAsync(st->desc_acc_dev, st->desc_acc_host.data(), sizeof(FeatDesc) * st->desc_acc_host.size(),
                          hipMemcpyHostToDevice, st->ctx->stream));
   MSC_HIP(hipStreamSynchronize(st->ctx->stream));     // (the tile copy is rebuilt by the next call)
   return MSC_OK;
@@ -1046,6 +1074,7 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_fuse_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->nich_info, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->desc_acc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
   for (uint32_t f = 0; f < nfeatures; f++) {
@@ -1866,7 +1895,7 @@ static int accumulate_impl(msc_state *st, const msc_dataview *view, const uint32
   for (auto &h : st->feats) h.additive_valid = true;
   st->cnt_additive_valid = true;
   if (nrows > 0) {
-    const int rc = launch_accumulate(s, st->ctx->num_cus, st->desc_dev, st->desc_host.data(), (int)st->nfeat,
+    const int rc = launch_accumulate(s, st->ctx->num_cus, st->desc_acc_dev, st->desc_acc_host.data(), (int)st->desc_acc_host.size(),
                                      st->K, st->kpad, row0, nrows, z_dev,
                                      (flags & MSC_ACC_SUBTRACT) ? -1 : 1, st->red_i64);
     if (rc == -2) return fail(MSC_EUNSUPPORTED, "accumulate tables for %u groups exceed LDS", st->K);

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
 template <bool LOO, bool CRP, int Q, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, uint64_t nslots,
+                                                      uint64_t nrows, uint64_t nslots, uint32_t spread, uint64_t per,
                                                       const int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
                                                       const float *__restrict__ crp,
@@ -556,10 +556,17 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   const bool tile_full = (kt + 1) * kGroupTile <= K;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
   // everything the wave's rows need, fetched at once: lane i holds row r = i % Q of visit k = i / Q
-  const uint32_t nvis = (uint32_t)(((nrows + Q - 1) / Q + nslots - 1) / nslots);      // <= 64 / Q (launcher)
+  // SPREAD (an experiment knob, MSC_NICH1_SPREAD = S regions; 0: off): block L of the launch order is block
+  // (L % S) * per + L / S of the matrix -- the waves resident at one moment write S windows `per` blocks apart instead of
+  // one dense window (profiles/r04_spread_store.txt: does the write stream's rate still depend on where the driver put
+  // the pages when the window is spread over the whole buffer?)
+  const uint64_t nblocks = spread ? (uint64_t)spread * per : (nrows + Q - 1) / Q;
+  auto block_of = [&](uint64_t L) -> uint64_t { return spread ? (L % spread) * per + L / spread : L; };
+  const uint32_t nvis = (uint32_t)((nblocks + nslots - 1) / nslots);      // <= 64 / Q (launcher)
   const uint32_t vk = (uint32_t)lane / Q, vr = (uint32_t)lane % Q;
-  const uint64_t myrow = (slot + (uint64_t)vk * nslots) * Q + vr;
-  const bool mine = vk < nvis && myrow < nrows;
+  const uint64_t myblock = slot + (uint64_t)vk * nslots;
+  const uint64_t myrow = block_of(myblock) * Q + vr;
+  const bool mine = vk < nvis && myblock < nblocks && myrow < nrows;
   const float xv = mine ? xcol[myrow] : 0.0f;
   const unsigned long long mbits_all =
       __builtin_amdgcn_ballot_w64(fd.mask != nullptr && mine && fd.mask[row0 + myrow] != 0);
@@ -575,8 +582,10 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
     }
   }
   for (uint32_t k = 0; k < nvis; k++) {
-    const uint64_t rb = (slot + (uint64_t)k * nslots) * Q;
-    if (rb >= nrows) break;
+    const uint64_t L = slot + (uint64_t)k * nslots;
+    if (L >= nblocks) break;
+    const uint64_t rb = block_of(L) * Q;
+    if (rb >= nrows) continue;
     const int nr = (int)((nrows - rb) < (uint64_t)Q ? (nrows - rb) : (uint64_t)Q);
     const int l0 = (int)(k * Q);                              // first lane of this visit's values
     const unsigned long long mbits = (mbits_all >> l0) & ((1ull << Q) - 1ull);
@@ -1399,7 +1408,11 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     // (profiles/r01_nich1_variants.txt); abi.cpp run_score times the shapes of kNich1Shapes at the first large
     // pass of a context and passes the winner's index here (0 = the default).
     const Nich1Shape sh = kNich1Shapes[nich1_shape >= 0 && nich1_shape < kNich1NumShapes ? nich1_shape : 0];
-    const uint64_t nvisits_all = (nrows + sh.q - 1) / sh.q;
+    const char *spread_env = std::getenv("MSC_NICH1_SPREAD");             // (read per launch: the experiment changes it between passes)
+    const uint32_t spread = spread_env ? (uint32_t)std::atoi(spread_env) : 0u;
+    const uint64_t nblocks_real = (nrows + sh.q - 1) / sh.q;
+    const uint64_t per = spread ? (nblocks_real + spread - 1) / spread : 0;
+    const uint64_t nvisits_all = spread ? (uint64_t)spread * per : nblocks_real;
     const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
     uint64_t visits = sh.visits;
     while ((nvisits_all + visits - 1) / visits > max_slots && visits * sh.q < 64) visits++;
@@ -1407,7 +1420,7 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
     hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), dim3((unsigned)gx), dim3(256), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, nslots, z, own, crp, out, ld);
+                       feats_dev, K, kpad, row0, nrows, nslots, spread, per, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
   for (uint32_t sl = 0; sl < nslices; sl++) {
     const uint32_t c_lo = sl * slice;
     const uint32_t c_n = sliced ? (fd.dim - c_lo < slice ? fd.dim - c_lo : slice) : 0;
-    const AccShape sh = acc_shape(fd.family, c_n);
+    const bool fused = fd.fuse_n >= 2;                             // (bb members: heads | tails of member j at rows 2 j, 2 j + 1)
+    const AccShape sh = fused ? AccShape{2u * fd.fuse_n, 0u, 0u} : acc_shape(fd.family, c_n);
     double *f64 = reinterpret_cast<double *>(smem);
     unsigned long long *u64 = reinterpret_cast<unsigned long long *>(f64 + (size_t)K * sh.nf64);
     uint32_t *u32 = reinterpret_cast<uint32_t *>(u64 + (size_t)K * sh.nu64);
@@ -148,6 +149,15 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
         for (int j = 0; j < U; j++) {
           if ((uint32_t)g[j] >= K) continue;
           const uint32_t gg = (uint32_t)g[j], raw = w[j];
+          if (fused) {                                           // the byte's digits: member j's value (2 = masked: not counted)
+            uint32_t rest = raw;
+            for (uint32_t m = 0; m < fd.fuse_n; m++) {
+              const uint32_t d = fd.fuse_radix == 2 ? (rest & 1u) : rest % 3u;
+              rest = fd.fuse_radix == 2 ? rest >> 1 : rest / 3u;
+              if (d < 2u) atomicAdd(&u32[(size_t)(2u * m + (d != 0 ? 0u : 1u)) * K + gg], 1u);
+            }
+            continue;
+          }
           switch (fd.family) {
             case MSC_BBNC:
             case MSC_BB: atomicAdd(&u32[(raw != 0 ? 0 : K) + gg], 1u); break;
@@ -229,8 +239,8 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
       if (!u32[i]) continue;
       uint32_t dst_row = r;
       if (fd.family == MSC_DD) dst_row = c_lo + r;
-      atomicAdd(reinterpret_cast<unsigned long long *>(&fd.acc_i64[(size_t)dst_row * kpad + k]),
-                (unsigned long long)(sgn * (long long)u32[i]));
+      long long *dst = fused ? fd.fuse_acc[r >> 1] + (size_t)(r & 1u) * kpad + k : &fd.acc_i64[(size_t)dst_row * kpad + k];
+      atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)(sgn * (long long)u32[i]));
     }
     for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += nt) {
       const uint32_t r = i / K, k = i - r * K;
@@ -736,7 +746,8 @@ size_t accumulate_lds_bytes(const FeatDesc *feats_host, int nfeat, uint32_t K, u
     const uint32_t cap = feats_host[f].family == MSC_DM ? (dd_slice > 1 ? dd_slice / 2 : 1) : dd_slice;
     const uint32_t sl = feats_host[f].family == MSC_DD || feats_host[f].family == MSC_DM
                             ? (feats_host[f].dim < cap ? feats_host[f].dim : cap) : 0;
-    const AccShape sh = acc_shape(feats_host[f].family, sl);
+    AccShape sh = acc_shape(feats_host[f].family, sl);
+    if (feats_host[f].fuse_n >= 2) sh = AccShape{2u * feats_host[f].fuse_n, 0u, 0u};      // a fused bb feature: its members' counters
     const size_t b = (size_t)K * (8u * sh.nf64 + 8u * sh.nu64 + 4u * sh.nu32);
     if (b > need) need = b;
   }

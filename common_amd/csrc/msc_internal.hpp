@@ -159,6 +159,9 @@ struct FeatDesc {
   // second phase.
   uint32_t blk_first, blk_end;
   NichPlanInfo *nich_info;
+  // the accumulate pass's copy of a fused bb feature (abi.cpp plan_groups, desc_acc): the members' additive tables, in the
+  // members' order -- one read of the byte column and of z feeds all of them (k_accumulate)
+  long long *fuse_acc[4];
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -383,6 +386,10 @@ struct msc_state {
   bool fuse_any = false;
   float *fuse_tab = nullptr;          // the fused tables, 32 rows of kpad floats a fused feature (16 or 27 used)
   size_t fuse_tab_floats = 0;
+  // what msc_accumulate walks: the fused bb features first (each feeds its members' tables from one byte column), then
+  // every feature no fused one covers, as the caller gave it (masks and all)
+  msc::FeatDesc *desc_acc_dev = nullptr;
+  std::vector<msc::FeatDesc> desc_acc_host;
   msc::NichPlanInfo *nich_info = nullptr;   // [nfeat]: per feature of the plans' second phase (FeatDesc::nich_info)
   bool nich_blocks_any = false;       // the plan has a nich block of two or more features
   const msc_dataview *bound_view = nullptr;
