@@ -406,7 +406,9 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         out = ctx.alloc((N, K), torch.float32)
         rates, kept = ctx.alloc_stats()
         placement = {"allocator": "msc_device_alloc (library default)", "candidates_fill_GBps": [round(r, 1) for r in rates],
-                     "kept": kept}
+                     "kept": kept,
+                     # (include/microscopes_hip.h: non-temporal stores into a buffer probed at >= 6.65 TB/s, plain ones otherwise)
+                     "stores": "non-temporal" if rates and rates[kept] >= 6650.0 else "plain"}
     tuned = None
     if a.tune:
         tuned = st.score_tune(view, out)                     # explicit and synchronous; never inside msc_score_value
@@ -466,7 +468,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         for _ in range(50):
             st.score_value(view, out=tbuf)
         _, c_ms = region(tbuf, max(200, min(a.steps, 500)))
-        caller = {"allocator": "torch.empty", "kernel_avg_ms": c_ms, "achieved": alg_bytes / (c_ms * 1e-3) / 1e9,
+        caller = {"allocator": "torch.empty", "stores": "plain", "kernel_avg_ms": c_ms, "achieved": alg_bytes / (c_ms * 1e-3) / 1e9,
                   "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del tbuf
     line = {

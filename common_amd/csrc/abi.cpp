@@ -341,6 +341,7 @@ static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates
   if (bufs[best].vmm) ctx->vmm.push_back(bufs[best].v);
   ctx->last_alloc_rates = rate;
   ctx->last_alloc_chosen = (uint32_t)best;
+  ctx->placed.push_back(msc_context::Placed{bufs[best].p, nbytes, max_candidates > 1 && rate[best] >= kNtFastGbps});
   if (rates_gbps)
     for (uint32_t i = 0; i < max_candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
   if (chosen) *chosen = (uint32_t)best;
@@ -403,6 +404,11 @@ extern "C" int msc_device_free(msc_context *ctx, void *dev) {
   if (!dev) return MSC_OK;
   MSC_HIP(hipSetDevice(ctx->device));
   MSC_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ctx->placed.size(); i++)
+    if (ctx->placed[i].base == dev) {
+      ctx->placed.erase(ctx->placed.begin() + i);
+      break;
+    }
   for (size_t i = 0; i < ctx->vmm.size(); i++)
     if (ctx->vmm[i].va == dev) {                          // a probed buffer mapped from chunks
       vmm_free(ctx->vmm[i]);
@@ -1695,15 +1701,31 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
 // buffer, else for this size, else the default.  (profiles/r02_placement_study.txt: the shape moves the rate by <= 4 %
 // either way; what decides between 5.6 and 7.0 TB/s is where the driver placed the buffer.)
 static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, uint32_t K) {
+  // which stores the pass uses (bit 8 of the launch code: plain): what msc_score_tune found for this very buffer; else
+  // non-temporal into a buffer this context placed and probed fast, plain into everything else (msc_context::placed);
+  // MSC_NICH1_STORES = nt | plain overrides
+  static const int forced_stores = [] {
+    const char *e = std::getenv("MSC_NICH1_STORES");
+    return !e ? -1 : (e[0] == 'p' ? 1 : 0);
+  }();
+  int plain = 1;
+  for (const msc_context::Placed &p : ctx->placed)
+    if (out >= p.base && static_cast<const char *>(out) < static_cast<const char *>(p.base) + p.size) plain = p.nt_fast ? 0 : 1;
   static const int fixed = [] { const char *e = std::getenv("MSC_NICH1_SHAPE"); return e ? std::atoi(e) : -1; }();
-  if (fixed >= 0 && fixed < kNich1NumShapes) return fixed;
-  int by_size = -1;
+  int shape = -1, by_size = -1;
   for (const msc_context::ShapeEntry &e : ctx->nich1_shapes) {
     if (e.nrows != nrows || e.K != K) continue;
-    if (e.out == out) return e.shape;
+    if (e.out == out) {
+      shape = e.shape;
+      if (e.plain_stores >= 0) plain = e.plain_stores;
+      break;
+    }
     if (by_size < 0) by_size = e.shape;
   }
-  return by_size < 0 ? 0 : by_size;
+  if (shape < 0) shape = by_size < 0 ? 0 : by_size;
+  if (fixed >= 0 && fixed < kNich1NumShapes) shape = fixed;
+  if (forced_stores >= 0) plain = forced_stores;
+  return shape | (plain ? 0x100 : 0);
 }
 
 static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t *z_dev, bool crp,
@@ -1828,6 +1850,23 @@ extern "C" int msc_score_tune(msc_state *st, const msc_dataview *view, const uin
       shape = cand;
     }
   }
+  // ... and, with the winning shape, the stores: non-temporal or plain (which is faster depends on where the buffer lies)
+  int plain_stores = 0;
+  if (rc == MSC_OK && shape >= 0) {
+    float ms_kind[2] = {0.f, 0.f};
+    for (int kind = 0; kind < 2 && rc == MSC_OK; kind++) {
+      const int code = shape | (kind ? 0x100 : 0);
+      if (launch(code)) { rc = fail(MSC_EHIP, "score kernel launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+      hipError_t e = hipEventRecord(e0, s);
+      for (int r = 0; r < 6 && e == hipSuccess; r++) (void)launch(code);
+      if (e == hipSuccess) e = hipEventRecord(e1, s);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms_kind[kind], e0, e1);
+      if (e != hipSuccess) rc = fail(MSC_EHIP, "timing failed: %s", hipGetErrorString(e));
+    }
+    plain_stores = ms_kind[1] < ms_kind[0] ? 1 : 0;
+    best = ms_kind[plain_stores];
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   MSC_TRY(rc);
@@ -1835,7 +1874,7 @@ extern "C" int msc_score_tune(msc_state *st, const msc_dataview *view, const uin
   for (size_t i = 0; i < memo.size();)                      // one entry per (buffer, size); the newest size entry leads
     if (memo[i].out == out_dev && memo[i].nrows == nrows && memo[i].K == st->K) memo.erase(memo.begin() + i);
     else i++;
-  memo.insert(memo.begin(), msc_context::ShapeEntry{out_dev, nrows, st->K, shape});
+  memo.insert(memo.begin(), msc_context::ShapeEntry{out_dev, nrows, st->K, shape, plain_stores});
   if (memo.size() > 16) memo.pop_back();
   if (shape_out) *shape_out = shape;
   if (ms_out) *ms_out = best / 6.f;

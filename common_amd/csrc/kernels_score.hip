@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
 template <bool LOO, bool CRP, int Q, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, uint64_t nslots, uint32_t spread, uint64_t per,
+                                                      uint64_t nrows, uint64_t nslots, uint32_t spread, uint64_t per, int flavour,
                                                       const int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
                                                       const float *__restrict__ crp,
@@ -608,8 +608,20 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
         }
         const f32x4 v = {s.x, s.y, s.z, s.w};
         f32x4 *p = reinterpret_cast<f32x4 *>(out + (rb + r) * ld + kb);
-        if (NT) __builtin_nontemporal_store(v, p);
-        else *p = v;
+        if (flavour == 0) {
+          if (NT) __builtin_nontemporal_store(v, p);
+          else *p = v;
+        } else {
+          // (experiment, MSC_NICH1_STORE: the store's cache policy -- tools/scans/spread_store.py)
+          typedef __attribute__((address_space(1))) f32x4 *gp;
+          const gp q = (gp)p;
+          if (flavour == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(q), "v"(v) : "memory");
+          else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+          else if (flavour == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+          else if (flavour == 4) asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(q), "v"(v) : "memory");
+          else if (flavour == 5) asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1" ::"v"(q), "v"(v) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(q), "v"(v) : "memory");
+        }
       }
     } else {
       for (int r = 0; r < nr; r++) {
@@ -1407,9 +1419,14 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     // Which (Q, visits) suits the HBM write stream depends on the box and on where the score buffer landed
     // (profiles/r01_nich1_variants.txt); abi.cpp run_score times the shapes of kNich1Shapes at the first large
     // pass of a context and passes the winner's index here (0 = the default).
+    // (nich1_shape: the shape's index; bit 8: plain stores instead of non-temporal ones -- abi.cpp nich1_shape_for)
+    const bool plain_stores = (nich1_shape & 0x100) != 0;
+    nich1_shape &= 0xff;
     const Nich1Shape sh = kNich1Shapes[nich1_shape >= 0 && nich1_shape < kNich1NumShapes ? nich1_shape : 0];
-    const char *spread_env = std::getenv("MSC_NICH1_SPREAD");             // (read per launch: the experiment changes it between passes)
+    const char *spread_env = std::getenv("MSC_NICH1_SPREAD");             // (read per launch: the experiments change them between passes)
     const uint32_t spread = spread_env ? (uint32_t)std::atoi(spread_env) : 0u;
+    const char *store_env = std::getenv("MSC_NICH1_STORE");
+    const int flavour = store_env ? std::atoi(store_env) : 0;
     const uint64_t nblocks_real = (nrows + sh.q - 1) / sh.q;
     const uint64_t per = spread ? (nblocks_real + spread - 1) / spread : 0;
     const uint64_t nvisits_all = spread ? (uint64_t)spread * per : nblocks_real;
@@ -1419,8 +1436,12 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     uint64_t nslots = (nvisits_all + visits - 1) / visits;
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
-    hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), dim3((unsigned)gx), dim3(256), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, nslots, spread, per, z, own, crp, out, ld);
+    if (plain_stores)
+      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, false>), dim3((unsigned)gx), dim3(256), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, nslots, spread, per, flavour, z, own, crp, out, ld);
+    else
+      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), dim3((unsigned)gx), dim3(256), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, nslots, spread, per, flavour, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)

@@ -20,6 +20,7 @@ constexpr int kGroupTile = 256;    // groups per k-tile: lane <-> 4 consecutive 
 constexpr unsigned kMaxDDDim = 128;
 constexpr int kGrpRows = 128;   // table rows the LDS slot of the tile kernels holds (128 KiB): one feature group
 constexpr unsigned kGpMaxTable = 1024;   // gp counts below this are exact table entries
+constexpr float kNtFastGbps = 6650.f;    // probe fill rate from which a placed buffer takes non-temporal stores (msc_context::placed)
 
 // ---- error plumbing --------------------------------------------------------
 void set_error(const char *fmt, ...);
@@ -284,8 +285,14 @@ struct msc_context {
   int num_cus = 256;
   // k_score_nich1 launch shape (index into kNich1Shapes) per output buffer: which shape suits the write stream
   // depends on where the buffer lies (abi.cpp run_score); most recent first, at most 16 buffers remembered
-  struct ShapeEntry { const void *out; uint64_t nrows; uint32_t K; int shape; };
+  struct ShapeEntry { const void *out; uint64_t nrows; uint32_t K; int shape; int plain_stores; };   // plain_stores: -1 = not timed
   std::vector<ShapeEntry> nich1_shapes;
+  // buffers this context placed (msc_device_alloc >= 64 MiB, msc_device_alloc_probed) and how their probe went: a buffer
+  // that took the probe's NON-TEMPORAL fill at kNtFastGbps or better takes the single-nich pass's non-temporal stores at
+  // 0.85-0.88 of the HBM roof; every other buffer (the probe's lower bands, a caller's own) is written with plain stores --
+  // 0.78-0.83 whatever the placement, where non-temporal ones run 0.69-0.76 (profiles/r04_store_policy.txt)
+  struct Placed { const void *base; size_t size; bool nt_fast; };
+  std::vector<Placed> placed;
   // a stream of the library's own on which sweep steps are recorded (the caller's may be the null stream, which
   // cannot capture); nothing ever executes on it
   hipStream_t record_stream = nullptr;

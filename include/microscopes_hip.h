@@ -107,6 +107,11 @@ int msc_context_synchronize(msc_context *ctx);
  * fast stretch: nothing to find).  SYNCHRONOUS, about 1 ms per candidate and GB; MSC_ALLOC_CANDIDATES /
  * MSC_ALLOC_ACCEPT_GBPS / MSC_ALLOC_FLAT_AFTER in the environment change the bounds, MSC_ALLOC_CANDIDATES=0 is plain
  * hipMalloc.
+ * What the probe finds also decides how the single-nich scoring pass WRITES such a buffer: non-temporal stores into a
+ * buffer that took the probe at 6.65 TB/s or better (the pass then runs at 0.85-0.88 of the HBM roof), plain stores into
+ * every other buffer -- a placed one from the probe's lower bands, or one the caller brought -- where they run 0.78-0.83
+ * whatever the placement and non-temporal ones 0.69-0.76 (profiles/r04_store_policy.txt; MSC_NICH1_STORES = nt | plain
+ * overrides, msc_score_tune times both for a given buffer).
  * msc_device_alloc_probed is the same with the bounds given by the caller: all `candidates` are probed and the fastest
  * is returned; rates_gbps (nullable, `candidates` floats) receives every candidate's fill rate, *chosen (nullable) the
  * index kept.  msc_device_alloc_stats reports the same for the context's most recent placed allocation.

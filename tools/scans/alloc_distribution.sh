@@ -6,5 +6,5 @@ for i in $(seq 1 $N); do
 import json,sys
 r=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 ro=r['roofline']; sm=r['config']['score_matrix']
-print(json.dumps({'run': $i, 'frac': round(ro['frac'],4), 'frac_caller_alloc': round(ro['frac_caller_alloc'],4), 'kernel_avg_ms': round(ro['kernel_avg_ms'],5), 'candidates_fill_GBps': sm.get('candidates_fill_GBps'), 'kept': sm.get('kept')}))"
+print(json.dumps({'run': $i, 'frac': round(ro['frac'],4), 'frac_caller_alloc': round(ro['frac_caller_alloc'],4), 'kernel_avg_ms': round(ro['kernel_avg_ms'],5), 'stores': sm.get('stores'), 'candidates_fill_GBps': sm.get('candidates_fill_GBps'), 'kept': sm.get('kept')}))"
 done

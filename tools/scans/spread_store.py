@@ -20,6 +20,10 @@ view = common_amd.DataView.from_tensors(ctx, [x])
 st = common_amd.State(ctx, [(common_amd.NICH, 0)], K)
 st.accumulate(view, z)
 bufs = [torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device) for _ in range(8)]
+if "--lib-alloc" in sys.argv:                             # ... and two from the library's placing allocator
+    for _ in range(2):
+        bufs.append(ctx.alloc((N, K), torch.float32))
+        print(json.dumps({"msc_device_alloc": ctx.alloc_stats()}), flush=True)
 alg = 4.0 * N + 4.0 * N * K
 
 
@@ -41,10 +45,15 @@ for _ in range(300):
 os.environ["MSC_NICH1_SPREAD"] = "0"
 st.score_value(view, out=bufs[0])
 ref = bufs[0].clone()
-for S in (0, 4, 16, 64, 256, 1024, 0):
-    os.environ["MSC_NICH1_SPREAD"] = str(S)
+sweep = [("spread", S) for S in (0, 4, 16, 64, 256, 1024, 0)]
+if "--stores" in sys.argv:                                # the store's cache policy instead (MSC_NICH1_STORE)
+    sweep = [("store", f) for f in (0, 1, 6, 2, 0, 1)]
+names = {0: "nt (product)", 1: "plain", 2: "sc1", 3: "sc0 sc1", 4: "nt sc1", 5: "nt sc0 sc1", 6: "sc0"}
+for what, v in sweep:
+    os.environ["MSC_NICH1_SPREAD" if what == "spread" else "MSC_NICH1_STORE"] = str(v)
     rates = [rate(b) for b in bufs]
     st.score_value(view, out=bufs[1])
+    torch.cuda.synchronize()
     same = bool(torch.equal(bufs[1], ref))
-    print(json.dumps({"spread": S, "GBps": [round(r) for r in rates], "frac_of_8TBps": [round(r / 8000, 3) for r in rates],
-                      "same_result": same}), flush=True)
+    print(json.dumps({what: v if what == "spread" else names[v], "GBps": [round(r) for r in rates],
+                      "frac_of_8TBps": [round(r / 8000, 3) for r in rates], "same_result": same}), flush=True)
