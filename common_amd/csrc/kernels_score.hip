@@ -746,9 +746,16 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
 // SUM of the two (C3: ~60 k + ~95 k cycles of 193 k).  Here the workgroup's sixteen waves split the phases between
 // them: waves 0-7 take the lookups of all 128 rows (16 rows each), waves 8-15 the nich features of the same rows --
 // their constants straight from the tables in L2, no LDS, so nothing ties them to the staging of the lookup groups
-// (the lookup waves synchronise among themselves: WaveSubsetBarrier) -- and at the end of a chunk wave 8 + p hands its
-// sums to wave p through the (then idle) table slot, the one place where the whole workgroup meets.  (prior + lookups) + (nich features): the sum score_tile<SPLIT>
-// forms, so a row gets the same bits from either kernel.
+// (the lookup waves synchronise among themselves: WaveSubsetBarrier).
+// The hand-over (round 4: REVERSED).  With the nich features in blocks (family_math.hpp) the nich half is the shorter one
+// (1.0 ms of C3's pass alone, the lookup half 1.4), so what follows the two sums -- adding them, the prior's high half,
+// the leave-one-out entry, the 16 KiB of stores -- moved to the nich waves: at the end of a chunk lookup wave p parks its
+// sums (prior lo + lookups) in the then idle table slot and goes on to stage the next chunk's first feature group, wave
+// 8 + p adds its own to them -- (prior + lookups) + (nich features): the sum score_tile<SPLIT> forms, so a row gets the
+// same bits from either kernel --, finishes the rows and stores them.  Two workgroup barriers a chunk, as before: the sums
+// are in the slot / every nich wave has read them.  (Before: the nich waves parked THEIR sums and the lookup waves
+// finished; with leave-one-out + prior that cost the lookup waves 0.5 ms of C3's 2.07 -- ~45 spilled reloads in their
+// epilogue, harmless while the nich half was the longer one.)
 // ---------------------------------------------------------------------------
 constexpr int kRoleRows = 16;          // rows per wave pair
 template <bool LOO, bool CRP>
@@ -758,90 +765,90 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
                                                                const float *__restrict__ crp, float *__restrict__ out,
                                                                uint64_t ld) {
   constexpr int R = kRoleRows;
-  __shared__ float4 lds[kGrpRows * 64 + (LOO ? 8 * 64 : 0)];
+  __shared__ float4 lds[kGrpRows * 64];                   // the table slot; between chunks the hand-over
   __shared__ uint32_t lookers_arrived;                    // the lookup waves' own barrier (WaveSubsetBarrier)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool looker = wave < 8;                           // waves 0-7: lookups; 8-15: nich
+  const bool looker = wave < 8;                           // waves 0-7: lookups; 8-15: nich, then the rows' finish
   if (threadIdx.x == 0) lookers_arrived = 0u;
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
   const int pair = wave & 7;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  float4 logcnt = make_float4(0, 0, 0, 0);
+  const uint64_t rows_per_wg = 8 * R;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  float4 *const handover = lds + (size_t)pair * R * 64 + lane;           // the pair's 16 rows of the slot
+  if (looker) {
+    // ---- the lookup waves: prior lo + lookups, parked in the slot ----
+    float4 logcnt = make_float4(0, 0, 0, 0);
+    if (CRP) logcnt = ld4(crp + kb);
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;       // relative to row0
+      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+      float4 acc[R];
+      int single = 0;                                     // lane r: removing row r empties its group
+      if (LOO && CRP && lane < nr) {
+        const int g0 = z[rb + lane];
+        single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
+      }
+      if (CRP) {
+        const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
+        const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+      }
+      score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
+      lbar();                                             // every lookup wave is done reading the slot's tables
+#pragma unroll
+      for (int r = 0; r < R; r++) handover[r * 64] = acc[r];
+      __syncthreads();                                    // (1) the lookup sums are in the slot
+      __syncthreads();                                    // (2) the nich waves have read them: the slot may be staged again
+    }
+    return;
+  }
+  // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over; block by block (score_block.hpp
+  // nich_phase_global: the steps every tile kernel takes); then the rows' finish ----
+  float4 hi = make_float4(0, 0, 0, 0);
   float le0 = 0, le1 = 0;
-  if (CRP && looker) {
-    logcnt = ld4(crp + kb);
+  if (CRP) {
+    hi = ld4(crp + kb);
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
   }
-  const uint64_t rows_per_wg = 8 * R;
-  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;       // relative to row0
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;         // relative to row0
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
-    float4 acc[R];
-    if (!looker) {
-      // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over; block by block
-      // (score_block.hpp nich_phase_global: the steps every tile kernel takes) ----
-      const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      nich_phase_global<R, false>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);
-      __syncthreads();                                    // every lookup wave is done with the slot
-      float4 *mine = lds + (size_t)pair * R * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; r++) mine[r * 64] = acc[r];
-      __syncthreads();                                    // the sums are in the slot
-      continue;
-    }
-    // ---- the lookup waves ----
-    int single = 0;                                       // lane r: removing row r empties its group
-    if (LOO && CRP && lane < nr) {
-      const int g0 = z[rb + lane];
-      single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
-    }
-    if (CRP) {
-      const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
-      const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
-#pragma unroll
-      for (int r = 0; r < R; r++) acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
-    }
-    score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
-    __syncthreads();                                      // every lookup wave is done with the slot
-    __syncthreads();                                      // the nich sums are in it
-    {
-      const float4 *theirs = lds + (size_t)pair * R * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; r++) add4(acc[r], theirs[r * 64]);
-    }
-    // epilogue as in k_score_tile: + hi of the prior, the own group's leave-one-out value through the wave's KiB of LDS
-    float4 *mine = lds + (size_t)kGrpRows * 64 + (size_t)wave * 64;
-    int gz = -1;
+    // what the finish needs of the rows, fetched before the arithmetic (its latency under the nich phase)
+    int gz = -1, single = 0;
     float sloo = 0.f;
-    float4 hi = make_float4(0, 0, 0, 0);
-    if (CRP) {
-      const float *again = crp;
-      asm volatile("" : "+s"(again));
-      hi = ld4(again + kb);
-    }
     if (LOO && lane < nr) {
       gz = z[rb + lane];
       sloo = own[rb + lane];
+      if (CRP) single = gz >= 0 && (uint32_t)gz < K && __builtin_isinf(crp[kpad + gz]) ? 1 : 0;
     }
     if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+    float4 acc[R];
+    const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
+    nich_phase_global<R, false>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);
+    __syncthreads();                                      // (1) the lookup sums are in the slot
+#pragma unroll
+    for (int r = 0; r < R; r++) {                         // (prior lo + lookups) + (nich features)
+      float4 t = handover[r * 64];
+      add4(t, acc[r]);
+      acc[r] = t;
+    }
+    __syncthreads();                                      // (2) read: the lookup waves go on
+    // the rows' finish: + hi of the prior, then the own group's entry becomes the row's leave-one-out value (the lane and
+    // component that hold group g take it: score_block.hpp replace_own)
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
       if (LOO) {
         const int g = lane_bcast(gz, r);
-        if (g >= 0) {                                     // (wave-uniform)
-          mine[lane] = acc[r];
-          if (lane == 0) reinterpret_cast<float *>(mine)[(uint32_t)g % kGroupTile] = lane_bcast(sloo, r);
-          __builtin_amdgcn_wave_barrier();
-          acc[r] = mine[lane];
-        }
+        if (g >= 0) replace_own(acc[r], kb, g, lane_bcast(sloo, r));   // (wave-uniform g; in registers: no LDS left to these waves)
       }
       if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
     }

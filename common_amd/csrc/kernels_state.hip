@@ -239,7 +239,10 @@ __global__ __launch_bounds__(1024) void k_accumulate(const FeatDesc *__restrict_
       if (!u32[i]) continue;
       uint32_t dst_row = r;
       if (fd.family == MSC_DD) dst_row = c_lo + r;
-      long long *dst = fused ? fd.fuse_acc[r >> 1] + (size_t)(r & 1u) * kpad + k : &fd.acc_i64[(size_t)dst_row * kpad + k];
+      // (no run-time index into the descriptor's array: that would move the whole descriptor copy to scratch memory)
+      const uint32_t mem = r >> 1;
+      long long *const mbase = mem == 0 ? fd.fuse_acc[0] : mem == 1 ? fd.fuse_acc[1] : mem == 2 ? fd.fuse_acc[2] : fd.fuse_acc[3];
+      long long *dst = fused ? mbase + (size_t)(r & 1u) * kpad + k : &fd.acc_i64[(size_t)dst_row * kpad + k];
       atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)(sgn * (long long)u32[i]));
     }
     for (uint32_t i = threadIdx.x; i < K * sh.nu64; i += nt) {

@@ -1043,6 +1043,11 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // prior included) into `tail`, 64 TAILP floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
 // nich sums are read (the region is the wave's own until every lookup wave has passed the next chunk's first barrier)
 // and draws over tile + tail.  An instantiation of its own: the K <= 256 kernel keeps its registers.
+// TAILP == 0 (K <= 256), round 4: the hand-over REVERSED as in k_score_tile_roles -- the lookup waves park prior + lookups
+// in the slot and go on to the next chunk, the nich waves (the shorter half since the nich features go in blocks) add
+// their sums, put the leave-one-out value in place and DRAW.  TAILP > 0 keeps the first arrangement (the lookup waves
+// draw: the tail's rows travel through their pair's region of the slot, which a lookup wave that runs ahead would
+// overwrite).
 template <int TAILP>
 __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
@@ -1068,6 +1073,68 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
   const uint64_t rows_per_wg = 8 * R;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  if constexpr (!TAIL) {
+    float4 *const handover = lds + (size_t)pair * R * 64 + lane;
+    if (looker) {
+      for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
+        const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+        float erow = le0;                                 // (a row that is its group's only member leaves one more empty group)
+        if (lane < nr) {
+          const int g0 = z[rb + lane];
+          if ((uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0])) erow = le1;
+        }
+        float4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
+        score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc, lbar);
+        lbar();                                           // every lookup wave is done reading the slot's tables
+#pragma unroll
+        for (int r = 0; r < R; r++) handover[r * 64] = acc[r];
+        __syncthreads();                                  // (1) prior + lookups are in the slot
+        __syncthreads();                                  // (2) the nich waves have read them
+      }
+      return;
+    }
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
+      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+      int gz = -1;
+      float sloo = 0.f;
+      if (lane < nr) {
+        gz = z[rb + lane];
+        if ((uint32_t)gz >= K) gz = -1;                   // (an id outside the table: not assigned)
+        if (gz >= 0) sloo = own[rb + lane];
+      }
+      const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+      float4 acc[R];
+      const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
+      nich_phase_global<R, true>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+      __syncthreads();                                    // (1)
+#pragma unroll
+      for (int r = 0; r < R; r++) {                       // (prior + lookups) + (nich features)
+        float4 t = handover[r * 64];
+        add4(t, acc[r]);
+        acc[r] = t;
+      }
+      __syncthreads();                                    // (2)
+      int znew = gz;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float4 s4 = acc[r];
+        const int g = lane_bcast(gz, r);
+        if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
+        float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kb + j >= K) sc[j] = -INFINITY;
+        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        if (lane == r) znew = pick;
+      }
+      if (lane < nr) z[rb + lane] = znew;
+    }
+    return;
+  }
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);

@@ -50,6 +50,9 @@ def make_columns(ctx, spec, N, K, seed):
         elif fam == NICH:
             c = torch.randn(K, generator=g, device=dev) * 10
             cols.append((c[zl] + torch.randn(N, generator=g, device=dev)).float().contiguous())
+        elif fam == common_amd.DM:                         # int32 [N, dim] counts: small (the tables cover them: tens of rows)
+            lam = (torch.rand(K, dim, generator=g, device=dev) * 3.0 + 0.5)
+            cols.append(torch.poisson(lam[zl], generator=g).to(torch.int32).contiguous())
         elif fam == NIW:
             c = torch.randn(K, dim, generator=g, device=dev) * 3
             A = torch.randn(K, dim, dim, generator=g, device=dev) / dim ** 0.5
