@@ -640,6 +640,7 @@ extern "C" int msc_dataview_invalidate(msc_dataview *view) {
   view->converted.clear();
   view->sentinels.clear();
   view->packed_bits.clear();
+  view->nich_x.clear();
   view->col_max.assign(view->cols.size(), -1);
   view->dm_max.assign(view->cols.size(), std::vector<uint32_t>());
   view->dm_tot.assign(view->cols.size(), nullptr);
@@ -828,6 +829,30 @@ static int packed_column(const msc_dataview *view, const void *const *cols, int 
   return MSC_OK;
 }
 
+// the float columns `cols` (n2 of them; device, one float a row) as one matrix float [nrows][n2p], n2p = n2 rounded up to
+// four and the padding zero: what the role-split kernels' nich waves read a row's second-phase values from (msc::NichPos).
+// Kept by the view like the packed bool columns; a copy of those columns (64 MB for C3's sixteen on a million rows).
+static int nich_x_matrix(const msc_dataview *view, const std::vector<const void *> &cols, const float **out) {
+  for (const auto &e : view->nich_x)
+    if (e.first == cols) {
+      *out = e.second;
+      return MSC_OK;
+    }
+  const uint32_t n2 = (uint32_t)cols.size(), n2p = (n2 + 3u) & ~3u;
+  void *dst = nullptr, *ptrs = nullptr;
+  MSC_HIP(hipMalloc(&dst, std::max<size_t>(16, (size_t)view->nrows * n2p * sizeof(float))));
+  view->owned_lazy.push_back(dst);
+  MSC_HIP(hipMalloc(&ptrs, sizeof(void *) * n2));
+  view->owned_lazy.push_back(ptrs);                       // (the kernel reads the list after this call has returned)
+  MSC_HIP(hipMemcpyAsync(ptrs, cols.data(), sizeof(void *) * n2, hipMemcpyHostToDevice, view->ctx->stream));
+  MSC_HIP(hipStreamSynchronize(view->ctx->stream));       // (`cols` is the caller's)
+  if (launch_pack_nich_x(view->ctx->stream, static_cast<const float *const *>(ptrs), n2, n2p, view->nrows, static_cast<float *>(dst)))
+    return fail(MSC_EHIP, "k_pack_nich_x launch failed");
+  view->nich_x.emplace_back(cols, static_cast<const float *>(dst));
+  *out = static_cast<const float *>(dst);
+  return MSC_OK;
+}
+
 static int plan_groups(msc_state *st) {
   const msc_dataview *const bview = bound_view_of(st);    // (null: no column pointer survives in desc_host either)
   auto nich_tail = [](const FeatDesc &d) { return d.family == MSC_NICH && d.mask == nullptr && d.col != nullptr; };
@@ -1009,6 +1034,33 @@ static int plan_groups(msc_state *st) {
     tf[i].blk_end -= n - st->fuse_nfeat;
   }
   if (st->fuse_any) facts = plan_layout(tf, st->fuse_split, extra_f);
+  // what the role-split kernels' nich waves read (msc::NichPos): positions, the pack (k_fuse_tables fills it at the head
+  // of every call), the x matrix -- the last needs the view; without it (a plan made while no view is bound) the plan
+  // does not take those kernels, and the next call with a view plans again
+  for (FeatDesc &d : tf) d.rn_pack = nullptr, d.rn_pos = nullptr, d.rn_x = nullptr, d.rn_n2 = d.rn_n2p = 0;
+  for (FeatDesc &d : t) d.rn_pack = nullptr, d.rn_pos = nullptr, d.rn_x = nullptr, d.rn_n2 = d.rn_n2p = 0;
+  static const bool no_roles_pack = std::getenv("MSC_NO_ROLES") != nullptr;      // (A/B knob: the kernels that run the phases one after the other)
+  if (facts.roles_ok && (bview == nullptr || no_roles_pack)) facts.roles_ok = false;
+  if (facts.roles_ok) {
+    const uint32_t s0 = st->fuse_split, n2 = st->fuse_nfeat - s0, n2p = (n2 + 3u) & ~3u;
+    std::vector<NichPos> pos(n2p);
+    std::vector<const void *> xcols(n2);
+    for (uint32_t i = 0; i < n2p; i++) {
+      NichPos &q = pos[i];
+      q.xlim = INFINITY, q.blk_ok = 0u;                       // (the head kernel writes these two for real positions)
+      if (i < n2) {
+        const FeatDesc &d = tf[s0 + i];
+        q.blk = (d.blk_first - s0) | (d.blk_end - d.blk_first) << 16, q.seg_end = d.grp_end - s0;
+        xcols[i] = d.col;
+      } else q.blk = i | 1u << 16, q.seg_end = n2p;
+    }
+    const float *xm = nullptr;
+    MSC_TRY(nich_x_matrix(bview, xcols, &xm));
+    MSC_HIP(hipMemcpyAsync(st->rn_pos, pos.data(), sizeof(NichPos) * n2p, hipMemcpyHostToDevice, st->ctx->stream));
+    MSC_HIP(hipStreamSynchronize(st->ctx->stream));           // (`pos` is this function's)
+    FeatDesc &h = tf[s0];
+    h.rn_pack = st->rn_pack, h.rn_pos = st->rn_pos, h.rn_x = xm, h.rn_n2 = n2, h.rn_n2p = n2p;
+  }
   st->tile_roles_ok = facts.roles_ok;
   st->tile_narrow_tail_ok = facts.tail_ok;
   st->tail_masked_nich = facts.tail_masked_nich;
@@ -1080,6 +1132,12 @@ extern "C" int msc_state_create(msc_context *ctx, const msc_feature_spec *featur
   if ((rc = dev_alloc(st->owned, &st->desc_tile_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->desc_fuse_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->nich_info, nfeatures))) return bail(rc);
+  if ((rc = dev_alloc(st->owned, &st->rn_pos, (size_t)((nfeatures + 3u) & ~3u)))) return bail(rc);
+  {
+    size_t nnich = 0;
+    for (uint32_t f = 0; f < nfeatures; f++) nnich += features[f].family == MSC_NICH;
+    if ((rc = dev_alloc(st->owned, &st->rn_pack, (1 + kNichPackRows * nnich) * (size_t)kpad))) return bail(rc);
+  }
   if ((rc = dev_alloc(st->owned, &st->desc_acc_dev, nfeatures))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->rng_dev, 2))) return bail(rc);
   if ((rc = dev_alloc(st->owned, &st->colmax_dev, 1))) return bail(rc);
@@ -1624,8 +1682,8 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
 // ... and so does what the plan's nich blocks go by (NichPlanInfo: is a block's c1 one number per group, how far a value may
 // lie before a product of four could overflow) -- the same launch
 static int refresh_fused_tables(msc_state *st) {
-  if (!st->fuse_any && !st->nich_blocks_any) return MSC_OK;
-  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, st->nich_blocks_any ? (int)st->fuse_nfeat : (int)st->fuse_split, st->kpad))
+  if (!st->fuse_any && !st->nich_blocks_any && !st->tile_roles_ok) return MSC_OK;
+  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, (st->nich_blocks_any || st->tile_roles_ok) ? (int)st->fuse_nfeat : (int)st->fuse_split, st->kpad))
     return fail(MSC_EHIP, "k_fuse_tables launch failed");
   return MSC_OK;
 }

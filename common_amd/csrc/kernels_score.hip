@@ -772,6 +772,12 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
   if (threadIdx.x == 0) lookers_arrived = 0u;
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
+#ifdef MSC_ROLE_PRIO_LOOK
+  if (looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_LOOK);
+#endif
+#ifdef MSC_ROLE_PRIO_NICH
+  if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
+#endif
   const int pair = wave & 7;
   const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -832,7 +838,12 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
     if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-    nich_phase_global<R, false>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);
+#ifdef MSC_EXP_NO_NICH                                    // (timing experiment)
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+#else
+    nich_phase_packed<R, false>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);
+#endif
     __syncthreads();                                      // (1) the lookup sums are in the slot
 #pragma unroll
     for (int r = 0; r < R; r++) {                         // (prior lo + lookups) + (nich features)

@@ -493,6 +493,32 @@ __global__ __launch_bounds__(256) void k_pack_bits(PackCols cols, int m, uint32_
   }
   out[i] = (uint8_t)v;
 }
+// float columns as one row-major matrix (msc::NichPos: the x matrix); a 64-row tile through LDS so that both sides move
+// whole lines
+__global__ __launch_bounds__(256) void k_pack_nich_x(const float *const *__restrict__ cols, uint32_t n2, uint32_t n2p, uint64_t n,
+                                                     float *__restrict__ out) {
+  __shared__ float tile[64][65];
+  const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+  for (uint32_t c0 = 0; c0 < n2p; c0 += 64) {
+    for (uint32_t e = threadIdx.x; e < 64 * 64; e += 256) {
+      const uint32_t c = e >> 6, r = e & 63u;
+      tile[r][c] = (c0 + c < n2 && r0 + r < n) ? cols[c0 + c][r0 + r] : 0.f;
+    }
+    __syncthreads();
+    const uint32_t w = n2p - c0 < 64u ? n2p - c0 : 64u;
+    for (uint32_t e = threadIdx.x; e < 64 * w; e += 256) {
+      const uint32_t r = e / w, c = e % w;
+      if (r0 + r < n) out[(r0 + r) * n2p + c0 + c] = tile[r][c];
+    }
+    __syncthreads();
+  }
+}
+int launch_pack_nich_x(hipStream_t stream, const float *const *cols_dev, uint32_t n2, uint32_t n2p, uint64_t n, float *out) {
+  if (n == 0 || n2 == 0) return 0;
+  hipLaunchKernelGGL(k_pack_nich_x, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, cols_dev, n2, n2p, n, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_t radix, uint64_t n, void *out) {
   if (n == 0) return 0;
   PackCols pc;
@@ -513,7 +539,27 @@ int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_
 __global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict__ feats, int nsplit, uint32_t kpad) {
   const FeatDesc &fd = feats[blockIdx.x];
   if ((int)blockIdx.x >= nsplit) {
-    if (fd.nich_info == nullptr) return;
+    // the role-split kernels' copy of the second phase (msc::NichPos): this position's five rows, and -- the first
+    // position's block -- the summed c0 of all of them, summed as nich_c0_sum does (plan order, from zero)
+    const FeatDesc &head = feats[nsplit];
+    float *const pack = head.rn_pack;
+    const uint32_t pos = blockIdx.x - (uint32_t)nsplit;
+    if (pack != nullptr) {
+      float *mine = pack + (size_t)(1 + kNichPackRows * pos) * kpad;
+      for (uint32_t k = threadIdx.x; k < kpad; k += 256) {
+        mine[k] = fd.tab[(size_t)NICH_MU_HI * kpad + k];
+        mine[(size_t)kpad + k] = fd.tab[(size_t)NICH_MU_LO * kpad + k];
+        mine[(size_t)2 * kpad + k] = fd.tab[(size_t)NICH_C2 * kpad + k];
+        mine[(size_t)3 * kpad + k] = fd.tab[(size_t)NICH_C1LN2 * kpad + k];
+        mine[(size_t)4 * kpad + k] = fd.tab[(size_t)NICH_C1 * kpad + k];
+        if (pos == 0) {
+          float c0s = 0.f;
+          for (uint32_t j = 0; j < head.rn_n2; j++) c0s += feats[nsplit + j].tab[(size_t)NICH_C0 * kpad + k];
+          pack[k] = c0s;
+        }
+      }
+    }
+    if (fd.nich_info == nullptr) return;                   // (no block of two or more in the plan: no far rows, NichPos as the host set it)
     float smax = 0.f, bmax = 0.f;
     bool fine = true, same = true;
     const bool leads = fd.blk_first == blockIdx.x && fd.blk_end > blockIdx.x + 1u;
@@ -534,8 +580,10 @@ __global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict_
     const int all_fine = __syncthreads_and(fine ? 1 : 0), all_same = __syncthreads_and(same ? 1 : 0);
     if (threadIdx.x == 0) {
       for (int i = 1; i < 256; i++) smax = fmaxf(smax, s_s[i]), bmax = fmaxf(bmax, s_b[i]);
-      fd.nich_info->xlim = (all_fine && bmax < kNichFarA) ? (kNichFarA - bmax) / smax : -1.f;
+      const float xlim = (all_fine && bmax < kNichFarA) ? (kNichFarA - bmax) / smax : -1.f;
+      fd.nich_info->xlim = xlim;
       fd.nich_info->blk_ok = (leads && all_same) ? 1u : 0u;
+      if (head.rn_pos != nullptr) head.rn_pos[pos].xlim = xlim, head.rn_pos[pos].blk_ok = (leads && all_same) ? 1u : 0u;
     }
     return;
   }

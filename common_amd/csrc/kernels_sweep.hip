@@ -1068,6 +1068,12 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
   if (threadIdx.x == 0) lookers_arrived = 0u;
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
+#ifdef MSC_ROLE_PRIO_LOOK
+  if (looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_LOOK);
+#endif
+#ifdef MSC_ROLE_PRIO_NICH
+  if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
+#endif
   const uint32_t kb = lane * 4;            // single k-tile: K <= 256
   const float4 logcnt = ld4(crp + kb);
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
@@ -1109,7 +1115,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
       float4 acc[R];
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      nich_phase_global<R, true>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+      nich_phase_packed<R, true>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
       __syncthreads();                                    // (1)
 #pragma unroll
       for (int r = 0; r < R; r++) {                       // (prior + lookups) + (nich features)
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
     float4 acc[R];
     if (!looker) {
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      nich_phase_global<R, true>(feats, nsplit, nfeat, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+      nich_phase_packed<R, true>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
       __syncthreads();                                    // every lookup wave is done with the slot
       float4 *mine = lds + (size_t)pair * R * 64 + lane;
 #pragma unroll

@@ -176,6 +176,7 @@ int launch_dm_stats(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_
 int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint32_t *out_dev);
 int launch_mask_sentinel(hipStream_t stream, const void *col, const uint8_t *mask, uint64_t n, bool bytes, uint32_t sentinel, void *out);
 int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_t radix, uint64_t n, void *out);
+int launch_pack_nich_x(hipStream_t stream, const float *const *cols_dev, uint32_t n2, uint32_t n2p, uint64_t n, float *out);
 int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, int nblocks, uint32_t kpad);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
                   uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);

@@ -91,6 +91,24 @@ struct NichPlanInfo {                                    // per feature of the p
   uint32_t blk_ok;                                       // at a block's FIRST feature: c1 ln2 is bit-equal over the block
 };
 
+// The role-split kernels' nich waves (score_block.hpp nich_phase_packed) read the second phase from three arrays made
+// for them -- the plan's own descriptors are 300 bytes a feature and every number in them is a scalar load that waits for
+// the one before (round 4: the nich waves issued 0.53 of their time, the rest were such chains):
+//   * NichPos[n2p]: per POSITION i of the second phase (plan index - split; padded to a multiple of four) its block
+//     (first position, length), the end of its LDS segment (the order of the sums follows the segments in every kernel),
+//     and what the head kernel found (xlim, blk_ok: NichPlanInfo's two, copied here);
+//   * the pack: (1 + kNichPackRows n2) rows of kpad floats -- row 0 the features' summed c0 (summed in plan order from 0,
+//     as nich_c0_sum does), then per position mu_hi, mu_lo, c2, c1 ln2, c1 -- written by the head kernel at the head of
+//     every scoring / sweep call from the tables as they stand: ONE buffer, scalar offsets;
+//   * the x matrix: float [view rows][n2p], position-major inside a row -- a row's values of the second phase in one
+//     64-byte stretch (abi.cpp nich_x_matrix: built when the view is bound, cached on the view).
+struct NichPos {                                         // (32-bit fields: a scalar load fetches no less)
+  float xlim;
+  uint32_t blk_ok;
+  uint32_t blk;                                          // the position's block: first position | length << 16
+  uint32_t seg_end;
+};
+constexpr uint32_t kNichPackRows = 5;                    // mu_hi, mu_lo, c2, c1 ln2, c1
 struct FeatDesc {
   // -- what the tile kernels' lookup runs read per feature: one 32-byte block, one scalar load (score_block.hpp) --
   const void *col;         // bound dataview column (device), null until bound
@@ -160,6 +178,12 @@ struct FeatDesc {
   // second phase.
   uint32_t blk_first, blk_end;
   NichPlanInfo *nich_info;
+  // at the FIRST feature of the score / sweep plan's second phase, when the plan may take the role-split kernels: the
+  // arrays of NichPos above (null otherwise); rn_n2 positions, rn_n2p = rn_n2 rounded up to four
+  float *rn_pack;
+  NichPos *rn_pos;
+  const float *rn_x;
+  uint32_t rn_n2, rn_n2p;
   // the accumulate pass's copy of a fused bb feature (abi.cpp plan_groups, desc_acc): the members' additive tables, in the
   // members' order -- one read of the byte column and of z feeds all of them (k_accumulate)
   long long *fuse_acc[4];
@@ -339,6 +363,8 @@ struct msc_dataview {
   // byte columns holding the bits of two to four bool columns (key: the member columns' device pointers), made when a
   // state's plan fuses them (abi.cpp plan_groups, k_pack_bits)
   mutable std::vector<std::pair<std::vector<const void *>, const void *>> packed_bits;
+  // float [nrows][n2p] of the columns in the key, position-major (msc::NichPos; abi.cpp nich_x_matrix)
+  mutable std::vector<std::pair<std::vector<const void *>, const float *>> nich_x;
 };
 
 struct msc_feature_host {
@@ -398,6 +424,8 @@ struct msc_state {
   msc::FeatDesc *desc_acc_dev = nullptr;
   std::vector<msc::FeatDesc> desc_acc_host;
   msc::NichPlanInfo *nich_info = nullptr;   // [nfeat]: per feature of the plans' second phase (FeatDesc::nich_info)
+  float *rn_pack = nullptr;                 // the role-split kernels' second phase (msc::NichPos): (1 + 5 nfeat) x kpad floats
+  msc::NichPos *rn_pos = nullptr;           // [nfeat rounded up to four]
   bool nich_blocks_any = false;       // the plan has a nich block of two or more features
   const msc_dataview *bound_view = nullptr;
   uint64_t bound_serial = 0;

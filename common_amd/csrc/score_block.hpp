@@ -101,6 +101,9 @@ template <bool NT = true>
 MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint32_t kb, uint32_t K,
                        float4 s, bool vec_ok) {
   float *p = out + row * ld + kb;
+#ifdef MSC_EXP_NO_STORE                                   // (timing experiment: only a NaN row is stored)
+  if (!(s.x != s.x)) return;
+#endif
   if (vec_ok && kb + 3 < K) {
     const f32x4 v = {s.x, s.y, s.z, s.w};
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
@@ -351,6 +354,9 @@ struct WaveSubsetBarrier {
   uint32_t *counter;                                    // in LDS, zeroed by the workgroup before first use
   uint32_t passed;
   MSC_DEV void operator()() {
+#ifdef MSC_EXP_NO_LBAR                                    // (timing experiment)
+    return;
+#endif
     passed++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -378,8 +384,10 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
     const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
     const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
     float4 *dst = lds + (size_t)fd.grp_off * 64;
+#ifndef MSC_EXP_NO_COPY                                   // (timing experiment: DESIGN.md section 5, round 4)
     for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)     // one 1 KiB table row per wave instruction
       glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the group's tables has landed
   bar();                                                // ... everyone's
@@ -500,6 +508,40 @@ struct NichFromGlobal {
     const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(table(f), kb * 4u, (uint32_t)(row * kpad) * 4u, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
+  MSC_DEV float x(int f, uint64_t myrow) const { return gld1(as_global(as_scalar(feats)[f].col) + myrow); }
+};
+// ... the same rows from the PACK (msc_internal.hpp NichPos; k_fuse_tables writes it at the head of every call): one buffer
+// for the whole phase -- its descriptor four scalar registers for the kernel's life, a row's offset scalar arithmetic --
+// and the rows' values from the x matrix; `f` is a POSITION of the second phase here.  (Through the plan's descriptors
+// every block began with a dozen scalar loads, each waiting for the one before: the nich waves issued half the time.)
+struct NichPacked {
+  __amdgpu_buffer_rsrc_t pack;
+  const float *__restrict__ xrow;                          // this lane's row of the x matrix
+  uint32_t kpad, kb;
+  typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  static MSC_DEV int pack_row(int nich_row) {
+    return nich_row == NICH_MU_HI ? 0 : nich_row == NICH_MU_LO ? 1 : nich_row == NICH_C2 ? 2 : nich_row == NICH_C1LN2 ? 3 : 4;
+  }
+  MSC_DEV uint32_t at(int f, int row) const { return (uint32_t)((1 + (int)kNichPackRows * f + pack_row(row)) * (int)kpad) * 4u; }
+  template <int NC> MSC_DEV void comps(int f, int row, int c0, float (&o)[NC]) const {
+    const uint32_t so = at(f, row) + (uint32_t)c0 * 4u;
+    if constexpr (NC == 1) {
+      o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pack, kb * 4u, so, 0));
+    } else if constexpr (NC == 2) {
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(pack, kb * 4u, so, 0);
+      o[0] = __uint_as_float(v.x), o[1] = __uint_as_float(v.y);
+    } else {
+      const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(pack, kb * 4u, so, 0);
+      o[0] = __uint_as_float(v.x), o[1] = __uint_as_float(v.y), o[2] = __uint_as_float(v.z), o[3] = __uint_as_float(v.w);
+    }
+  }
+  MSC_DEV float4 quad_at(uint32_t so) const {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(pack, kb * 4u, so, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+  MSC_DEV float4 quad(int f, int row) const { return quad_at(at(f, row)); }
+  MSC_DEV float x(int f, uint64_t) const { return gld1(as_global(xrow) + f); }
 };
 // ... or the staged feature group in LDS (the kernels that run the phases one after the other)
 struct NichFromLds {
@@ -519,6 +561,7 @@ struct NichFromLds {
     }
   }
   MSC_DEV float4 quad(int f, int row) const { return lds[((size_t)as_scalar(feats)[f].grp_off + row) * 64 + lane]; }
+  MSC_DEV float x(int f, uint64_t myrow) const { return gld1(as_global(as_scalar(feats)[f].col) + myrow); }
 };
 // groups of the lane's four a block part takes: 2 (26 registers of constants at M = 4 beside the 4 R sums; with 1 the rows'
 // values are broadcast four times over -- C3 1.78 ms against 1.57 --, with 4 the constants spill: 2.76)
@@ -542,7 +585,7 @@ template <int M, int R, bool EST, typename Src>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
-  for (int j = 0; j < M; j++) xv[j] = gld1(as_global(as_scalar(feats)[f + j].col) + myrow);
+  for (int j = 0; j < M; j++) xv[j] = src.x(f + j, myrow);
   constexpr int NC = MSC_NICH_NC;
   nich_block_part<M, R, 0, NC, EST>(feats, f, src, xv, acc);
   if constexpr (NC <= 2) nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
@@ -575,7 +618,7 @@ MSC_DEV void nich_pass_plain(const FeatDesc *__restrict__ feats, int f0, int f1,
     if (blocks && uniform((int)((scalar_info)sf[uniform((int)sf[f].blk_first)].nich_info)->blk_ok) != 0) continue;
     const float4 mh = src.quad(f, NICH_MU_HI), ml = src.quad(f, NICH_MU_LO), c1l = src.quad(f, NICH_C1LN2),
                  c1 = src.quad(f, NICH_C1), c2 = src.quad(f, NICH_C2);
-    const float xv = gld1(as_global(sf[f].col) + myrow);
+    const float xv = src.x(f, myrow);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const float x = lane_bcast(xv, r);
@@ -623,6 +666,84 @@ MSC_DEV void nich_phase_global(const FeatDesc *__restrict__ feats, int f0, int n
     s0 = s1;
   }
   nich_redo_far_rows<R, EST>(feats, f0, nfeat, kpad, kb, row_abs0, far, acc);
+}
+// The same phase from the pack (NichPacked): the same sums in the same order -- segment by segment, blocks of four, three,
+// two, the rest --, the plan read from NichPos records (16 bytes a position, one scalar load) instead of the descriptors.
+// `head`: the plan's first second-phase feature (FeatDesc::rn_*).  acc is SET.
+typedef const __attribute__((address_space(4))) NichPos *scalar_pos;
+template <bool EST>
+static __device__ __attribute__((noinline)) float4 nich_row_plain_packed(const float *pack, const float *xrow, int n2, uint32_t kpad, uint32_t kb) {
+  float4 a = ld4(pack + kb);
+  for (int i = 0; i < n2; i++) {
+    const float *t = pack + (size_t)(1 + (int)kNichPackRows * i) * kpad + kb;
+    const float4 mh = ld4(t), ml = ld4(t + kpad), c2 = ld4(t + 2 * (size_t)kpad), c1l = ld4(t + 3 * (size_t)kpad), c1 = ld4(t + 4 * (size_t)kpad);
+    const float x = xrow[i];
+    a.x = nich_accum<EST>(a.x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+    a.y = nich_accum<EST>(a.y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+    a.z = nich_accum<EST>(a.z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+    a.w = nich_accum<EST>(a.w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+  }
+  return a;
+}
+template <int M, int R, bool EST>
+MSC_DEV void nich_pass_blocks_packed(scalar_pos pos, int p0, int p1, const NichPacked &src, float4 (&acc)[R]) {
+  for (int p = p0; p < p1;) {
+    const int len = uniform((int)(pos[p].blk >> 16));
+    if (len == M && uniform((int)pos[p].blk_ok) != 0) nich_block<M, R, EST>(nullptr, p, src, 0, acc);
+    p = uniform(p + len);
+  }
+}
+template <int R, bool EST>
+MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint32_t kpad, uint32_t kb, uint64_t row_abs0, int nr,
+                               uint64_t myrow, float4 (&acc)[R]) {
+  const scalar_feats sf = as_scalar(feats);
+  const float *const packp = sf[f0].rn_pack;
+  const scalar_pos pos = (scalar_pos)sf[f0].rn_pos;
+  const int n2 = uniform((int)sf[f0].rn_n2), n2p = uniform((int)sf[f0].rn_n2p);
+  const float *const xrow = sf[f0].rn_x + myrow * (uint64_t)n2p;
+  const NichPacked src{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packp), 0, 0x7fffffff, 0x00020000), xrow, kpad, kb};
+  // far rows (bit r: the wave's row r; NaN included): the row's values a quad at a time against the positions' limits
+  // (the padding: value 0 against +inf)
+  bool far = false;
+  for (int q = 0; q < n2p; q += 4) {
+    const float4 x4 = gld4(as_global(xrow) + q);
+    far |= !(__builtin_fabsf(x4.x) <= pos[q].xlim) | !(__builtin_fabsf(x4.y) <= pos[q + 1].xlim) |
+           !(__builtin_fabsf(x4.z) <= pos[q + 2].xlim) | !(__builtin_fabsf(x4.w) <= pos[q + 3].xlim);
+  }
+  const unsigned long long farbits = __builtin_amdgcn_ballot_w64(far && (int)(threadIdx.x & 63) < nr);
+  {
+    const float4 c0s = src.quad_at(0u);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = c0s;
+  }
+  for (int s0 = 0; s0 < n2;) {
+    const int s1 = uniform((int)pos[s0].seg_end);
+    if (kNichBlock >= 4) nich_pass_blocks_packed<4, R, EST>(pos, s0, s1, src, acc);
+    if (kNichBlock >= 3) nich_pass_blocks_packed<3, R, EST>(pos, s0, s1, src, acc);
+    nich_pass_blocks_packed<2, R, EST>(pos, s0, s1, src, acc);
+    for (int p = s0; p < s1; p = uniform(p + 1)) {
+      if (uniform((int)pos[uniform((int)(pos[p].blk & 0xffffu))].blk_ok) != 0) continue;     // (went as one with its block)
+      const float4 mh = src.quad(p, NICH_MU_HI), ml = src.quad(p, NICH_MU_LO), c1l = src.quad(p, NICH_C1LN2),
+                   c1 = src.quad(p, NICH_C1), c2 = src.quad(p, NICH_C2);
+      const float xv = src.x(p, 0);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const float x = lane_bcast(xv, r);
+        acc[r].x = nich_accum<EST>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
+        acc[r].y = nich_accum<EST>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
+        acc[r].z = nich_accum<EST>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
+        acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    s0 = s1;
+  }
+  if (farbits != 0ull) {
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if ((farbits >> r) & 1ull)
+        acc[r] = nich_row_plain_packed<EST>(packp, sf[f0].rn_x + (row_abs0 + r) * (uint64_t)n2p, n2, kpad, kb);
+  }
 }
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
 template <int R, int W, bool EST = false>
@@ -689,6 +810,9 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         const uint64_t byte = u8 ? ldrow : ldrow * 4;
         const uint64_t base = reinterpret_cast<uint64_t>(h.col);
         const uint64_t at = (base + byte) & ~(uint64_t)3;     // (the columns are dword-aligned for 32-bit types anyway)
+#ifdef MSC_EXP_NO_VALUES                                  // (timing experiment: no value loads, every row looks up entry `lane & 1`)
+        return (uint32_t)(at & 4u) >> 2;
+#endif
         return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((g_u8)at);
       };
       auto index_of = [&](const Head &h, uint32_t word) -> uint32_t {
@@ -700,6 +824,10 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
       auto lookups = [&](const Head &h, uint32_t word) {
         const uint32_t idx = index_of(h, word);
         const float4 *buf = lds + (size_t)h.off * 64 + lane;
+#ifdef MSC_EXP_NO_LOOKUPS                                 // (timing experiment: the value is still fetched and used)
+        acc[0].x += __uint_as_float(idx & 1u);
+        return;
+#endif
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 4) {
           float4 t[4];
