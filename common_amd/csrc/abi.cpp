@@ -2096,6 +2096,13 @@ static bool sweep_is_niw1(const msc_state *st) {
 // (priced with the cost model of launchers.hpp: the lane <-> row launches -- plus, beyond 64 groups, the trip through
 // 128 floats per row and the row sampler -- against the rounds of the fused tile sweep kernel; for a tail beyond a full
 // tile, against one more tile pass, the materialised matrix and the sampler)
+// PAIR mode of the role-split sweep kernel (at most 128 groups; kernels_sweep.hip): by the bound view's rows (or the rows
+// of the whole a sharded driver announced), never the call's -- its draw associates a row's entries differently from the
+// other tile kernels', so every row range of a view takes the same one
+static bool sweep_pair_mode(const msc_state *st) {
+  const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
+  return rows >= kTailMinRows && pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE, st->K, false);
+}
 static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
   if (const char *forced = std::getenv("MSC_TAIL_MIN_ROWS")) return rows >= (uint64_t)std::atoll(forced);
@@ -2110,7 +2117,7 @@ static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
     tile_us = tile_rounds_us(c128, cus, false) + sample_us;                    // one more tile pass, then the sampler over K floats a row
   } else {
     if (groups > 64) rows_us += sample_us;
-    tile_us = tile_rounds_us(c128, cus, true);
+    tile_us = tile_rounds_us(c128, cus, true) * (sweep_pair_mode(st) ? kPairTileShare : 1.0);
   }
   return rows_us < tile_us;
 }
@@ -2205,8 +2212,8 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
           not_zeroed = true;                              // (nothing emptied the additive tables on the way)
         } else if (rc == 1) rc = -2;
       }
-      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
-    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0 && !not_zeroed;
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior

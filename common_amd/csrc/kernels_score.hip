@@ -757,14 +757,16 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_score_tile(const Fea
 // finished; with leave-one-out + prior that cost the lookup waves 0.5 ms of C3's 2.07 -- ~45 spilled reloads in their
 // epilogue, harmless while the nich half was the longer one.)
 // ---------------------------------------------------------------------------
-constexpr int kRoleRows = 16;          // rows per wave pair
-template <bool LOO, bool CRP>
+constexpr int kRoleRows = 16;          // sums (float4) per wave: 16 rows, or -- PAIR -- 32
+// PAIR: at most 128 groups (score_block.hpp pair_dup): a lane carries two groups, a float4 of sums two rows, a wave 32 rows,
+// a workgroup 256
+template <bool LOO, bool CRP, bool PAIR = false>
 __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                                const int32_t *__restrict__ z, const float *__restrict__ own,
                                                                const float *__restrict__ crp, float *__restrict__ out,
                                                                uint64_t ld) {
-  constexpr int R = kRoleRows;
+  constexpr int R = kRoleRows, RW = PAIR ? 2 * kRoleRows : kRoleRows;   // sums / rows per wave
   __shared__ float4 lds[kGrpRows * 64];                   // the table slot; between chunks the hand-over
   __shared__ uint32_t lookers_arrived;                    // the lookup waves' own barrier (WaveSubsetBarrier)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -779,18 +781,19 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
   if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
 #endif
   const int pair = wave & 7;
-  const uint32_t kb = blockIdx.y * kGroupTile + lane * 4;
-  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const uint64_t rows_per_wg = 8 * R;
+  const uint32_t kb = PAIR ? (uint32_t)lane * 2u : blockIdx.y * kGroupTile + lane * 4;
+  const bool vec_ok = PAIR ? ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)
+                           : ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const uint64_t rows_per_wg = 8 * RW;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
   float4 *const handover = lds + (size_t)pair * R * 64 + lane;           // the pair's 16 rows of the slot
   if (looker) {
     // ---- the lookup waves: prior lo + lookups, parked in the slot ----
     float4 logcnt = make_float4(0, 0, 0, 0);
-    if (CRP) logcnt = ld4(crp + kb);
+    if (CRP) logcnt = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
     for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;       // relative to row0
-      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;      // relative to row0
+      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
       float4 acc[R];
       int single = 0;                                     // lane r: removing row r empties its group
       if (LOO && CRP && lane < nr) {
@@ -798,15 +801,20 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
         single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
       }
       if (CRP) {
-        const float4 lo = ld4(crp + crp_lo_cnt(kpad) + kb);
+        const float4 lo = PAIR ? pair_dup(ld2(crp + crp_lo_cnt(kpad) + kb)) : ld4(crp + crp_lo_cnt(kpad) + kb);
         const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+        for (int r = 0; r < R; r++) {
+          if constexpr (PAIR)
+            acc[r] = crp_prior_pair_lo(make_float2(logcnt.x, logcnt.y), make_float2(lo.x, lo.y), LOO && lane_bcast(single, 2 * r) ? e1 : e0,
+                                       LOO && lane_bcast(single, 2 * r + 1) ? e1 : e0);
+          else acc[r] = crp_prior4_lo(logcnt, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
       }
-      score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
+      score_tile_groups<R, 8, false, false, PAIR>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
       lbar();                                             // every lookup wave is done reading the slot's tables
 #pragma unroll
       for (int r = 0; r < R; r++) handover[r * 64] = acc[r];
@@ -815,18 +823,18 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
     }
     return;
   }
-  // ---- the nich waves: constants from L2, no LDS and no barrier until the hand-over; block by block (score_block.hpp
-  // nich_phase_global: the steps every tile kernel takes); then the rows' finish ----
+  // ---- the nich waves: the second phase from the pack, no LDS and no barrier until the hand-over; block by block
+  // (score_block.hpp nich_phase_packed: the steps every tile kernel takes); then the rows' finish ----
   float4 hi = make_float4(0, 0, 0, 0);
   float le0 = 0, le1 = 0;
   if (CRP) {
-    hi = ld4(crp + kb);
+    hi = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
     le0 = crp[2 * (size_t)kpad];
     le1 = crp[2 * (size_t)kpad + 1];
   }
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;         // relative to row0
-    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;        // relative to row0
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
     // what the finish needs of the rows, fetched before the arithmetic (its latency under the nich phase)
     int gz = -1, single = 0;
     float sloo = 0.f;
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
 #else
-    nich_phase_packed<R, false>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);
+    nich_phase_packed<R, false, PAIR>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);
 #endif
     __syncthreads();                                      // (1) the lookup sums are in the slot
 #pragma unroll
@@ -856,12 +864,22 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
     // component that hold group g take it: score_block.hpp replace_own)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
-      if (LOO) {
-        const int g = lane_bcast(gz, r);
-        if (g >= 0) replace_own(acc[r], kb, g, lane_bcast(sloo, r));   // (wave-uniform g; in registers: no LDS left to these waves)
+      if constexpr (PAIR) {
+        if (CRP)
+          add4(acc[r], crp_prior_pair(make_float2(hi.x, hi.y), LOO && lane_bcast(single, 2 * r) ? le1 : le0,
+                                      LOO && lane_bcast(single, 2 * r + 1) ? le1 : le0));
+        if (LOO)
+          replace_own_pair(acc[r], lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+        if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, K, acc[r].x, acc[r].y, vec_ok);
+        if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, K, acc[r].z, acc[r].w, vec_ok);
+      } else {
+        if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
+        if (LOO) {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(acc[r], kb, g, lane_bcast(sloo, r));   // (wave-uniform g; in registers: no LDS left to these waves)
+        }
+        if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
       }
-      if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
     }
   }
 }
@@ -989,6 +1007,11 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// PAIR mode of the role-split kernels: one k-tile of at most 128 groups, rows enough for the role-split kernels at all
+bool pair_mode_ok(int path, uint32_t K, bool few_rows) {
+  static const bool off = std::getenv("MSC_NO_PAIR") != nullptr;     // (A/B knob)
+  return !off && path == MSC_PATH_TILE_ROLES && tile_roles_enabled() && K <= 128 && !few_rows;
+}
 bool tile_roles_enabled() {
   static const bool on = [] {
     const char *e = std::getenv("MSC_TILE_ROLES");      // A/B knob: 0 keeps every wave on both phases (k_score_tile)
@@ -1487,7 +1510,10 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     // against the launches of the lane <-> row kernel)
     const char *forced = std::getenv("MSC_TAIL_MIN_ROWS");          // (tests: the kernel on a few thousand rows)
     const uint64_t c128 = (nrows + 127) / 128;
-    const double tile_us = tile_rounds_us(c128 * ktiles, num_cus, false) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false) : 0.0);
+    // (a state of at most 128 groups on the role-split kernels: PAIR mode, 256 rows a workgroup at about the price of 128)
+    const bool pair = pair_mode_ok(path, K, small4);
+    const double tile_us = (pair ? kPairTileShare : 1.0) *
+                           (tile_rounds_us(c128 * ktiles, num_cus, false) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false) : 0.0));
     const bool many_rows = forced ? nrows >= (uint64_t)std::atoll(forced)
                                   : nrows >= kTailMinRows && tail_rows_us(K - (ktiles - 1) * kGroupTile, true, nrows, num_cus) < tile_us;
     const bool tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
@@ -1497,6 +1523,9 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
+    else if (pair)
+      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1), dim3(1024), 0, stream,
+                         feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (!small4 && path == MSC_PATH_TILE_ROLES && tile_roles_enabled())
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);

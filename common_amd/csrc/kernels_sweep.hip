@@ -1048,7 +1048,9 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // their sums, put the leave-one-out value in place and DRAW.  TAILP > 0 keeps the first arrangement (the lookup waves
 // draw: the tail's rows travel through their pair's region of the slot, which a lookup wave that runs ahead would
 // overwrite).
-template <int TAILP>
+// PAIR (with TAILP == 0; K <= 128): a lane carries two groups, a float4 of sums two rows, a wave 32 rows (score_block.hpp
+// pair_dup; k_score_tile_roles<.., PAIR>); a row's draw runs over the wave's 64 x 2 entries.
+template <int TAILP, bool PAIR = false>
 __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__restrict__ feats, int nfeat, int nsplit,
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                                uint64_t row_id0, int32_t *__restrict__ z,
@@ -1074,17 +1076,19 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 #ifdef MSC_ROLE_PRIO_NICH
   if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
 #endif
-  const uint32_t kb = lane * 4;            // single k-tile: K <= 256
-  const float4 logcnt = ld4(crp + kb);
+  static_assert(!PAIR || TAILP == 0, "PAIR mode: one tile of at most 128 groups");
+  constexpr int RW = PAIR ? 2 * R : R;     // rows per wave
+  const uint32_t kb = PAIR ? lane * 2 : lane * 4;            // single k-tile: K <= 256
+  const float4 logcnt = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
-  const uint64_t rows_per_wg = 8 * R;
+  const uint64_t rows_per_wg = 8 * RW;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
   if constexpr (!TAIL) {
     float4 *const handover = lds + (size_t)pair * R * 64 + lane;
     if (looker) {
       for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
-        const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+        const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;
+        const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
         float erow = le0;                                 // (a row that is its group's only member leaves one more empty group)
         if (lane < nr) {
           const int g0 = z[rb + lane];
@@ -1092,8 +1096,10 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
         }
         float4 acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-        score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc, lbar);
+        for (int r = 0; r < R; r++)
+          acc[r] = PAIR ? crp_prior_pair(make_float2(logcnt.x, logcnt.y), lane_bcast(erow, 2 * r), lane_bcast(erow, 2 * r + 1))
+                        : crp_prior4(logcnt, lane_bcast(erow, r));
+        score_tile_groups<R, 8, false, false, PAIR>(feats, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc, lbar);
         lbar();                                           // every lookup wave is done reading the slot's tables
 #pragma unroll
         for (int r = 0; r < R; r++) handover[r * 64] = acc[r];
@@ -1103,8 +1109,8 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       return;
     }
     for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
-      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
+      const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;
+      const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
       int gz = -1;
       float sloo = 0.f;
       if (lane < nr) {
@@ -1115,7 +1121,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
       float4 acc[R];
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      nich_phase_packed<R, true>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+      nich_phase_packed<R, true, PAIR>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
       __syncthreads();                                    // (1)
 #pragma unroll
       for (int r = 0; r < R; r++) {                       // (prior + lookups) + (nich features)
@@ -1128,14 +1134,26 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 #pragma unroll
       for (int r = 0; r < R; r++) {
         float4 s4 = acc[r];
-        const int g = lane_bcast(gz, r);
-        if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
-        float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+        if constexpr (PAIR) {
+          replace_own_pair(s4, lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+          float sa[2] = {s4.x, s4.y}, sb[2] = {s4.z, s4.w};
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (kb + j >= K) sc[j] = -INFINITY;
-        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
-        if (lane == r) znew = pick;
+          for (int j = 0; j < 2; j++)
+            if (kb + j >= K) sa[j] = sb[j] = -INFINITY;
+          const int pa = sample_from_scores<2>(sa, lane_bcast(u01, 2 * r), lane, K);
+          const int pb = sample_from_scores<2>(sb, lane_bcast(u01, 2 * r + 1), lane, K);
+          if (lane == 2 * r) znew = pa;
+          if (lane == 2 * r + 1) znew = pb;
+        } else {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
+          float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (kb + j >= K) sc[j] = -INFINITY;
+          const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+          if (lane == r) znew = pick;
+        }
       }
       if (lane < nr) z[rb + lane] = znew;
     }
@@ -1700,7 +1718,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
@@ -1718,6 +1736,11 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   if (has_dm)
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
+  else if (pair && roles_ok && K <= 128)
+    // PAIR mode (abi.cpp decides on the bound view's rows, not this call's: its draw sums a row's entries two to a lane
+    // where the other tile kernels sum four, so every row range of a view must take the same one)
+    hipLaunchKernelGGL((k_sweep_tile_roles<0, true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap))), dim3(1024), 0,
+                       stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, static_cast<const float *>(nullptr));
   else if (small4)
     hipLaunchKernelGGL((k_sweep_tile<4, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);

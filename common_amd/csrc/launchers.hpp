@@ -64,10 +64,12 @@ constexpr uint32_t kTailMaxGroups = 128;
 constexpr uint64_t kTailMinRows = 16384;     // fewer rows always stay with the tile kernels (lanes as groups)
 // What a pass over `nrows` rows costs, in microseconds, on either kind of kernel (measured on C3's 64 columns, MI355X:
 // tools/scans/tail_threshold.py, small_n.py, n_scan.py) -- only to choose between them:
-//   tile kernels: one workgroup of 128 rows per CU and round, ~60 us a round of a scoring pass, ~100 us of a fused sweep;
+//   tile kernels: one workgroup of 128 rows per CU and round, ~50 us a round of a scoring pass, ~55 us of a fused sweep
+//   (round 4's kernels: 1.53 / 1.65 ms for C3's 30.5 rounds; 60 / 100 in round 3); at most 128 groups on the role-split
+//   kernels (PAIR mode, 256 rows a workgroup): kPairTileShare of that (0.95 / 1.05 ms);
 //   lane <-> row kernel: a launch of g groups takes ~30 + 1.7 g us per round of 1024 rows a CU (two workgroups of 512).
 inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep) {
-  return (sweep ? 100.0 : 60.0) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
+  return (sweep ? 55.0 : 50.0) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
 }
 inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus) {
   const uint32_t widest = exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
@@ -111,7 +113,9 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
                        uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng_dev, ZeroSpans zero);
 bool tile_roles_enabled();
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, const FeatDesc *feats_dev, int nfeat, int nsplit,
+bool pair_mode_ok(int path, uint32_t K, bool few_rows);
+constexpr double kPairTileShare = 0.62;     // what a pass of the role-split kernels costs in PAIR mode (<= 128 groups), of a full tile pass
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero);
 int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,

@@ -97,6 +97,39 @@ MSC_DEV void replace_own(float4 &s, uint32_t kb, int g, float v) {
 }
 MSC_DEV void add4(float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
+// ---------------------------------------------------------------------------
+// PAIR mode of the role-split kernels (round 4): a state of at most 128 groups.  A lane carries TWO groups (2 lane,
+// 2 lane + 1) and a float4 of sums holds TWO rows of the wave -- (x, y): row 2 r, (z, w): row 2 r + 1 -- so the same 64
+// registers of sums cover 32 rows a wave and 256 a workgroup: per row half the LDS bytes (a table row is 512 B, a lookup
+// one ds_read_b64), half the additions, one block part instead of two, the table copies spread over twice the rows.
+// Every (row, group) sum is formed by the same operations in the same order as in the other tile kernels: same bits.
+// ---------------------------------------------------------------------------
+MSC_DEV float4 pair_dup(float2 v) { return make_float4(v.x, v.y, v.x, v.y); }
+MSC_DEV float4 crp_prior_pair(float2 logcnt, float e_a, float e_b) {
+  float4 p;
+  p.x = __builtin_isinf(logcnt.x) ? e_a : logcnt.x;
+  p.y = __builtin_isinf(logcnt.y) ? e_a : logcnt.y;
+  p.z = __builtin_isinf(logcnt.x) ? e_b : logcnt.x;
+  p.w = __builtin_isinf(logcnt.y) ? e_b : logcnt.y;
+  return p;
+}
+MSC_DEV float4 crp_prior_pair_lo(float2 hi, float2 lo, float e_a, float e_b) {
+  float4 p;
+  p.x = __builtin_isinf(hi.x) ? e_a : lo.x;
+  p.y = __builtin_isinf(hi.y) ? e_a : lo.y;
+  p.z = __builtin_isinf(hi.x) ? e_b : lo.x;
+  p.w = __builtin_isinf(hi.y) ? e_b : lo.y;
+  return p;
+}
+// (ga / gb wave-uniform, -1: none; the lane that holds group g is g >> 1, the component g & 1 of the row's half)
+MSC_DEV void replace_own_pair(float4 &s, int lane, int ga, float va, int gb, float vb) {
+  const bool la = ga >= 0 && lane == (ga >> 1), lb = gb >= 0 && lane == (gb >> 1);
+  s.x = (la && (ga & 1) == 0) ? va : s.x;
+  s.y = (la && (ga & 1) == 1) ? va : s.y;
+  s.z = (lb && (gb & 1) == 0) ? vb : s.z;
+  s.w = (lb && (gb & 1) == 1) ? vb : s.w;
+}
+
 template <bool NT = true>
 MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint32_t kb, uint32_t K,
                        float4 s, bool vec_ok) {
@@ -114,6 +147,20 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
     if (rem > 1) p[1] = s.y;
     if (rem > 2) p[2] = s.z;
     if (rem > 3) p[3] = s.w;
+  }
+}
+
+// one row's half of a PAIR of sums: two floats a lane, 512 B a wave instruction
+MSC_DEV void store_half_row(float *__restrict__ out, uint64_t ld, uint64_t row, int lane, uint32_t K, float a, float b, bool vec_ok) {
+  const uint32_t k0 = (uint32_t)lane * 2u;
+  float *p = out + row * ld + k0;
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  if (vec_ok && k0 + 1 < K) {
+    const f32x2s v = {a, b};
+    *reinterpret_cast<f32x2s *>(p) = v;
+  } else if (k0 < K) {
+    p[0] = a;
+    if (k0 + 1 < K) p[1] = b;
   }
 }
 
@@ -375,7 +422,7 @@ struct WaveSubsetBarrier {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 };
-template <int W, typename Barrier = WorkgroupBarrier>
+template <int W, bool PAIR = false, typename Barrier = WorkgroupBarrier>
 MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uint32_t kpad, uint32_t ktile, int lane,
                          int wave, float4 *__restrict__ lds, Barrier &&bar = Barrier()) {
   bar();                                                // the slot's previous readers are done
@@ -383,6 +430,18 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
     const FeatDesc &fd = feats[f];
     const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u;
     const float *tile = fd.tab + (size_t)first_row * kpad + (size_t)ktile * kGroupTile;
+    if constexpr (PAIR) {
+      // the first 128 groups of two table rows per wave instruction: lanes 0-31 row 2 q, lanes 32-63 row 2 q + 1; in the
+      // slot a table row is 32 float4 (an odd block's last instruction writes with its upper half masked off)
+      float4 *dst = lds + (size_t)fd.grp_off * 32;
+#ifndef MSC_EXP_NO_COPY
+      for (uint32_t q = (uint32_t)wave; 2u * q < fd.grp_rows; q += W) {
+        const uint32_t row = 2u * q + ((uint32_t)lane >> 5);
+        if (row < fd.grp_rows) glds16(tile + (size_t)row * kpad + 4 * (lane & 31), dst + q * 64);
+      }
+#endif
+      continue;
+    }
     float4 *dst = lds + (size_t)fd.grp_off * 64;
 #ifndef MSC_EXP_NO_COPY                                   // (timing experiment: DESIGN.md section 5, round 4)
     for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)     // one 1 KiB table row per wave instruction
@@ -455,14 +514,16 @@ template <int C> MSC_DEV float &comp(float4 &v) {
   else if constexpr (C == 2) return v.z;
   else return v.w;
 }
-template <int M, int R, int C0, int NC, bool EST>
+// (PAIR: sums r holds the wave's rows 2 r -- components 0, 1 -- and 2 r + 1 -- components 2, 3 --, against the SAME two
+// groups: the part for C0 = 2 takes the same constants and the other row's values)
+template <int M, int R, int C0, int NC, bool EST, bool PAIR = false>
 MSC_DEV void nich_block_rows(const float (&xv)[M], const float (&mh)[M][NC], const float (&ml)[M][NC], const float (&sc)[M][NC],
                              const float (&c1l)[NC], float4 (&acc)[R]) {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float x[M];
 #pragma unroll
-    for (int j = 0; j < M; j++) x[j] = lane_bcast(xv[j], r);
+    for (int j = 0; j < M; j++) x[j] = lane_bcast(xv[j], PAIR ? 2 * r + C0 / 2 : r);
     float p[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -541,6 +602,12 @@ struct NichPacked {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
   MSC_DEV float4 quad(int f, int row) const { return quad_at(at(f, row)); }
+  // PAIR mode (kb = 2 lane): the lane's two groups, as (a, b, a, b)
+  MSC_DEV float4 dup_at(uint32_t so) const {
+    const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(pack, kb * 4u, so, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.x), __uint_as_float(v.y));
+  }
+  MSC_DEV float4 dup(int f, int row) const { return dup_at(at(f, row)); }
   MSC_DEV float x(int f, uint64_t) const { return gld1(as_global(xrow) + f); }
 };
 // ... or the staged feature group in LDS (the kernels that run the phases one after the other)
@@ -568,24 +635,33 @@ struct NichFromLds {
 #ifndef MSC_NICH_NC
 #define MSC_NICH_NC 2
 #endif
-template <int M, int R, int C0, int NC, bool EST, typename Src>
+template <int M, int R, int C0, int NC, bool EST, typename Src, bool PAIR = false>
 MSC_DEV void nich_block_part(const FeatDesc *__restrict__ feats, int f, const Src &src, const float (&xv)[M], float4 (&acc)[R]) {
   float mh[M][NC], ml[M][NC], sc[M][NC], c1l[NC];
+  constexpr int CG = PAIR ? 0 : C0;                     // (PAIR: both halves of the sums against the lane's two groups)
 #pragma unroll
   for (int j = 0; j < M; j++) {
-    src.template comps<NC>(f + j, NICH_MU_HI, C0, mh[j]);
-    src.template comps<NC>(f + j, NICH_MU_LO, C0, ml[j]);
-    src.template comps<NC>(f + j, NICH_C2, C0, sc[j]);
+    src.template comps<NC>(f + j, NICH_MU_HI, CG, mh[j]);
+    src.template comps<NC>(f + j, NICH_MU_LO, CG, ml[j]);
+    src.template comps<NC>(f + j, NICH_C2, CG, sc[j]);
   }
-  src.template comps<NC>(f, NICH_C1LN2, C0, c1l);
-  nich_block_rows<M, R, C0, NC, EST>(xv, mh, ml, sc, c1l, acc);
+  src.template comps<NC>(f, NICH_C1LN2, CG, c1l);
+  nich_block_rows<M, R, C0, NC, EST, PAIR>(xv, mh, ml, sc, c1l, acc);
   __builtin_amdgcn_sched_barrier(0);                          // (the next part's constants after this part's rows)
 }
-template <int M, int R, bool EST, typename Src>
+template <int M, int R, bool EST, typename Src, bool PAIR = false>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
   for (int j = 0; j < M; j++) xv[j] = src.x(f + j, myrow);
+  if constexpr (PAIR) {
+    // the lane's two groups against one row of every pair, then against the other.  The constants are fetched again for
+    // the second half (an L1 hit), as the four-group form fetches its second part's: kept across both halves they cost the
+    // allocator the sums (141-202 spilled registers in three of the four instantiations).
+    nich_block_part<M, R, 0, 2, EST, Src, true>(feats, f, src, xv, acc);
+    nich_block_part<M, R, 2, 2, EST, Src, true>(feats, f, src, xv, acc);
+    return;
+  }
   constexpr int NC = MSC_NICH_NC;
   nich_block_part<M, R, 0, NC, EST>(feats, f, src, xv, acc);
   if constexpr (NC <= 2) nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
@@ -671,12 +747,14 @@ MSC_DEV void nich_phase_global(const FeatDesc *__restrict__ feats, int f0, int n
 // two, the rest --, the plan read from NichPos records (16 bytes a position, one scalar load) instead of the descriptors.
 // `head`: the plan's first second-phase feature (FeatDesc::rn_*).  acc is SET.
 typedef const __attribute__((address_space(4))) NichPos *scalar_pos;
-template <bool EST>
+// (PAIR: kb = 2 lane, the lane's two groups in x, y; z, w repeat them)
+template <bool EST, bool PAIR = false>
 static __device__ __attribute__((noinline)) float4 nich_row_plain_packed(const float *pack, const float *xrow, int n2, uint32_t kpad, uint32_t kb) {
-  float4 a = ld4(pack + kb);
+  auto ldq = [](const float *p) { return PAIR ? pair_dup(ld2(p)) : ld4(p); };
+  float4 a = ldq(pack + kb);
   for (int i = 0; i < n2; i++) {
     const float *t = pack + (size_t)(1 + (int)kNichPackRows * i) * kpad + kb;
-    const float4 mh = ld4(t), ml = ld4(t + kpad), c2 = ld4(t + 2 * (size_t)kpad), c1l = ld4(t + 3 * (size_t)kpad), c1 = ld4(t + 4 * (size_t)kpad);
+    const float4 mh = ldq(t), ml = ldq(t + kpad), c2 = ldq(t + 2 * (size_t)kpad), c1l = ldq(t + 3 * (size_t)kpad), c1 = ldq(t + 4 * (size_t)kpad);
     const float x = xrow[i];
     a.x = nich_accum<EST>(a.x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
     a.y = nich_accum<EST>(a.y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
@@ -685,15 +763,16 @@ static __device__ __attribute__((noinline)) float4 nich_row_plain_packed(const f
   }
   return a;
 }
-template <int M, int R, bool EST>
+template <int M, int R, bool EST, bool PAIR>
 MSC_DEV void nich_pass_blocks_packed(scalar_pos pos, int p0, int p1, const NichPacked &src, float4 (&acc)[R]) {
   for (int p = p0; p < p1;) {
     const int len = uniform((int)(pos[p].blk >> 16));
-    if (len == M && uniform((int)pos[p].blk_ok) != 0) nich_block<M, R, EST>(nullptr, p, src, 0, acc);
+    if (len == M && uniform((int)pos[p].blk_ok) != 0) nich_block<M, R, EST, NichPacked, PAIR>(nullptr, p, src, 0, acc);
     p = uniform(p + len);
   }
 }
-template <int R, bool EST>
+// (PAIR: kb = 2 lane; nr counts ROWS -- up to 2 R --, lane i < nr holds row i)
+template <int R, bool EST, bool PAIR = false>
 MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint32_t kpad, uint32_t kb, uint64_t row_abs0, int nr,
                                uint64_t myrow, float4 (&acc)[R]) {
   const scalar_feats sf = as_scalar(feats);
@@ -712,37 +791,51 @@ MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint3
   }
   const unsigned long long farbits = __builtin_amdgcn_ballot_w64(far && (int)(threadIdx.x & 63) < nr);
   {
-    const float4 c0s = src.quad_at(0u);
+    const float4 c0s = PAIR ? src.dup_at(0u) : src.quad_at(0u);
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = c0s;
   }
   for (int s0 = 0; s0 < n2;) {
     const int s1 = uniform((int)pos[s0].seg_end);
-    if (kNichBlock >= 4) nich_pass_blocks_packed<4, R, EST>(pos, s0, s1, src, acc);
-    if (kNichBlock >= 3) nich_pass_blocks_packed<3, R, EST>(pos, s0, s1, src, acc);
-    nich_pass_blocks_packed<2, R, EST>(pos, s0, s1, src, acc);
+    if (kNichBlock >= 4) nich_pass_blocks_packed<4, R, EST, PAIR>(pos, s0, s1, src, acc);
+    if (kNichBlock >= 3) nich_pass_blocks_packed<3, R, EST, PAIR>(pos, s0, s1, src, acc);
+    nich_pass_blocks_packed<2, R, EST, PAIR>(pos, s0, s1, src, acc);
     for (int p = s0; p < s1; p = uniform(p + 1)) {
       if (uniform((int)pos[uniform((int)(pos[p].blk & 0xffffu))].blk_ok) != 0) continue;     // (went as one with its block)
-      const float4 mh = src.quad(p, NICH_MU_HI), ml = src.quad(p, NICH_MU_LO), c1l = src.quad(p, NICH_C1LN2),
-                   c1 = src.quad(p, NICH_C1), c2 = src.quad(p, NICH_C2);
+      auto row_of = [&](int nich_row) { return PAIR ? src.dup(p, nich_row) : src.quad(p, nich_row); };
+      const float4 mh = row_of(NICH_MU_HI), ml = row_of(NICH_MU_LO), c1l = row_of(NICH_C1LN2), c1 = row_of(NICH_C1), c2 = row_of(NICH_C2);
       const float xv = src.x(p, 0);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const float x = lane_bcast(xv, r);
+        const float x = lane_bcast(xv, PAIR ? 2 * r : r), xb = PAIR ? lane_bcast(xv, 2 * r + 1) : x;
         acc[r].x = nich_accum<EST>(acc[r].x, x, mh.x, ml.x, c1l.x, c1.x, c2.x);
         acc[r].y = nich_accum<EST>(acc[r].y, x, mh.y, ml.y, c1l.y, c1.y, c2.y);
-        acc[r].z = nich_accum<EST>(acc[r].z, x, mh.z, ml.z, c1l.z, c1.z, c2.z);
-        acc[r].w = nich_accum<EST>(acc[r].w, x, mh.w, ml.w, c1l.w, c1.w, c2.w);
+        acc[r].z = nich_accum<EST>(acc[r].z, xb, mh.z, ml.z, c1l.z, c1.z, c2.z);
+        acc[r].w = nich_accum<EST>(acc[r].w, xb, mh.w, ml.w, c1l.w, c1.w, c2.w);
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     s0 = s1;
   }
   if (farbits != 0ull) {
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int r = 0; r < R; r++)
-      if ((farbits >> r) & 1ull)
-        acc[r] = nich_row_plain_packed<EST>(packp, sf[f0].rn_x + (row_abs0 + r) * (uint64_t)n2p, n2, kpad, kb);
+      for (int r = 0; r < R; r++) {
+        if ((farbits >> (2 * r)) & 1ull) {
+          const float4 v = nich_row_plain_packed<EST, true>(packp, sf[f0].rn_x + (row_abs0 + 2 * r) * (uint64_t)n2p, n2, kpad, kb);
+          acc[r].x = v.x, acc[r].y = v.y;
+        }
+        if ((farbits >> (2 * r + 1)) & 1ull) {
+          const float4 v = nich_row_plain_packed<EST, true>(packp, sf[f0].rn_x + (row_abs0 + 2 * r + 1) * (uint64_t)n2p, n2, kpad, kb);
+          acc[r].z = v.x, acc[r].w = v.y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if ((farbits >> r) & 1ull)
+          acc[r] = nich_row_plain_packed<EST>(packp, sf[f0].rn_x + (row_abs0 + r) * (uint64_t)n2p, n2, kpad, kb);
+    }
   }
 }
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
@@ -771,10 +864,13 @@ MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, in
 
 // GENERIC = false: the caller knows every feature of the phase to be of a lookup kind (k_score_tile_roles: the host
 // checks the plan), and the branch for everything else -- with its temporaries -- is not compiled in
-template <int R, int W, bool DM, bool GENERIC = true, typename Barrier = WorkgroupBarrier>
+// PAIR (the role-split kernels at <= 128 groups, see pair_dup above): nr counts rows -- up to 2 R, lane i holds row i's value
+// --, a table row in the slot is 64 float2 and a lookup of a pair of rows two ds_read_b64
+template <int R, int W, bool DM, bool GENERIC = true, bool PAIR = false, typename Barrier = WorkgroupBarrier>
 MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t kpad, uint32_t ktile,
                                int lane, uint64_t row_abs0, int nr, uint64_t row_safe, float4 *__restrict__ lds,
                                float4 (&acc)[R], Barrier &&bar = Barrier()) {
+  static_assert(!PAIR || (!GENERIC && !DM), "PAIR mode: lookup runs only");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
@@ -782,7 +878,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
   int f0 = 0;
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].grp_end;
-    stage_group<W>(feats, f0, f1, kpad, ktile, lane, wave, lds, bar);
+    stage_group<W, PAIR>(feats, f0, f1, kpad, ktile, lane, wave, lds, bar);
     int f = f0;
     while (f < f1) {
       // A run of unmasked lookup features (bb, gp, bnb, dd with their whole table staged; the host marks them
@@ -828,6 +924,22 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         acc[0].x += __uint_as_float(idx & 1u);
         return;
 #endif
+        if constexpr (PAIR) {
+          const float2 *buf2 = reinterpret_cast<const float2 *>(lds) + (size_t)h.off * 64 + lane;
+#pragma unroll
+          for (int r0 = 0; r0 < R; r0 += 4) {
+            float2 ta[4], tb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              ta[j] = buf2[(uint32_t)lane_bcast((int)idx, 2 * (r0 + j)) * 64];
+              tb[j] = buf2[(uint32_t)lane_bcast((int)idx, 2 * (r0 + j) + 1) * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) add4(acc[r0 + j], make_float4(ta[j].x, ta[j].y, tb[j].x, tb[j].y));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          return;
+        }
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 4) {
           float4 t[4];

@@ -349,11 +349,12 @@ def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
     assert rel_err(got, want + niw).max() <= TOL
 
 
-@pytest.mark.parametrize("K", [100, 300])
+@pytest.mark.parametrize("K", [65, 100, 127, 128, 300])
 def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K):
-    """40k rows take the kernel whose waves split the lookup and the nich phase between them (k_score_tile_roles), a
-    few hundred rows the ones that run the phases one after the other: (prior + lookups) + (nich) in both, so the
-    same row must come out bit for bit -- plain, leave-one-out, with the prior"""
+    """40k rows take the kernel whose waves split the lookup and the nich phase between them (k_score_tile_roles; up to 128
+    groups in its PAIR mode: two groups a lane, two rows a float4 of sums), a few hundred rows the ones that run the
+    phases one after the other: (prior + lookups) + (nich) in both, so the same row must come out bit for bit -- plain,
+    leave-one-out, with the prior"""
     import common_amd
     rng = np.random.default_rng(K)
     N = 40_000

@@ -454,15 +454,17 @@ def test_a_state_outlives_the_view_it_last_bound(gpu_ctx):
     del junk
 
 
-def test_columns_rewritten_in_place_need_invalidate(gpu_ctx):
+@pytest.mark.parametrize("N", [6000, 40_000])
+def test_columns_rewritten_in_place_need_invalidate(gpu_ctx, N):
     """A view over the caller's tensors (msc_dataview_from_device_columns) caches what it derives from them -- bool columns
-    packed four to a byte, masked columns with the mask folded in, converted copies, column maxima.  After the caller
+    packed four to a byte, masked columns with the mask folded in, converted copies, column maxima, the plain nich columns as
+    one row-major matrix (what the role-split kernels' nich waves read: 40k rows take those kernels).  After the caller
     refills the tensors in place (minibatches through fixed buffers) msc_dataview_invalidate drops all of it: scores and
     suff-stats follow the new contents."""
     import common_amd
     rng = np.random.default_rng(12)
-    N, K = 6000, 70
-    specs = [(orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.GP, 0), (orc.NICH, 0)]
+    K = 70
+    specs = [(orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.BB, 0), (orc.GP, 0), (orc.NICH, 0)] + ([(orc.NICH, 0)] * 2 if N > 20_000 else [])
     dev = gpu_ctx.torch_device
 
     def batch(seed):
@@ -473,7 +475,7 @@ def test_columns_rewritten_in_place_need_invalidate(gpu_ctx):
     feats = batch(0)
     cols = [torch.from_numpy(f["values"].copy()).to(dev) for f in feats]
     mask3 = torch.from_numpy(rng.random(N) < 0.2).to(dev)
-    view = common_amd.DataView.from_tensors(gpu_ctx, cols, masks=[None, None, None, mask3, None, None])
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols, masks=[None, None, None, mask3] + [None] * (len(specs) - 4))
     z = rng.integers(0, K, N).astype(np.int32)
     zt = torch.from_numpy(z).to(dev)
     st = common_amd.State(gpu_ctx, specs, K)

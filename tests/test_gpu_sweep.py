@@ -555,6 +555,39 @@ def test_sweep_on_the_lane_row_kernel_matches_oracle_and_its_shards(gpu_ctx, pla
     _rows_sweep_case(gpu_ctx, ROWS_PLANS[plan], K, empty)
 
 
+@pytest.mark.parametrize("K,empty", [(65, 0), (100, 20), (127, 3), (128, 1)])
+def test_sweep_in_pair_mode_matches_oracle_and_its_shards(gpu_ctx, K, empty):
+    """65 .. 128 groups and rows enough for the role-split kernels (40k; no kernel forced): k_sweep_tile_roles<0, PAIR> -- a
+    lane carries two groups, a float4 of sums two rows, the draw runs over 64 x 2 entries.  Against the oracle's sweep (every
+    disagreeing draw on a CDF step), empty groups on offer, an unassigned row; three shards of the view draw what the whole
+    draws (the mode follows the view's rows, not the call's)."""
+    import common_amd
+    specs = ROWS_PLANS["mixed"]
+    N = 40_000
+    got, want, scores, z = _run(gpu_ctx, specs, N, K, seed=170 + K, sweep_idx=1, alpha=1.1, empty=empty)
+    _check_agreement(got, want, scores, 170 + K, 1, 0.995)
+    rng = np.random.default_rng(K)
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    zz = rng.integers(0, K - empty, N).astype(np.int32)
+    zz[5] = -1
+    fs = state_from_assignment(feats, K, zz)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(zz[zz >= 0], minlength=K).astype(np.uint32))
+    st.set_alpha(1.1)
+    whole = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    st.sweep_assign(view, whole, seed=9, sweep=1)
+    parts = torch.from_numpy(zz).to(gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=9, sweep=1, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts)
+    w = whole.cpu().numpy()
+    assert w.min() >= 0 and w.max() < K and (w != zz).mean() > 0.05
+
+
 def test_sweep_on_the_lane_row_kernel_sixteen_sums(gpu_ctx):
     """(12 groups and more table rows than the narrow tiling's LDS holds even then: the kernel's narrowest instantiation)"""
     _rows_sweep_case(gpu_ctx, [(orc.DD, 64)] * 17 + [(orc.NICH, 0)], 12, 2)
