@@ -559,13 +559,15 @@ def _gate_on_sum(got, feats, fs, rows, z=None, prior=None):
     return (np.abs(got - total) / np.maximum(mag, np.abs(total))).max()
 
 
-@pytest.mark.parametrize("K", [48, 100, 256, 300])
+@pytest.mark.parametrize("K,lane_row", [(48, True), (100, True), (100, False), (128, False), (256, True), (300, True)])
 @pytest.mark.parametrize("nnich", [2, 3, 4, 5, 9, 16])
-def test_nich_blocks_of_every_size_against_the_twin(gpu_ctx, K, nnich, monkeypatch):
+def test_nich_blocks_of_every_size_against_the_twin(gpu_ctx, K, lane_row, nnich, monkeypatch):
     """two to sixteen plain nich columns beside lookup columns (blocks of 2, 3, 4; 5 = 3 + 2; 9 = 3 + 3 + 3; 16 = 4 x 4) on
-    every kernel that walks the plan: few rows (tile kernels, phases one after the other), many (role-split / lane <-> row),
-    leave-one-out + prior.  The gate is the north star's on a sum of features; slices of the whole come out bit for bit."""
-    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    every kernel that walks the plan: few rows (tile kernels, phases one after the other), many (role-split -- up to 128
+    groups in PAIR mode when the lane <-> row kernel is not forced -- / lane <-> row), leave-one-out + prior.  The gate is
+    the north star's on a sum of features; slices of the whole come out bit for bit."""
+    if lane_row:
+        monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
     rng = np.random.default_rng(1000 * K + nnich)
     N = 40_000
     specs = [(orc.BB, 0), (orc.GP, 0)] + [(orc.NICH, 0)] * nnich + [(orc.DD, 9)]
@@ -615,15 +617,17 @@ def test_nich_blocks_follow_the_nu_prior_and_the_counts_the_suffstats_hold(gpu_c
     assert torch.equal(st4.score_value(v4, row0=500, nrows=100), a[500:600])
 
 
-@pytest.mark.parametrize("K", [64, 256, 290])
-def test_far_rows_take_the_plain_path_for_all_their_nich_features(gpu_ctx, K, monkeypatch):
+@pytest.mark.parametrize("K,lane_row", [(64, True), (100, False), (256, True), (290, True)])
+def test_far_rows_take_the_plain_path_for_all_their_nich_features(gpu_ctx, K, lane_row, monkeypatch):
     """a value 10^7 posterior scales from the groups (|a| beyond 2^15: four such squares multiplied leave the float range)
     makes its ROW a far row: nich_accum feature by feature for that row, whatever the other rows of its wave do -- so the
     row's bits are the same in a slice of 64 rows and in the whole, on the tile kernels and on the lane <-> row kernel, and
-    its scores meet the gate like any other's (they are hugely negative: relative)."""
-    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    its scores meet the gate like any other's (they are hugely negative: relative).  (K = 100: the role-split kernels'
+    PAIR mode, where a far row is one half of a pair of sums.)"""
+    if lane_row:
+        monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
     rng = np.random.default_rng(31 * K)
-    N = 20_000
+    N = 20_000 if lane_row else 40_000
     specs = [(orc.BB, 0)] + [(orc.NICH, 0)] * 6 + [(orc.GP, 0)]
     far_rows = np.array([5, 129, 4097, 12_345, N - 1])
 
