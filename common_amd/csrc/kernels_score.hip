@@ -774,12 +774,6 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
   if (threadIdx.x == 0) lookers_arrived = 0u;
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
-#ifdef MSC_ROLE_PRIO_LOOK
-  if (looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_LOOK);
-#endif
-#ifdef MSC_ROLE_PRIO_NICH
-  if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
-#endif
   const int pair = wave & 7;
   const uint32_t kb = PAIR ? (uint32_t)lane * 2u : blockIdx.y * kGroupTile + lane * 4;
   const bool vec_ok = PAIR ? ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)

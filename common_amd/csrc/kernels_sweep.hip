@@ -1070,12 +1070,6 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
   if (threadIdx.x == 0) lookers_arrived = 0u;
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
-#ifdef MSC_ROLE_PRIO_LOOK
-  if (looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_LOOK);
-#endif
-#ifdef MSC_ROLE_PRIO_NICH
-  if (!looker) __builtin_amdgcn_s_setprio(MSC_ROLE_PRIO_NICH);
-#endif
   static_assert(!PAIR || TAILP == 0, "PAIR mode: one tile of at most 128 groups");
   constexpr int RW = PAIR ? 2 * R : R;     // rows per wave
   const uint32_t kb = PAIR ? lane * 2 : lane * 4;            // single k-tile: K <= 256
