@@ -1043,11 +1043,11 @@ __global__ __launch_bounds__(W * 64, DM ? 2 : W / 4) void k_sweep_tile(const Fea
 // prior included) into `tail`, 64 TAILP floats per row; a lookup wave fetches its sixteen rows of them into its pair's hand-over region once the
 // nich sums are read (the region is the wave's own until every lookup wave has passed the next chunk's first barrier)
 // and draws over tile + tail.  An instantiation of its own: the K <= 256 kernel keeps its registers.
-// TAILP == 0 (K <= 256), round 4: the hand-over REVERSED as in k_score_tile_roles -- the lookup waves park prior + lookups
-// in the slot and go on to the next chunk, the nich waves (the shorter half since the nich features go in blocks) add
-// their sums, put the leave-one-out value in place and DRAW.  TAILP > 0 keeps the first arrangement (the lookup waves
-// draw: the tail's rows travel through their pair's region of the slot, which a lookup wave that runs ahead would
-// overwrite).
+// Round 4: the hand-over REVERSED as in k_score_tile_roles -- the lookup waves park prior + lookups in the slot and go on
+// to the next chunk, the nich waves (the shorter half since the nich features go in blocks) add their sums, put the
+// leave-one-out value in place and DRAW; with a tail (TAILP > 0) they fetch a row's tail scores from `tail` themselves,
+// four rows at a time ahead of the draws (before: the lookup waves drew, the tail's rows through their pair's region of
+// the slot).
 // PAIR (with TAILP == 0; K <= 128): a lane carries two groups, a float4 of sums two rows, a wave 32 rows (score_block.hpp
 // pair_dup; k_score_tile_roles<.., PAIR>); a row's draw runs over the wave's 64 x 2 entries.
 template <int TAILP, bool PAIR = false>
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
   const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
   const uint64_t rows_per_wg = 8 * RW;
   const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
-  if constexpr (!TAIL) {
+  {
     float4 *const handover = lds + (size_t)pair * R * 64 + lane;
     if (looker) {
       for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
       }
       __syncthreads();                                    // (2)
       int znew = gz;
+      [[maybe_unused]] float4 t4[4];
 #pragma unroll
       for (int r = 0; r < R; r++) {
         float4 s4 = acc[r];
@@ -1142,88 +1143,35 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
           const int g = lane_bcast(gz, r);
           if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
           float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+          int pick;
+          if constexpr (TAIL) {
+            // the groups beyond the tile: this row's 64 TAILP scores (k_score_tail_rows wrote them, leave-one-out value and
+            // prior included), four a lane on the first TL lanes, fetched four rows at a time ahead of their draws
+            if ((r & 3) == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (kb + j >= K) sc[j] = -INFINITY;
-          const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+              for (int j = 0; j < 4; j++) {
+                uint64_t tr = rb + (uint64_t)(r + j);
+                tr = tr < nrows ? tr : nrows - 1;
+                t4[j] = gld4(as_global(tail) + tr * (uint64_t)(4 * TL) + 4 * (lane % TL));
+              }
+            }
+            const float4 tq = t4[r & 3];
+            float st[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (lane >= TL || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
+            pick = sample_tile_and_tail<TAIL ? TAILP : 1>(sc, st, lane_bcast(u01, r), lane, K);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (kb + j >= K) sc[j] = -INFINITY;
+            pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+          }
           if (lane == r) znew = pick;
         }
       }
       if (lane < nr) z[rb + lane] = znew;
     }
-    return;
-  }
-  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * R;
-    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)R ? (nrows - rb) : (uint64_t)R);
-    float4 acc[R];
-    if (!looker) {
-      const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-      nich_phase_packed<R, true>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
-      __syncthreads();                                    // every lookup wave is done with the slot
-      float4 *mine = lds + (size_t)pair * R * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; r++) mine[r * 64] = acc[r];
-      __syncthreads();                                    // the sums are in the slot
-      continue;
-    }
-    int gz = -1;
-    float sloo = 0.f, erow = le0;
-    if (lane < nr) {
-      gz = z[rb + lane];
-      if ((uint32_t)gz >= K) gz = -1;                     // (an id outside the table: not assigned)
-      if (gz >= 0) {
-        sloo = own[rb + lane];
-        erow = __builtin_isinf(crp[kpad + gz]) ? le1 : le0;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = crp_prior4(logcnt, lane_bcast(erow, r));
-    score_tile_groups<R, 8, false, false>(feats, nsplit, kpad, 0, lane, row0 + rb, nr, row0, lds, acc, lbar);
-    __syncthreads();
-    __syncthreads();
-    {
-      const float4 *theirs = lds + (size_t)pair * R * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; r++) add4(acc[r], theirs[r * 64]);
-    }
-    float4 *mytail = lds + (size_t)pair * R * 64;
-    if (TAIL) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the nich sums are read: the region is free)
-      constexpr int RPI = 64 / TL;                         // rows per instruction: four of 64 floats, two of 128
-#pragma unroll
-      for (int i = 0; i < R / RPI; i++) {
-        uint64_t tr = rb + (uint64_t)(RPI * i + lane / TL);
-        tr = tr < nrows ? tr : nrows - 1;
-        glds16(tail + tr * (4 * TL) + 4 * (lane % TL), mytail + (size_t)i * 64);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
-    int znew = gz;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      float4 s4 = acc[r];
-      const int g = lane_bcast(gz, r);
-      if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
-      float sc[4] = {s4.x, s4.y, s4.z, s4.w};
-      int pick;
-      if (TAIL) {
-        const float4 t4 = mytail[(size_t)r * TL + (lane % TL)];
-        float st[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (lane >= TL || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
-        pick = sample_tile_and_tail<TAIL ? TAILP : 1>(sc, st, lane_bcast(u01, r), lane, K);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (kb + j >= K) sc[j] = -INFINITY;
-        pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
-      }
-      if (lane == r) znew = pick;
-    }
-    if (lane < nr) z[rb + lane] = znew;
   }
 }
 
