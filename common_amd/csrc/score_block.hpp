@@ -917,8 +917,7 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         const int v = (int)(u8 ? (word >> sh) & 0xffu : word);
         return (uint32_t)(v < 0 ? 0 : (v > (int)h.clamp ? (int)h.clamp : v));
       };
-      auto lookups = [&](const Head &h, uint32_t word) {
-        const uint32_t idx = index_of(h, word);
+      auto lookups = [&](const Head &h, uint32_t idx) {
         const float4 *buf = lds + (size_t)h.off * 64 + lane;
 #ifdef MSC_EXP_NO_LOOKUPS                                 // (timing experiment: the value is still fetched and used)
         acc[0].x += __uint_as_float(idx & 1u);
@@ -954,14 +953,20 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         Head ha = head_of(f), hb = head_of(f + 1);
         uint32_t wa = fetch(ha);
         for (; f < fe; f += 2) {
+          // (the value fetched a feature ago is TAKEN before the next fetch is issued -- the scheduling barrier keeps the
+          // load below -- or the wait for it counts the fresh load too: the ISA had vmcnt(0) behind every other prefetch)
+          const uint32_t ia = index_of(ha, wa);
+          __builtin_amdgcn_sched_barrier(0);
           const uint32_t wb = fetch(hb);                      // value of f + 1
           const Head hc = head_of(f + 2);                     // descriptor of f + 2
-          lookups(ha, wa);
+          lookups(ha, ia);
           if (f + 1 >= fe) { f++; break; }
+          const uint32_t ib = index_of(hb, wb);
+          __builtin_amdgcn_sched_barrier(0);
           wa = fetch(hc);                                     // value of f + 2
           ha = hc;
           const Head hd = head_of(f + 3);                     // descriptor of f + 3
-          lookups(hb, wb);
+          lookups(hb, ib);
           hb = hd;
         }
         if (f > fe) f = fe;
