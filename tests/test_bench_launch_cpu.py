@@ -32,3 +32,19 @@ def test_gpus_must_agree_with_world_size():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 2 and b"WORLD_SIZE=2" in p.stderr and not p.stdout.strip()
+
+
+def test_the_drivers_own_launch_line_over_gloo():
+    """the command the driver uses for N > 1 -- torch.distributed.run around bench.py, one rank per GPU -- as a dry run of
+    four ranks: rank 0 alone prints, and prints one line"""
+    env = dict(os.environ, MSC_BENCH_BACKEND="gloo", MSC_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 4 and r["ranks_seen"] == 4 and r["steps"] == 2 and r["warmup"] == 1 and r["dry_run"] is True
