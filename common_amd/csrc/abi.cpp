@@ -722,7 +722,7 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
 // kGrpRows rows per group, never across the two phases.
 // what the choice of kernels depends on, for one plan
 struct PlanFacts {
-  bool roles_ok = false, tail_ok = false, tail_masked_nich = false;
+  bool roles_ok = false, nich_only = false, tail_ok = false, tail_masked_nich = false;
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;
 };
 
@@ -789,6 +789,7 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
     if (i < split && t[i].kind == MSC_KIND_GENERIC) pf.roles_ok = false;
   }
   if (has_dm) pf.roles_ok = false;
+  pf.nich_only = split == 0 && n >= 2;                     // (the second phase is plain nich features by construction)
   // the lane <-> row kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase
   // (what it implements), whatever the second holds of plain nich features
   pf.tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
@@ -1040,8 +1041,8 @@ static int plan_groups(msc_state *st) {
   for (FeatDesc &d : tf) d.rn_pack = nullptr, d.rn_pos = nullptr, d.rn_x = nullptr, d.rn_n2 = d.rn_n2p = 0;
   for (FeatDesc &d : t) d.rn_pack = nullptr, d.rn_pos = nullptr, d.rn_x = nullptr, d.rn_n2 = d.rn_n2p = 0;
   static const bool no_roles_pack = std::getenv("MSC_NO_ROLES") != nullptr;      // (A/B knob: the kernels that run the phases one after the other)
-  if (facts.roles_ok && (bview == nullptr || no_roles_pack)) facts.roles_ok = false;
-  if (facts.roles_ok) {
+  if (bview == nullptr || no_roles_pack) facts.roles_ok = facts.nich_only = false;
+  if (facts.roles_ok || facts.nich_only) {
     const uint32_t s0 = st->fuse_split, n2 = st->fuse_nfeat - s0, n2p = (n2 + 3u) & ~3u;
     std::vector<NichPos> pos(n2p);
     std::vector<const void *> xcols(n2);
@@ -1062,6 +1063,7 @@ static int plan_groups(msc_state *st) {
     h.rn_pack = st->rn_pack, h.rn_pos = st->rn_pos, h.rn_x = xm, h.rn_n2 = n2, h.rn_n2p = n2p;
   }
   st->tile_roles_ok = facts.roles_ok;
+  st->tile_nich_only = facts.nich_only;
   st->tile_narrow_tail_ok = facts.tail_ok;
   st->tail_masked_nich = facts.tail_masked_nich;
   st->tail_max_rows = facts.tail_max_rows;
@@ -1682,8 +1684,9 @@ static int ensure_own(msc_state *st, uint64_t nrows) {
 // ... and so does what the plan's nich blocks go by (NichPlanInfo: is a block's c1 one number per group, how far a value may
 // lie before a product of four could overflow) -- the same launch
 static int refresh_fused_tables(msc_state *st) {
-  if (!st->fuse_any && !st->nich_blocks_any && !st->tile_roles_ok) return MSC_OK;
-  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, (st->nich_blocks_any || st->tile_roles_ok) ? (int)st->fuse_nfeat : (int)st->fuse_split, st->kpad))
+  const bool packed = st->tile_roles_ok || st->tile_nich_only;
+  if (!st->fuse_any && !st->nich_blocks_any && !packed) return MSC_OK;
+  if (launch_fuse_tables(st->ctx->stream, st->desc_fuse_dev, (int)st->fuse_split, (st->nich_blocks_any || packed) ? (int)st->fuse_nfeat : (int)st->fuse_split, st->kpad))
     return fail(MSC_EHIP, "k_fuse_tables launch failed");
   return MSC_OK;
 }
@@ -1808,7 +1811,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   if (n_niw < st->nfeat || crp) {
     bool has_dm = false;
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
-    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE;
+    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_fuse_dev;
     TailPlan tail;
     if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
@@ -2101,7 +2104,7 @@ static bool sweep_is_niw1(const msc_state *st) {
 // other tile kernels', so every row range of a view takes the same one
 static bool sweep_pair_mode(const msc_state *st) {
   const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
-  return rows >= kTailMinRows && pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : MSC_PATH_TILE, st->K, false);
+  return rows >= kTailMinRows && pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE, st->K, false);
 }
 static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
@@ -2212,8 +2215,8 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
           not_zeroed = true;                              // (nothing emptied the additive tables on the way)
         } else if (rc == 1) rc = -2;
       }
-      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
-    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0 && !not_zeroed;
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior

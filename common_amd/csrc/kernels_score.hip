@@ -879,6 +879,81 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 }
 
 // ---------------------------------------------------------------------------
+// k_score_nich_pack: a state of plain nich features only (two or more: a mixture of independent Gaussians per dimension).
+// The tile plan has no first phase then, and what the role-split kernels' nich waves do needs neither the table slot nor
+// a barrier: here ALL sixteen waves of a workgroup are such waves -- 16 rows each (32 in PAIR mode, at most 128 groups),
+// the constants from the pack in L2 (score_block.hpp nich_phase_packed), the rows' values from the x matrix -- and a
+// chunk is 256 (512) rows.  (prior lo + nothing) + (nich features) + prior hi, the leave-one-out entry in registers:
+// the sums score_tile<SPLIT> forms for such a plan, same bits.  (The kernels that stage the nich constants through LDS
+// feature group by feature group ran sixteen nich columns on a million rows at 1.16 ms; this one: see DESIGN section 5.)
+// ---------------------------------------------------------------------------
+template <bool LOO, bool CRP, bool PAIR>
+__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_score_nich_pack(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad, uint64_t row0,
+                                                              uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own,
+                                                              const float *__restrict__ crp, float *__restrict__ out, uint64_t ld) {
+  constexpr int R = kRoleRows, RW = PAIR ? 2 * kRoleRows : kRoleRows;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t kb = PAIR ? (uint32_t)lane * 2u : blockIdx.y * kGroupTile + lane * 4;
+  const bool vec_ok = PAIR ? ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)
+                           : ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const uint64_t rows_per_wg = kNichPackWaves * RW;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  float4 hi = make_float4(0, 0, 0, 0), lo = make_float4(0, 0, 0, 0);
+  float le0 = 0, le1 = 0, e0 = 0, e1 = 0;
+  if (CRP) {
+    hi = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
+    lo = PAIR ? pair_dup(ld2(crp + crp_lo_cnt(kpad) + kb)) : ld4(crp + crp_lo_cnt(kpad) + kb);
+    le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+    e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
+  }
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * RW;        // relative to row0
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+    if (nr == 0) continue;                                // (wave-uniform; nothing in this kernel waits for another wave)
+    int gz = -1, single = 0;
+    float sloo = 0.f;
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+      if (CRP) single = gz >= 0 && (uint32_t)gz < K && __builtin_isinf(crp[kpad + gz]) ? 1 : 0;
+    }
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+    float4 acc[R];
+    const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
+    nich_phase_packed<R, false, PAIR>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if constexpr (PAIR) {
+        if (CRP) {
+          const bool sa = LOO && lane_bcast(single, 2 * r), sb = LOO && lane_bcast(single, 2 * r + 1);
+          float4 t = crp_prior_pair_lo(make_float2(hi.x, hi.y), make_float2(lo.x, lo.y), sa ? e1 : e0, sb ? e1 : e0);
+          add4(t, acc[r]);                                // (prior lo) + (nich features)
+          add4(t, crp_prior_pair(make_float2(hi.x, hi.y), sa ? le1 : le0, sb ? le1 : le0));
+          acc[r] = t;
+        }
+        if (LOO)
+          replace_own_pair(acc[r], lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+        if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, K, acc[r].x, acc[r].y, vec_ok);
+        if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, K, acc[r].z, acc[r].w, vec_ok);
+      } else {
+        if (CRP) {
+          const bool s1 = LOO && lane_bcast(single, r);
+          float4 t = crp_prior4_lo(hi, lo, s1 ? e1 : e0);
+          add4(t, acc[r]);
+          add4(t, crp_prior4(hi, s1 ? le1 : le0));
+          acc[r] = t;
+        }
+        if (LOO) {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(acc[r], kb, g, lane_bcast(sloo, r));
+        }
+        if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // counts beyond the exact tables of gp / bnb / dm (only launched when a column's maximum exceeds
 // the table cap): one wave per row, lanes over groups; adds the exact value in double (the own
 // group's value is already the leave-one-out one).
@@ -1004,7 +1079,7 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
 // PAIR mode of the role-split kernels: one k-tile of at most 128 groups, rows enough for the role-split kernels at all
 bool pair_mode_ok(int path, uint32_t K, bool few_rows) {
   static const bool off = std::getenv("MSC_NO_PAIR") != nullptr;     // (A/B knob)
-  return !off && path == MSC_PATH_TILE_ROLES && tile_roles_enabled() && K <= 128 && !few_rows;
+  return !off && (path == MSC_PATH_TILE_ROLES || path == MSC_PATH_NICH_PACK) && tile_roles_enabled() && K <= 128 && !few_rows;
 }
 bool tile_roles_enabled() {
   static const bool on = [] {
@@ -1517,6 +1592,12 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
+    else if (pair && path == MSC_PATH_NICH_PACK)
+      hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)), 1), dim3(kNichPackWaves * 64), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
+    else if (path == MSC_PATH_NICH_PACK && !small4)
+      hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false>), dim3((unsigned)std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)), grid.y), dim3(kNichPackWaves * 64), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (pair)
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1), dim3(1024), 0, stream,
                          feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);

@@ -1176,6 +1176,77 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_nich_pack: the fused assignment step of a state of plain nich features only (kernels_score.hip
+// k_score_nich_pack, where the why is written down): sixteen nich waves a workgroup, no LDS, no barrier; nich sums + prior,
+// the leave-one-out entry, the draw.  K <= 256; PAIR: K <= 128, two groups a lane, 32 rows a wave.
+// ---------------------------------------------------------------------------
+template <bool PAIR>
+__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sweep_nich_pack(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad, uint64_t row0,
+                                                              uint64_t nrows, uint64_t row_id0, int32_t *__restrict__ z,
+                                                              const float *__restrict__ own, const float *__restrict__ crp,
+                                                              const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  constexpr int R = 16, RW = PAIR ? 32 : 16;
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t kb = PAIR ? lane * 2 : lane * 4;
+  const uint64_t rows_per_wg = kNichPackWaves * RW;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * RW;
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+    // (across the nich phase only the row's group and its leave-one-out value stay in registers -- the phase has the 4 R
+    // sums, a block's constants and nothing to spare: with the prior's terms and the uniform held too the PAIR
+    // instantiation spilled 403 registers and ran 1.04 ms where the scoring kernel takes 0.45)
+    int gz = -1;
+    float sloo = 0.f;
+    if (lane < nr) {
+      gz = z[rb + lane];
+      if ((uint32_t)gz >= K) gz = -1;                     // (an id outside the table: not assigned)
+      if (gz >= 0) sloo = own[rb + lane];
+    }
+    float4 acc[R];
+    const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
+    nich_phase_packed<R, true, PAIR>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+    __builtin_amdgcn_sched_barrier(0);                    // (the draw's temporaries stay behind the phase)
+    const float *prior = crp;
+    asm volatile("" : "+s"(prior));                       // (fetched per chunk, an L2 hit: not kept across the phase)
+    const float4 logcnt = PAIR ? pair_dup(ld2(prior + kb)) : ld4(prior + kb);
+    const float le0 = prior[2 * (size_t)kpad], le1 = prior[2 * (size_t)kpad + 1];
+    const float erow = (gz >= 0 && __builtin_isinf(prior[kpad + (gz >= 0 ? gz : 0)])) ? le1 : le0;   // (its group's only member: one more empty group)
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    int znew = gz;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float4 s4 = acc[r];
+      if constexpr (PAIR) {
+        add4(s4, crp_prior_pair(make_float2(logcnt.x, logcnt.y), lane_bcast(erow, 2 * r), lane_bcast(erow, 2 * r + 1)));
+        replace_own_pair(s4, lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+        float sa[2] = {s4.x, s4.y}, sb[2] = {s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          if (kb + j >= K) sa[j] = sb[j] = -INFINITY;
+        const int pa = sample_from_scores<2>(sa, lane_bcast(u01, 2 * r), lane, K);
+        const int pb = sample_from_scores<2>(sb, lane_bcast(u01, 2 * r + 1), lane, K);
+        if (lane == 2 * r) znew = pa;
+        if (lane == 2 * r + 1) znew = pb;
+      } else {
+        add4(s4, crp_prior4(logcnt, lane_bcast(erow, r)));
+        const int g = lane_bcast(gz, r);
+        if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
+        float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kb + j >= K) sc[j] = -INFINITY;
+        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        if (lane == r) znew = pick;
+      }
+    }
+    if (lane < nr) z[rb + lane] = znew;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K <= 64: the narrow tiling.  In the 256-group tiling above a lane owns 4 groups of a 256-group tile, so with 16
 // groups 4 lanes of 64 work (a million rows x 16 groups x 8 bb columns scored at 1/17 of what the bytes allow).
 // Here L = ceil(K / 4) rounded to 4 / 8 / 16 lanes share a row -- lane q of them owns groups 4q .. 4q+3 -- and a
@@ -1660,7 +1731,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
@@ -1678,6 +1749,12 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   if (has_dm)
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
+  else if (nich_only && pair && K <= 128)                 // (PAIR follows the view's rows, whatever this call's are: see below)
+    hipLaunchKernelGGL((k_sweep_nich_pack<true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)))), dim3(kNichPackWaves * 64), 0, stream,
+                       feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  else if (nich_only && !small && !pair)
+    hipLaunchKernelGGL((k_sweep_nich_pack<false>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)))), dim3(kNichPackWaves * 64), 0, stream,
+                       feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   else if (pair && roles_ok && K <= 128)
     // PAIR mode (abi.cpp decides on the bound view's rows, not this call's: its draw sums a row's entries two to a lane
     // where the other tile kernels sum four, so every row range of a view must take the same one)

@@ -436,6 +436,7 @@ struct msc_state {
   size_t tail_floats = 0;
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
+  bool tile_nich_only = false;    // plan_groups: no first phase at all, two or more plain nich features (k_score_nich_pack)
   bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail_rows
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;   // the lookup tables of the tile plan's first phase: the largest, all together
   bool tail_masked_nich = false;      // ... and masked nich columns among them (evaluated in place, under the row's mask)

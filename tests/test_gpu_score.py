@@ -349,16 +349,24 @@ def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
     assert rel_err(got, want + niw).max() <= TOL
 
 
-@pytest.mark.parametrize("K", [65, 100, 127, 128, 300])
-def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K):
+BITS_PLANS = {
+    "mixed": [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BB, 0), (orc.NICH, 0)],
+    "nich_only": [(orc.NICH, 0)] * 5,       # (no first phase at all: k_score_nich_pack, every wave a nich wave; blocks of 3 + 2)
+}
+
+
+@pytest.mark.parametrize("plan", sorted(BITS_PLANS))
+@pytest.mark.parametrize("K", [65, 100, 127, 128, 256, 300])
+def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K, plan):
     """40k rows take the kernel whose waves split the lookup and the nich phase between them (k_score_tile_roles; up to 128
-    groups in its PAIR mode: two groups a lane, two rows a float4 of sums), a few hundred rows the ones that run the
-    phases one after the other: (prior + lookups) + (nich) in both, so the same row must come out bit for bit -- plain,
-    leave-one-out, with the prior"""
+    groups in its PAIR mode: two groups a lane, two rows a float4 of sums) -- a state of plain nich features alone the one
+    whose waves are all nich waves (k_score_nich_pack) --, a few hundred rows the ones that run the phases one after the
+    other: (prior + lookups) + (nich) in all of them, so the same row must come out bit for bit -- plain, leave-one-out,
+    with the prior"""
     import common_amd
     rng = np.random.default_rng(K)
     N = 40_000
-    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BB, 0), (orc.NICH, 0)]
+    specs = BITS_PLANS[plan]
     feats = [make_feature(f, N, K, rng, d) for f, d in specs]
     z = rng.integers(0, K, N).astype(np.int32)
     fs = state_from_assignment(feats, K, z)

@@ -555,14 +555,25 @@ def test_sweep_on_the_lane_row_kernel_matches_oracle_and_its_shards(gpu_ctx, pla
     _rows_sweep_case(gpu_ctx, ROWS_PLANS[plan], K, empty)
 
 
+@pytest.mark.parametrize("K,empty", [(100, 7), (128, 0), (200, 30), (256, 1)])
+def test_sweep_of_a_nich_only_state_matches_oracle_and_its_shards(gpu_ctx, K, empty):
+    """a state of plain nich features alone (a mixture of independent Gaussians per dimension) with rows enough: the fused
+    step on k_sweep_nich_pack -- every wave a nich wave, nothing through LDS; up to 128 groups in PAIR mode -- against the
+    oracle's sweep, and three shards of the view draw what the whole draws"""
+    _pair_sweep_case(gpu_ctx, [(orc.NICH, 0)] * 6, K, empty)
+
+
 @pytest.mark.parametrize("K,empty", [(65, 0), (100, 20), (127, 3), (128, 1)])
 def test_sweep_in_pair_mode_matches_oracle_and_its_shards(gpu_ctx, K, empty):
     """65 .. 128 groups and rows enough for the role-split kernels (40k; no kernel forced): k_sweep_tile_roles<0, PAIR> -- a
     lane carries two groups, a float4 of sums two rows, the draw runs over 64 x 2 entries.  Against the oracle's sweep (every
     disagreeing draw on a CDF step), empty groups on offer, an unassigned row; three shards of the view draw what the whole
     draws (the mode follows the view's rows, not the call's)."""
+    _pair_sweep_case(gpu_ctx, ROWS_PLANS["mixed"], K, empty)
+
+
+def _pair_sweep_case(gpu_ctx, specs, K, empty):
     import common_amd
-    specs = ROWS_PLANS["mixed"]
     N = 40_000
     got, want, scores, z = _run(gpu_ctx, specs, N, K, seed=170 + K, sweep_idx=1, alpha=1.1, empty=empty)
     _check_agreement(got, want, scores, 170 + K, 1, 0.995)
