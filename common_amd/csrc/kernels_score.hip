@@ -920,7 +920,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sco
     if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
-    nich_phase_packed<R, false, PAIR>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);
+    nich_phase_packed<R, false, PAIR, kNichPackNC>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if constexpr (PAIR) {

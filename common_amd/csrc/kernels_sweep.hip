@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
     }
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
-    nich_phase_packed<R, true, PAIR>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+    nich_phase_packed<R, true, PAIR, kNichPackNC>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
     __builtin_amdgcn_sched_barrier(0);                    // (the draw's temporaries stay behind the phase)
     const float *prior = crp;
     asm volatile("" : "+s"(prior));                       // (fetched per chunk, an L2 hit: not kept across the phase)

@@ -118,6 +118,10 @@ bool pair_mode_ok(int path, uint32_t K, bool few_rows);
 #define MSC_NICH_PACK_WAVES 8
 #endif
 constexpr int kNichPackWaves = MSC_NICH_PACK_WAVES;   // waves a workgroup of the nich-only kernels (8: two a SIMD and 256 registers each -- no LDS ties them to sixteen)
+#ifndef MSC_NICH_PACK_NC
+#define MSC_NICH_PACK_NC 4
+#endif
+constexpr int kNichPackNC = MSC_NICH_PACK_NC;          // groups of the lane a block part of the nich-only kernels takes (256 registers a wave there)
 constexpr double kPairTileShare = 0.62;     // what a pass of the role-split kernels costs in PAIR mode (<= 128 groups), of a full tile pass
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,

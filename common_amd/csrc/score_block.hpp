@@ -649,7 +649,7 @@ MSC_DEV void nich_block_part(const FeatDesc *__restrict__ feats, int f, const Sr
   nich_block_rows<M, R, C0, NC, EST, PAIR>(xv, mh, ml, sc, c1l, acc);
   __builtin_amdgcn_sched_barrier(0);                          // (the next part's constants after this part's rows)
 }
-template <int M, int R, bool EST, typename Src, bool PAIR = false>
+template <int M, int R, bool EST, typename Src, bool PAIR = false, int NCSEL = MSC_NICH_NC>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
@@ -662,7 +662,7 @@ MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &sr
     nich_block_part<M, R, 2, 2, EST, Src, true>(feats, f, src, xv, acc);
     return;
   }
-  constexpr int NC = MSC_NICH_NC;
+  constexpr int NC = NCSEL;                             // (groups of the lane a part takes: MSC_NICH_NC; 4 where the registers allow)
   nich_block_part<M, R, 0, NC, EST>(feats, f, src, xv, acc);
   if constexpr (NC <= 2) nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
   if constexpr (NC == 1) {
@@ -763,16 +763,16 @@ static __device__ __attribute__((noinline)) float4 nich_row_plain_packed(const f
   }
   return a;
 }
-template <int M, int R, bool EST, bool PAIR>
+template <int M, int R, bool EST, bool PAIR, int NCSEL>
 MSC_DEV void nich_pass_blocks_packed(scalar_pos pos, int p0, int p1, const NichPacked &src, float4 (&acc)[R]) {
   for (int p = p0; p < p1;) {
     const int len = uniform((int)(pos[p].blk >> 16));
-    if (len == M && uniform((int)pos[p].blk_ok) != 0) nich_block<M, R, EST, NichPacked, PAIR>(nullptr, p, src, 0, acc);
+    if (len == M && uniform((int)pos[p].blk_ok) != 0) nich_block<M, R, EST, NichPacked, PAIR, NCSEL>(nullptr, p, src, 0, acc);
     p = uniform(p + len);
   }
 }
 // (PAIR: kb = 2 lane; nr counts ROWS -- up to 2 R --, lane i < nr holds row i)
-template <int R, bool EST, bool PAIR = false>
+template <int R, bool EST, bool PAIR = false, int NCSEL = MSC_NICH_NC>
 MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint32_t kpad, uint32_t kb, uint64_t row_abs0, int nr,
                                uint64_t myrow, float4 (&acc)[R]) {
   const scalar_feats sf = as_scalar(feats);
@@ -797,9 +797,9 @@ MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint3
   }
   for (int s0 = 0; s0 < n2;) {
     const int s1 = uniform((int)pos[s0].seg_end);
-    if (kNichBlock >= 4) nich_pass_blocks_packed<4, R, EST, PAIR>(pos, s0, s1, src, acc);
-    if (kNichBlock >= 3) nich_pass_blocks_packed<3, R, EST, PAIR>(pos, s0, s1, src, acc);
-    nich_pass_blocks_packed<2, R, EST, PAIR>(pos, s0, s1, src, acc);
+    if (kNichBlock >= 4) nich_pass_blocks_packed<4, R, EST, PAIR, NCSEL>(pos, s0, s1, src, acc);
+    if (kNichBlock >= 3) nich_pass_blocks_packed<3, R, EST, PAIR, NCSEL>(pos, s0, s1, src, acc);
+    nich_pass_blocks_packed<2, R, EST, PAIR, NCSEL>(pos, s0, s1, src, acc);
     for (int p = s0; p < s1; p = uniform(p + 1)) {
       if (uniform((int)pos[uniform((int)(pos[p].blk & 0xffffu))].blk_ok) != 0) continue;     // (went as one with its block)
       auto row_of = [&](int nich_row) { return PAIR ? src.dup(p, nich_row) : src.quad(p, nich_row); };
