@@ -789,7 +789,13 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
     if (i < split && t[i].kind == MSC_KIND_GENERIC) pf.roles_ok = false;
   }
   if (has_dm) pf.roles_ok = false;
-  pf.nich_only = split == 0 && n >= 2;                     // (the second phase is plain nich features by construction)
+  // the kernels whose waves are all nich waves (k_score_nich_pack): no first phase at all and two or more plain nich features,
+  // or a first phase of at most kPackMaxLookups lookup features beside at least twice as many nich features (the lookups
+  // are gathered from L2 there, ~0.03 ms a feature and million rows: 8 bb + 8 nich sweep 0.81 -> 0.70 ms, 2 gp + 12 nich
+  // 0.99 -> 0.86; with 16 bb + 4 nich -- four fused lookups, four nich -- the role-split kernels are as good or better)
+  pf.nich_only = (split == 0 && n >= 2) || (pf.roles_ok && !has_dm && split <= (uint32_t)kPackMaxLookups && n - split >= 2 * split &&
+                                            std::getenv("MSC_NO_PACK_LOOKUPS") == nullptr);
+  if (pf.nich_only) pf.roles_ok = false;
   // the lane <-> row kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase
   // (what it implements), whatever the second holds of plain nich features
   pf.tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;

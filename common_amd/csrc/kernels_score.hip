@@ -887,8 +887,10 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 // the sums score_tile<SPLIT> forms for such a plan, same bits.  (The kernels that stage the nich constants through LDS
 // feature group by feature group ran sixteen nich columns on a million rows at 1.16 ms; this one: see DESIGN section 5.)
 // ---------------------------------------------------------------------------
-template <bool LOO, bool CRP, bool PAIR>
-__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_score_nich_pack(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad, uint64_t row0,
+// LOOK: the plan has a first phase of a FEW lookup features (abi.cpp plan_groups: at most kPackMaxLookups): their table rows
+// are gathered from L2 into a second set of sums (pack_l2_lookups) -- (prior lo + lookups) + (nich features), as everywhere.
+template <bool LOO, bool CRP, bool PAIR, bool LOOK>
+__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_score_nich_pack(const FeatDesc *__restrict__ feats, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0,
                                                               uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own,
                                                               const float *__restrict__ crp, float *__restrict__ out, uint64_t ld) {
   constexpr int R = kRoleRows, RW = PAIR ? 2 * kRoleRows : kRoleRows;
@@ -920,11 +922,36 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sco
     if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
-    nich_phase_packed<R, false, PAIR, kNichPackNC>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);
+    [[maybe_unused]] float4 accl[LOOK ? R : 1];
+    if constexpr (LOOK) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (!CRP) accl[r] = make_float4(0, 0, 0, 0);
+        else if constexpr (PAIR)
+          accl[r] = crp_prior_pair_lo(make_float2(hi.x, hi.y), make_float2(lo.x, lo.y), LOO && lane_bcast(single, 2 * r) ? e1 : e0,
+                                      LOO && lane_bcast(single, 2 * r + 1) ? e1 : e0);
+        else accl[r] = crp_prior4_lo(hi, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+      }
+      pack_l2_lookups<R, PAIR>(feats, nsplit, kpad, kb, myrow, accl);
+    }
+    nich_phase_packed<R, false, PAIR, LOOK ? 2 : kNichPackNC>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);
+    if constexpr (LOOK) {                                   // (prior lo + lookups) + (nich features), then the prior's high half
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float4 t = accl[r];
+        add4(t, acc[r]);
+        if (CRP) {
+          if constexpr (PAIR)
+            add4(t, crp_prior_pair(make_float2(hi.x, hi.y), LOO && lane_bcast(single, 2 * r) ? le1 : le0, LOO && lane_bcast(single, 2 * r + 1) ? le1 : le0));
+          else add4(t, crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
+        }
+        acc[r] = t;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if constexpr (PAIR) {
-        if (CRP) {
+        if (CRP && !LOOK) {
           const bool sa = LOO && lane_bcast(single, 2 * r), sb = LOO && lane_bcast(single, 2 * r + 1);
           float4 t = crp_prior_pair_lo(make_float2(hi.x, hi.y), make_float2(lo.x, lo.y), sa ? e1 : e0, sb ? e1 : e0);
           add4(t, acc[r]);                                // (prior lo) + (nich features)
@@ -936,7 +963,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sco
         if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, K, acc[r].x, acc[r].y, vec_ok);
         if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, K, acc[r].z, acc[r].w, vec_ok);
       } else {
-        if (CRP) {
+        if (CRP && !LOOK) {
           const bool s1 = LOO && lane_bcast(single, r);
           float4 t = crp_prior4_lo(hi, lo, s1 ? e1 : e0);
           add4(t, acc[r]);
@@ -1593,11 +1620,21 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (pair && path == MSC_PATH_NICH_PACK)
-      hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)), 1), dim3(kNichPackWaves * 64), 0, stream,
-                         feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
+    {
+      const dim3 g((unsigned)std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)), 1);
+      if (nsplit > 0)
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+      else
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+    }
     else if (path == MSC_PATH_NICH_PACK && !small4)
-      hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false>), dim3((unsigned)std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)), grid.y), dim3(kNichPackWaves * 64), 0, stream,
-                         feats_dev, K, kpad, row0, nrows, z, own, crp, out, ld);
+    {
+      const dim3 g((unsigned)std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)), grid.y);
+      if (nsplit > 0)
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+      else
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+    }
     else if (pair)
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1), dim3(1024), 0, stream,
                          feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);

@@ -1180,8 +1180,8 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 // k_score_nich_pack, where the why is written down): sixteen nich waves a workgroup, no LDS, no barrier; nich sums + prior,
 // the leave-one-out entry, the draw.  K <= 256; PAIR: K <= 128, two groups a lane, 32 rows a wave.
 // ---------------------------------------------------------------------------
-template <bool PAIR>
-__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sweep_nich_pack(const FeatDesc *__restrict__ feats, uint32_t K, uint32_t kpad, uint64_t row0,
+template <bool PAIR, bool LOOK>
+__global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sweep_nich_pack(const FeatDesc *__restrict__ feats, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0,
                                                               uint64_t nrows, uint64_t row_id0, int32_t *__restrict__ z,
                                                               const float *__restrict__ own, const float *__restrict__ crp,
                                                               const uint64_t *__restrict__ rng, ZeroSpans zero) {
@@ -1207,7 +1207,17 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
     }
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
-    nich_phase_packed<R, true, PAIR, kNichPackNC>(feats, 0, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+    [[maybe_unused]] float4 accl[LOOK ? R : 1];
+    if constexpr (LOOK) {                                   // a first phase of a few lookup features: prior + lookups, from L2
+      const float4 lc = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
+      const float l0 = crp[2 * (size_t)kpad], l1 = crp[2 * (size_t)kpad + 1];
+      const float er = (gz >= 0 && __builtin_isinf(crp[kpad + (gz >= 0 ? gz : 0)])) ? l1 : l0;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        accl[r] = PAIR ? crp_prior_pair(make_float2(lc.x, lc.y), lane_bcast(er, 2 * r), lane_bcast(er, 2 * r + 1)) : crp_prior4(lc, lane_bcast(er, r));
+      pack_l2_lookups<R, PAIR>(feats, nsplit, kpad, kb, myrow, accl);
+    }
+    nich_phase_packed<R, true, PAIR, LOOK ? 2 : kNichPackNC>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
     __builtin_amdgcn_sched_barrier(0);                    // (the draw's temporaries stay behind the phase)
     const float *prior = crp;
     asm volatile("" : "+s"(prior));                       // (fetched per chunk, an L2 hit: not kept across the phase)
@@ -1219,8 +1229,12 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float4 s4 = acc[r];
+      if constexpr (LOOK) {                                 // (prior + lookups) + (nich features)
+        s4 = accl[r];
+        add4(s4, acc[r]);
+      }
       if constexpr (PAIR) {
-        add4(s4, crp_prior_pair(make_float2(logcnt.x, logcnt.y), lane_bcast(erow, 2 * r), lane_bcast(erow, 2 * r + 1)));
+        if (!LOOK) add4(s4, crp_prior_pair(make_float2(logcnt.x, logcnt.y), lane_bcast(erow, 2 * r), lane_bcast(erow, 2 * r + 1)));
         replace_own_pair(s4, lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
         float sa[2] = {s4.x, s4.y}, sb[2] = {s4.z, s4.w};
 #pragma unroll
@@ -1231,7 +1245,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
         if (lane == 2 * r) znew = pa;
         if (lane == 2 * r + 1) znew = pb;
       } else {
-        add4(s4, crp_prior4(logcnt, lane_bcast(erow, r)));
+        if (!LOOK) add4(s4, crp_prior4(logcnt, lane_bcast(erow, r)));
         const int g = lane_bcast(gz, r);
         if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
         float sc[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -1750,11 +1764,21 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (nich_only && pair && K <= 128)                 // (PAIR follows the view's rows, whatever this call's are: see below)
-    hipLaunchKernelGGL((k_sweep_nich_pack<true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)))), dim3(kNichPackWaves * 64), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  {
+    const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves))));
+    if (nsplit > 0)
+      hipLaunchKernelGGL((k_sweep_nich_pack<true, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+    else
+      hipLaunchKernelGGL((k_sweep_nich_pack<true, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  }
   else if (nich_only && !small && !pair)
-    hipLaunchKernelGGL((k_sweep_nich_pack<false>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)))), dim3(kNichPackWaves * 64), 0, stream,
-                       feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  {
+    const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves))));
+    if (nsplit > 0)
+      hipLaunchKernelGGL((k_sweep_nich_pack<false, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+    else
+      hipLaunchKernelGGL((k_sweep_nich_pack<false, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  }
   else if (pair && roles_ok && K <= 128)
     // PAIR mode (abi.cpp decides on the bound view's rows, not this call's: its draw sums a row's entries two to a lane
     // where the other tile kernels sum four, so every row range of a view must take the same one)

@@ -121,6 +121,7 @@ constexpr int kNichPackWaves = MSC_NICH_PACK_WAVES;   // waves a workgroup of th
 #ifndef MSC_NICH_PACK_NC
 #define MSC_NICH_PACK_NC 4
 #endif
+constexpr int kPackMaxLookups = 4;                      // lookup features (after fusing the bool columns) a plan may hold and still take the nich-only kernels
 constexpr int kNichPackNC = MSC_NICH_PACK_NC;          // groups of the lane a block part of the nich-only kernels takes (256 registers a wave there)
 constexpr double kPairTileShare = 0.62;     // what a pass of the role-split kernels costs in PAIR mode (<= 128 groups), of a full tile pass
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, const FeatDesc *feats_dev, int nfeat, int nsplit,

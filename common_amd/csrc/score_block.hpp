@@ -838,6 +838,53 @@ MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint3
     }
   }
 }
+// The first phase of a plan with FEW lookup features, without the table slot: every row's table row gathered straight from
+// the tables in L2 (1 KiB a row and feature, 512 B in PAIR mode) and added to the sums in plan order -- what the lookup waves
+// of the role-split kernels do through LDS, for the kernels whose waves are all nich waves (k_score_nich_pack with a
+// first phase).  Costs the texture path 16 cycles a row and feature, which is why it is for few features only
+// (profiles/r04_roles_phases.txt: sixteen dd features moved this way cost more than the LDS saved).
+template <int R, bool PAIR>
+MSC_DEV void pack_l2_lookups(const FeatDesc *__restrict__ feats, int nsplit, uint32_t kpad, uint32_t kb, uint64_t myrow, float4 (&acc)[R]) {
+  const scalar_feats sf = as_scalar(feats);
+  typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  for (int f = 0; f < nsplit; f = uniform(f + 1)) {
+    // the value of this lane's row, as the lookup runs take it (score_tile_groups): a byte or a dword, clamped into the table
+    const bool u8 = uniform((int)sf[f].kind) == MSC_KIND_LOOKUP_U8;
+    const uint64_t base = reinterpret_cast<uint64_t>(sf[f].col);
+    const uint64_t at = (base + (u8 ? myrow : myrow * 4)) & ~(uint64_t)3;
+    const uint32_t word = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((const __attribute__((address_space(1))) unsigned char *)at);
+    const uint32_t sh = u8 ? (uint32_t)((base + myrow) & 3u) * 8u : 0u;
+    const int v = (int)(u8 ? (word >> sh) & 0xffu : word);
+    const int clampv = uniform((int)sf[f].run_clamp);
+    const int idx = v < 0 ? 0 : (v > clampv ? clampv : v);
+    const uint32_t first_row = is_count_family(uniform((int)sf[f].family)) ? (uint32_t)GP_T0 : 0u;
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sf[f].tab), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += 4) {
+      if constexpr (PAIR) {
+        u32x2v ta[4], tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          ta[j] = __builtin_amdgcn_raw_buffer_load_b64(tab, kb * 4u, (first_row + (uint32_t)lane_bcast(idx, 2 * (r0 + j))) * kpad * 4u, 0);
+          tb[j] = __builtin_amdgcn_raw_buffer_load_b64(tab, kb * 4u, (first_row + (uint32_t)lane_bcast(idx, 2 * (r0 + j) + 1)) * kpad * 4u, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          add4(acc[r0 + j], make_float4(__uint_as_float(ta[j].x), __uint_as_float(ta[j].y), __uint_as_float(tb[j].x), __uint_as_float(tb[j].y)));
+      } else {
+        u32x4v t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          t[j] = __builtin_amdgcn_raw_buffer_load_b128(tab, kb * 4u, (first_row + (uint32_t)lane_bcast(idx, r0 + j)) * kpad * 4u, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          add4(acc[r0 + j], make_float4(__uint_as_float(t[j].x), __uint_as_float(t[j].y), __uint_as_float(t[j].z), __uint_as_float(t[j].w)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
 // (acc is SET here: the phase's sums start from nich_c0_sum, not from what acc held)
 template <int R, int W, bool EST = false>
 MSC_DEV void score_tile_nich_tail(const FeatDesc *__restrict__ feats, int f0, int nfeat, uint32_t kpad, uint32_t ktile,

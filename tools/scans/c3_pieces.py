@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """C3's columns (bb + gp + dd32 + nich) x16, N = 1M: the pieces of a sweep step one by one, at several K.
 usage: tools/scans/c3_pieces.py [K ...]   (default 256)
-  score pass, leave-one-out + prior score pass (what the sweep's first half costs), accumulate, whole sweep step"""
+  score pass, leave-one-out + prior score pass (what the sweep's first half costs), accumulate, whole sweep step
+  --family=bb|gp|dd|nich : sixteen columns of one family;  --spec=bb:8,nich:8 : any feature list"""
 import json
 import os
 import sys
@@ -21,6 +22,12 @@ for a in sys.argv[1:]:                              # --family=bb|gp|dd|nich: si
     if a.startswith("--family="):
         spec = [{"bb": (common_amd.BB, 0), "gp": (common_amd.GP, 0), "dd": (common_amd.DD, 32),
                  "nich": (common_amd.NICH, 0)}[a.split("=")[1]]] * 16
+    if a.startswith("--spec="):                     # --spec=bb:8,nich:8,dd32:2 : any list, in that order
+        fam = {"bb": (common_amd.BB, 0), "gp": (common_amd.GP, 0), "dd32": (common_amd.DD, 32), "dd8": (common_amd.DD, 8), "nich": (common_amd.NICH, 0)}
+        spec = []
+        for part in a.split("=")[1].split(","):
+            name, n = part.split(":")
+            spec += [fam[name]] * int(n)
 for K in Ks:
     cols, z = make_columns(ctx, spec, N, K, 73)
     masks = None
