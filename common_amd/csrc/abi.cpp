@@ -1070,6 +1070,22 @@ static int plan_groups(msc_state *st) {
   }
   st->tile_roles_ok = facts.roles_ok;
   st->tile_nich_only = facts.nich_only;
+  {
+    // the prices the kernels are chosen by (launchers.hpp PlanCost): staged lookup features and table rows of the first
+    // phase, nich features (the second phase's, and masked ones evaluated in the first)
+    double lookups = 0, rows = 0, nich = (double)(st->fuse_nfeat - st->fuse_split);
+    for (uint32_t i = 0; i < st->fuse_split; i++) {
+      if (tf[i].family == MSC_NICH) nich += 1;
+      else lookups += 1, rows += tf[i].grp_rows;
+    }
+    PlanCost pc;
+    const double first = 6.0 + 0.45 * lookups + 0.012 * rows;
+    pc.tile_round_us = facts.nich_only ? 6.0 + 1.3 * nich + 3.0 * lookups : facts.roles_ok ? first + 0.75 * nich : first + 1.5 * nich;
+    pc.sweep_round_us = 1.1 * pc.tile_round_us;
+    pc.tail_fixed_us = 37.0;
+    pc.tail_group_us = 0.032 * lookups + 0.026 * nich;
+    st->plan_cost = pc;
+  }
   st->tile_narrow_tail_ok = facts.tail_ok;
   st->tail_masked_nich = facts.tail_masked_nich;
   st->tail_max_rows = facts.tail_max_rows;
@@ -1700,6 +1716,7 @@ static int refresh_fused_tables(msc_state *st) {
 // what the narrow kernels of a partly filled last tile need (launchers.hpp); the packed-table scratch grows on demand
 static int tail_plan(msc_state *st, TailPlan &tp) {
   tp = TailPlan();
+  tp.cost = st->plan_cost;
   if (!st->tile_narrow_tail_ok) return MSC_OK;
   const size_t need = (size_t)st->tail_pack_rows * 64;
   if (st->tail_pack_floats < need) {
@@ -1743,6 +1760,15 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
   static const bool off = std::getenv("MSC_NO_NARROW") != nullptr;        // (A/B knob; the tests run both tilings)
   // (32 lanes per row for K <= 128 was measured and loses to the 256-group tiling: 8 bb at K = 100, 0.52 against 0.20 ms)
   if (off || st->K > 64) return 0;
+  // Views of many rows leave it to the lane <-> row kernel (round 3's; by the bound VIEW's rows or the rows of the whole a
+  // sharded driver announced, so that a state keeps one kernel for all of a view's rows: the two add a row's features in
+  // different orders).  At a million rows that kernel is 1.3-2.7x the faster one (tools/scans/k_monotone.sh, MSC_NO_NARROW:
+  // sixteen dd32 columns at K = 32 0.34 -> 0.13 ms, 8 bb + 8 nich at K = 64 0.48 -> 0.26, sixteen nich at K = 32 0.30 -> 0.18);
+  // this tiling is for the small problems it was made for (C1: 10k rows, 8 us a pass).
+  {
+    const uint64_t view_rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
+    if (view_rows >= kNarrowMaxRows && st->tile_narrow_tail_ok && std::getenv("MSC_TAIL_MIN_ROWS") == nullptr) return 0;
+  }
   const int L = st->K <= 16 ? 4 : st->K <= 32 ? 8 : 16;
   uint32_t rows = 0;
   for (uint32_t f = 0; f < st->nfeat; f++) {
@@ -1760,6 +1786,23 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
     }
   }
   if ((size_t)rows * L * 16 > 64u * 1024u) return 0;
+  // ... and only where it is the cheaper tiling for THIS plan (by the plan alone, not the call's rows: the narrow kernel
+  // adds the features in the caller's order, the tile kernels in the plan's, so a state keeps one of them for all its rows).
+  // Per million rows, us, at 16 lanes a row (tools/scans/k_monotone.sh): a bb column 27 (the tile plan fuses four of them
+  // into one lookup, this tiling cannot), dd / gp 16, nich 32; against the tile kernels' rounds at the plan's price
+  // (launchers.hpp PlanCost; up to 128 groups the role-split / nich-only kernels run in PAIR mode).  32 bool columns at
+  // K = 64: 0.86 ms here, 0.30 on the tile kernel.
+  {
+    double us = 0;
+    for (uint32_t f = 0; f < st->nfeat; f++) {
+      const int fam = st->feats[f].family;
+      us += fam == MSC_BB || fam == MSC_BBNC ? 27.0 : fam == MSC_NICH ? 32.0 : fam == MSC_NOOP ? 0.0 : 16.0;
+    }
+    us *= L / 16.0;
+    const bool pair = pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE, st->K, false);
+    const double tile = st->plan_cost.tile_round_us * (1.0e6 / 128.0 / st->ctx->num_cus) * (pair ? kPairTileShare : 1.0);
+    if (us > 1.25 * tile) return 0;
+  }
   *table_rows = rows;
   return L;
 }
@@ -1820,6 +1863,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_fuse_dev;
     TailPlan tail;
+    tail.cost = st->plan_cost;
     if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
     if (path != MSC_PATH_NICH1) MSC_TRY(refresh_fused_tables(st));
@@ -2120,13 +2164,13 @@ static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t c128 = (rows + 127) / 128;
   const bool tail = groups < st->K;                       // the groups beyond a full first tile
   const double sample_us = [&](uint64_t floats_per_row) { return 30.0 + (double)rows * floats_per_row * 4.0 / 2.0e6; }(tail ? st->K : 128);
-  double rows_us = tail_rows_us(groups, false, rows, cus), tile_us;
+  double rows_us = tail_rows_us(groups, false, rows, cus, st->plan_cost), tile_us;
   if (tail) {
     rows_us *= 1.15;                                      // (the tile kernel's instantiation that reads the tail is that much slower)
-    tile_us = tile_rounds_us(c128, cus, false) + sample_us;                    // one more tile pass, then the sampler over K floats a row
+    tile_us = tile_rounds_us(c128, cus, false, st->plan_cost) + sample_us;                    // one more tile pass, then the sampler over K floats a row
   } else {
     if (groups > 64) rows_us += sample_us;
-    tile_us = tile_rounds_us(c128, cus, true) * (sweep_pair_mode(st) ? kPairTileShare : 1.0);
+    tile_us = tile_rounds_us(c128, cus, true, st->plan_cost) * (sweep_pair_mode(st) ? kPairTileShare : 1.0);
   }
   return rows_us < tile_us;
 }

@@ -1609,9 +1609,9 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     // (a state of at most 128 groups on the role-split kernels: PAIR mode, 256 rows a workgroup at about the price of 128)
     const bool pair = pair_mode_ok(path, K, small4);
     const double tile_us = (pair ? kPairTileShare : 1.0) *
-                           (tile_rounds_us(c128 * ktiles, num_cus, false) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false) : 0.0));
+                           (tile_rounds_us(c128 * ktiles, num_cus, false, narrow_tail.cost) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false, narrow_tail.cost) : 0.0));
     const bool many_rows = forced ? nrows >= (uint64_t)std::atoll(forced)
-                                  : nrows >= kTailMinRows && tail_rows_us(K - (ktiles - 1) * kGroupTile, true, nrows, num_cus) < tile_us;
+                                  : nrows >= kTailMinRows && tail_rows_us(K - (ktiles - 1) * kGroupTile, true, nrows, num_cus, narrow_tail.cost) < tile_us;
     const bool tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
                                                      (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
     if (tail && ktiles == 1) return;

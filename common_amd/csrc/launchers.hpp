@@ -61,25 +61,33 @@ struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 constexpr uint32_t kTailMaxGroups = 128;
+constexpr uint64_t kNarrowMaxRows = 131072;  // views from this many rows on do not take the K <= 64 narrow tiling (abi.cpp narrow_lanes)
 constexpr uint64_t kTailMinRows = 16384;     // fewer rows always stay with the tile kernels (lanes as groups)
-// What a pass over `nrows` rows costs, in microseconds, on either kind of kernel (measured on C3's 64 columns, MI355X:
-// tools/scans/tail_threshold.py, small_n.py, n_scan.py) -- only to choose between them:
-//   tile kernels: one workgroup of 128 rows per CU and round, ~50 us a round of a scoring pass, ~55 us of a fused sweep
-//   (round 4's kernels: 1.53 / 1.65 ms for C3's 30.5 rounds; 60 / 100 in round 3); at most 128 groups on the role-split
-//   kernels (PAIR mode, 256 rows a workgroup): kPairTileShare of that (0.95 / 1.05 ms);
-//   lane <-> row kernel: a launch of g groups takes ~30 + 1.7 g us per round of 1024 rows a CU (two workgroups of 512).
-inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep) {
-  return (sweep ? 55.0 : 50.0) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
+// What a pass over `nrows` rows costs, in microseconds, on either kind of kernel -- only to choose between them.  The
+// prices follow the PLAN (abi.cpp plan_cost; measured on one MI355X, 1M rows: tools/scans/c3_pieces.py --spec=...,
+// tail_threshold.py, small_n.py, n_scan.py) -- with C3's prices for every plan (round 3) a state of lookup features only took the
+// lane <-> row kernel up to 128 groups and ran 32 bool columns at 0.58 ms (K = 128) and 0.87 (K = 64) where the tile pass
+// takes 0.34:
+//   tile kernels: one workgroup of 128 rows per CU and round; a round costs ~6 us + 0.45 a staged lookup feature + 0.012 a
+//   staged table row + 1.5 a nich feature (the role-split kernels overlap the two halves: half the nich share; the
+//   nich-only kernels 1.3 a feature); C3: 50 us a round of a scoring pass, 55 of a fused sweep; at most 128 groups on the
+//   role-split / nich-only kernels (PAIR mode, 256 rows a workgroup): kPairTileShare of that;
+//   lane <-> row kernel: a launch of g groups takes ~37 us + g (0.032 a lookup feature + 0.026 a nich feature) per round
+//   of 1024 rows a CU (two workgroups of 512); C3: 30 + 1.7 g.
+// (struct PlanCost: msc_internal.hpp -- the state keeps its plan's)
+inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep, const PlanCost &pc = PlanCost()) {
+  return (sweep ? pc.sweep_round_us : pc.tile_round_us) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
 }
-inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus) {
+inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus, const PlanCost &pc = PlanCost()) {
   const uint32_t widest = exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
   const uint32_t per = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
   const uint64_t rounds = (nrows + 1024ull * num_cus - 1) / (1024ull * num_cus);
-  return (double)nblk * (30.0 + 1.7 * per) * (double)(rounds ? rounds : 1);
+  return (double)nblk * (pc.tail_fixed_us + pc.tail_group_us * per) * (double)(rounds ? rounds : 1);
 }
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
 struct TailPlan {
+  PlanCost cost;              // the plan's prices (set whether or not the narrow kernel may take the plan)
   bool ok = false;
   bool exact = true;          // the tile kernels' bits (two sums per group: score passes, where the row count picks the kernel);
                               // false: one sum per group, faster (sweeps: the choice of kernel follows the bound view's row count, not the call's)

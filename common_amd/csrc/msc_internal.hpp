@@ -102,6 +102,12 @@ struct NichPlanInfo {                                    // per feature of the p
 //     every scoring / sweep call from the tables as they stand: ONE buffer, scalar offsets;
 //   * the x matrix: float [view rows][n2p], position-major inside a row -- a row's values of the second phase in one
 //     64-byte stretch (abi.cpp nich_x_matrix: built when the view is bound, cached on the view).
+// what a round of the tile kernels / a launch of the lane <-> row kernel costs for a plan, in microseconds (launchers.hpp
+// tile_rounds_us / tail_rows_us; abi.cpp plan_groups computes it): only to choose between the kernels
+struct PlanCost {
+  double tile_round_us = 50.0, sweep_round_us = 55.0;    // (C3's, until a plan says otherwise)
+  double tail_fixed_us = 30.0, tail_group_us = 1.7;
+};
 struct NichPos {                                         // (32-bit fields: a scalar load fetches no less)
   float xlim;
   uint32_t blk_ok;
@@ -436,6 +442,7 @@ struct msc_state {
   size_t tail_floats = 0;
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
+  msc::PlanCost plan_cost;            // plan_groups: what a round of the tile kernels / a launch of the lane <-> row kernel costs for THIS plan
   bool tile_nich_only = false;    // plan_groups: no first phase at all, two or more plain nich features (k_score_nich_pack)
   bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail_rows
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;   // the lookup tables of the tile plan's first phase: the largest, all together
