@@ -739,9 +739,12 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
       case MSC_BB:
       case MSC_BBNC: return 2;
       case MSC_NICH: return 6;
-      case MSC_DD: return std::min<uint32_t>(d.dim, 64);
+      // (a table up to the whole slot is staged -- on its own group if need be: a dd feature of 100 categories with 64 of
+      // them staged was a GENERIC feature to every tile kernel, 1.03 ms for four of them beside two nich columns on a
+      // million rows whatever K <= 256 is; staged whole they are lookup runs like any other)
+      case MSC_DD: return std::min<uint32_t>(d.dim, (uint32_t)kGrpRows);
       case MSC_GP:
-      case MSC_BNB: return std::min<uint32_t>(d.vcap, 64);
+      case MSC_BNB: return std::min<uint32_t>(d.vcap, (uint32_t)kGrpRows);
       // dm: all dim + 1 tables or none (small counts: tens of rows).  Read from L2 they cost 2 KiB per row and
       // stage -- 4 x dm(4) on 1M rows ran at the L2's bandwidth, 1.9 ms
       case MSC_DM: return d.dm_meta != nullptr && d.dm_rows <= (uint32_t)kGrpRows ? d.dm_rows : 0;

@@ -1522,8 +1522,10 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
   unsigned grid = 0;
   if (K <= k0 || K - k0 > kTailMaxGroups || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
   if (nrows == 0) return 0;
-  // launches of equal width: 44 groups = 48; 64 = 32 + 32 (48 + 16 measured 2 % slower); 128 = 48 + 48 + 32
-  const uint32_t groups = K - k0, widest = tp.exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
+  // launches of equal width; with two sums a group (exact) at most 32 groups a launch -- the 48-group instantiation holds 96
+  // sums a lane and costs a light plan 2.8x a 32-group launch (8 bb columns, 1M rows: K = 48 0.22 ms, K = 64 = 32 + 32 0.16;
+  // C3's 64 columns: 0.49 against 0.29 + 0.19) --, with one sum up to 64
+  const uint32_t groups = K - k0, widest = tp.exact ? 32u : 64u, nblk = (groups + widest - 1) / widest;
   const uint32_t blk = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
   for (uint32_t kb = k0; kb < K; kb += blk) {
     const uint32_t kend = std::min<uint32_t>(K, kb + blk), tgp = (kend - kb + 15u) / 16u * 16u;

@@ -79,7 +79,7 @@ inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep, const
   return (sweep ? pc.sweep_round_us : pc.tile_round_us) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
 }
 inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus, const PlanCost &pc = PlanCost()) {
-  const uint32_t widest = exact ? 48u : 64u, nblk = (groups + widest - 1) / widest;
+  const uint32_t widest = exact ? 32u : 64u, nblk = (groups + widest - 1) / widest;      // (as launch_score_tail cuts them)
   const uint32_t per = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
   const uint64_t rounds = (nrows + 1024ull * num_cus - 1) / (1024ull * num_cus);
   return (double)nblk * (pc.tail_fixed_us + pc.tail_group_us * per) * (double)(rounds ? rounds : 1);
