@@ -1791,17 +1791,18 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
   if ((size_t)rows * L * 16 > 64u * 1024u) return 0;
   // ... and only where it is the cheaper tiling for THIS plan (by the plan alone, not the call's rows: the narrow kernel
   // adds the features in the caller's order, the tile kernels in the plan's, so a state keeps one of them for all its rows).
-  // Per million rows, us, at 16 lanes a row (tools/scans/k_monotone.sh): a bb column 27 (the tile plan fuses four of them
-  // into one lookup, this tiling cannot), dd / gp 16, nich 32; against the tile kernels' rounds at the plan's price
-  // (launchers.hpp PlanCost; up to 128 groups the role-split / nich-only kernels run in PAIR mode).  32 bool columns at
-  // K = 64: 0.86 ms here, 0.30 on the tile kernel.
+  // Per million rows, us, at 16 lanes a row (tools/scans/grid_scan.py at 100k rows, k_monotone.sh): a bb column 30 (the tile
+  // plan fuses four of them into one lookup, this tiling cannot), dd / gp 50, nich 60, half of it at 8 lanes and no less at
+  // 4; against the tile kernels' rounds at the plan's price (launchers.hpp PlanCost; up to 128 groups the role-split /
+  // nich-only kernels run in PAIR mode).  32 bool columns at K = 64, 1M rows: 0.86 ms here, 0.30 on the tile kernel; 64 at
+  // K = 8, 100k rows: 0.10 against 0.04.
   {
     double us = 0;
     for (uint32_t f = 0; f < st->nfeat; f++) {
       const int fam = st->feats[f].family;
-      us += fam == MSC_BB || fam == MSC_BBNC ? 27.0 : fam == MSC_NICH ? 32.0 : fam == MSC_NOOP ? 0.0 : 16.0;
+      us += fam == MSC_BB || fam == MSC_BBNC ? 30.0 : fam == MSC_NICH ? 60.0 : fam == MSC_NOOP ? 0.0 : 50.0;
     }
-    us *= L / 16.0;
+    us *= std::max(L, 8) / 16.0;
     const bool pair = pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE, st->K, false);
     const double tile = st->plan_cost.tile_round_us * (1.0e6 / 128.0 / st->ctx->num_cus) * (pair ? kPairTileShare : 1.0);
     if (us > 1.25 * tile) return 0;
