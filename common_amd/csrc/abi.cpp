@@ -1767,7 +1767,7 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
   // sharded driver announced, so that a state keeps one kernel for all of a view's rows: the two add a row's features in
   // different orders).  At a million rows that kernel is 1.3-2.7x the faster one (tools/scans/k_monotone.sh, MSC_NO_NARROW:
   // sixteen dd32 columns at K = 32 0.34 -> 0.13 ms, 8 bb + 8 nich at K = 64 0.48 -> 0.26, sixteen nich at K = 32 0.30 -> 0.18);
-  // this tiling is for the small problems it was made for (C1: 10k rows, 8 us a pass).
+  // this tiling is for the small problems it was made for (C1: 10k rows, 8 us a pass): views below kNarrowMaxRows rows.
   {
     const uint64_t view_rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
     if (view_rows >= kNarrowMaxRows && st->tile_narrow_tail_ok && std::getenv("MSC_TAIL_MIN_ROWS") == nullptr) return 0;

@@ -1,5 +1,7 @@
 // launchers.hpp -- host entry points of the kernel translation units.
 #pragma once
+#include <algorithm>
+
 #include "msc_internal.hpp"
 
 namespace msc {
@@ -61,7 +63,8 @@ struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
 extern const Nich1Shape kNich1Shapes[kNich1NumShapes];
 constexpr uint32_t kTailMaxGroups = 128;
-constexpr uint64_t kNarrowMaxRows = 131072;  // views from this many rows on do not take the K <= 64 narrow tiling (abi.cpp narrow_lanes)
+constexpr uint64_t kNarrowMaxRows = 65536;   // views from this many rows on do not take the K <= 64 narrow tiling (abi.cpp narrow_lanes:
+                                             // at 100k rows its sweeps already cost 2.5x the lane <-> row kernel's, at 20k they are level)
 constexpr uint64_t kTailMinRows = 16384;     // fewer rows always stay with the tile kernels (lanes as groups)
 // What a pass over `nrows` rows costs, in microseconds, on either kind of kernel -- only to choose between them.  The
 // prices follow the PLAN (abi.cpp plan_cost; measured on one MI355X, 1M rows: tools/scans/c3_pieces.py --spec=...,
@@ -81,8 +84,11 @@ inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep, const
 inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus, const PlanCost &pc = PlanCost()) {
   const uint32_t widest = exact ? 32u : 64u, nblk = (groups + widest - 1) / widest;      // (as launch_score_tail cuts them)
   const uint32_t per = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
-  const uint64_t rounds = (nrows + 1024ull * num_cus - 1) / (1024ull * num_cus);
-  return (double)nblk * (pc.tail_fixed_us + pc.tail_group_us * per) * (double)(rounds ? rounds : 1);
+  // (a round of 1024 rows a CU that is not full costs its share -- the workgroups are 512 rows, most CUs get none -- but no
+  // launch is cheaper than ~a third of a round: 70k rows of sixteen dd columns took the tile kernels at 0.050 ms where this
+  // kernel takes 0.02-0.03)
+  const double rounds = std::max(0.3, (double)nrows / (1024.0 * num_cus));
+  return (double)nblk * (pc.tail_fixed_us + pc.tail_group_us * per) * rounds;
 }
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
 // first phase is lookup features only, the second plain nich features).  ok = false: no.
