@@ -722,7 +722,7 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
 // kGrpRows rows per group, never across the two phases.
 // what the choice of kernels depends on, for one plan
 struct PlanFacts {
-  bool roles_ok = false, nich_only = false, tail_ok = false, tail_masked_nich = false;
+  bool roles_ok = false, nich_only = false, lookups_only = false, tail_ok = false, tail_masked_nich = false;
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;
 };
 
@@ -799,6 +799,9 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
   pf.nich_only = (split == 0 && n >= 2) || (pf.roles_ok && !has_dm && split <= (uint32_t)kPackMaxLookups && n - split >= 2 * split &&
                                             std::getenv("MSC_NO_PACK_LOOKUPS") == nullptr);
   if (pf.nich_only) pf.roles_ok = false;
+  // staged lookup features and nothing else: k_score_lookups / k_sweep_lookups (sixteen lookup waves of 16 sums)
+  pf.lookups_only = split == n && n > 0 && !has_dm && std::getenv("MSC_NO_LOOKUPS_KERNEL") == nullptr;
+  for (uint32_t i = 0; i < n; i++) pf.lookups_only &= t[i].kind != MSC_KIND_GENERIC;
   // the lane <-> row kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase
   // (what it implements), whatever the second holds of plain nich features
   pf.tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
@@ -1073,6 +1076,7 @@ static int plan_groups(msc_state *st) {
   }
   st->tile_roles_ok = facts.roles_ok;
   st->tile_nich_only = facts.nich_only;
+  st->tile_lookups_only = facts.lookups_only;
   {
     // the prices the kernels are chosen by (launchers.hpp PlanCost): staged lookup features and table rows of the first
     // phase, nich features (the second phase's, and masked ones evaluated in the first)
@@ -1083,7 +1087,7 @@ static int plan_groups(msc_state *st) {
     }
     PlanCost pc;
     const double first = 6.0 + 0.45 * lookups + 0.012 * rows;
-    pc.tile_round_us = facts.nich_only ? 6.0 + 1.3 * nich + 3.0 * lookups : facts.roles_ok ? first + 0.75 * nich : first + 1.5 * nich;
+    pc.tile_round_us = facts.nich_only ? 6.0 + 1.3 * nich + 3.0 * lookups : facts.roles_ok ? first + 0.75 * nich : facts.lookups_only ? 0.75 * first : first + 1.5 * nich;
     pc.sweep_round_us = 1.1 * pc.tile_round_us;
     pc.tail_fixed_us = 37.0;
     pc.tail_group_us = 0.032 * lookups + 0.026 * nich;
@@ -1803,7 +1807,7 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
       us += fam == MSC_BB || fam == MSC_BBNC ? 30.0 : fam == MSC_NICH ? 60.0 : fam == MSC_NOOP ? 0.0 : 50.0;
     }
     us *= std::max(L, 8) / 16.0;
-    const bool pair = pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE, st->K, false);
+    const bool pair = pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : st->tile_lookups_only ? MSC_PATH_LOOKUPS : MSC_PATH_TILE, st->K, false);
     const double tile = st->plan_cost.tile_round_us * (1.0e6 / 128.0 / st->ctx->num_cus) * (pair ? kPairTileShare : 1.0);
     if (us > 1.25 * tile) return 0;
   }
@@ -1864,7 +1868,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
   if (n_niw < st->nfeat || crp) {
     bool has_dm = false;
     for (auto &h : st->feats) has_dm |= h.family == MSC_DM;
-    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE;
+    const int path = nich1 ? MSC_PATH_NICH1 : has_dm ? MSC_PATH_TILE_DM : st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : st->tile_lookups_only ? MSC_PATH_LOOKUPS : MSC_PATH_TILE;
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_fuse_dev;
     TailPlan tail;
     tail.cost = st->plan_cost;
@@ -2158,7 +2162,7 @@ static bool sweep_is_niw1(const msc_state *st) {
 // other tile kernels', so every row range of a view takes the same one
 static bool sweep_pair_mode(const msc_state *st) {
   const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
-  return rows >= kTailMinRows && pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : MSC_PATH_TILE, st->K, false);
+  return rows >= kTailMinRows && pair_mode_ok(st->tile_roles_ok ? MSC_PATH_TILE_ROLES : st->tile_nich_only ? MSC_PATH_NICH_PACK : st->tile_lookups_only ? MSC_PATH_LOOKUPS : MSC_PATH_TILE, st->K, false);
 }
 static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
   const uint64_t rows = st->sweep_rows_hint ? st->sweep_rows_hint : st->bound_view ? st->bound_view->nrows : 0;
@@ -2269,8 +2273,8 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
           not_zeroed = true;                              // (nothing emptied the additive tables on the way)
         } else if (rc == 1) rc = -2;
       }
-      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
-    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+      if (rc == -2) rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->tile_lookups_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
+    } else rc = launch_sweep_mixed(s, cus, has_dm, st->tile_roles_ok, sweep_pair_mode(st), st->tile_nich_only, st->tile_lookups_only, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0, z_dev, st->own, st->logpc, st->rng_dev, zero);
     if (zeroed) *zeroed = rc == 0 && !not_zeroed;
   }
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior

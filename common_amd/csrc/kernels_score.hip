@@ -879,6 +879,89 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 }
 
 // ---------------------------------------------------------------------------
+// k_score_lookups: a state of staged lookup features ONLY (bb / gp / dd / bnb columns, none masked beyond the folded kind:
+// a mixture of categoricals and counts).  k_score_tile gives such a plan sixteen waves of 8 rows -- its registers are
+// sized for the nich phase it does not have --; here every wave is a lookup wave of 16 sums (16 rows, or -- PAIR, at most
+// 128 groups -- 32), so a staged feature group serves 256 (512) rows: half (a quarter of) the table copies and barriers a
+// row.  prior lo + lookups in plan order + prior hi: k_score_tile's sums for such a plan, same bits.
+// ---------------------------------------------------------------------------
+template <bool LOO, bool CRP, bool PAIR>
+__global__ __launch_bounds__(1024, 4) void k_score_lookups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
+                                                            uint64_t nrows, const int32_t *__restrict__ z, const float *__restrict__ own,
+                                                            const float *__restrict__ crp, float *__restrict__ out, uint64_t ld) {
+  constexpr int R = kRoleRows, RW = PAIR ? 2 * kRoleRows : kRoleRows;
+  __shared__ float4 lds[kGrpRows * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t kb = PAIR ? (uint32_t)lane * 2u : blockIdx.y * kGroupTile + lane * 4;
+  const bool vec_ok = PAIR ? ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)
+                           : ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const uint64_t rows_per_wg = 16 * RW;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * RW;        // relative to row0
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+    float4 acc[R];
+    int single = 0;
+    if (LOO && CRP && lane < nr) {
+      const int g0 = z[rb + lane];
+      single = g0 >= 0 && (uint32_t)g0 < K && __builtin_isinf(crp[kpad + g0]) ? 1 : 0;
+    }
+    if (CRP) {
+      const float4 hi0 = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
+      const float4 lo = PAIR ? pair_dup(ld2(crp + crp_lo_cnt(kpad) + kb)) : ld4(crp + crp_lo_cnt(kpad) + kb);
+      const float e0 = crp[2 * (size_t)kpad + 2], e1 = crp[2 * (size_t)kpad + 3];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if constexpr (PAIR)
+          acc[r] = crp_prior_pair_lo(make_float2(hi0.x, hi0.y), make_float2(lo.x, lo.y), LOO && lane_bcast(single, 2 * r) ? e1 : e0,
+                                     LOO && lane_bcast(single, 2 * r + 1) ? e1 : e0);
+        else acc[r] = crp_prior4_lo(hi0, lo, LOO && lane_bcast(single, r) ? e1 : e0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
+    }
+    score_tile_groups<R, 16, false, false, PAIR>(feats, nfeat, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc);
+    // the rows' finish: + hi of the prior (fetched again: an L2 hit per chunk, not held across the lookups), the
+    // leave-one-out entry in registers, the stores
+    float4 hi = make_float4(0, 0, 0, 0);
+    float le0 = 0, le1 = 0;
+    if (CRP) {
+      const float *again = crp;
+      asm volatile("" : "+s"(again));
+      hi = PAIR ? pair_dup(ld2(again + kb)) : ld4(again + kb);
+      le0 = again[2 * (size_t)kpad], le1 = again[2 * (size_t)kpad + 1];
+    }
+    int gz = -1;
+    float sloo = 0.f;
+    if (LOO && lane < nr) {
+      gz = z[rb + lane];
+      sloo = own[rb + lane];
+    }
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if constexpr (PAIR) {
+        if (CRP)
+          add4(acc[r], crp_prior_pair(make_float2(hi.x, hi.y), LOO && lane_bcast(single, 2 * r) ? le1 : le0,
+                                      LOO && lane_bcast(single, 2 * r + 1) ? le1 : le0));
+        if (LOO)
+          replace_own_pair(acc[r], lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+        if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, K, acc[r].x, acc[r].y, vec_ok);
+        if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, K, acc[r].z, acc[r].w, vec_ok);
+      } else {
+        if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
+        if (LOO) {
+          const int g = lane_bcast(gz, r);
+          if (g >= 0) replace_own(acc[r], kb, g, lane_bcast(sloo, r));
+        }
+        if (r < nr) store_row(out, ld, rb + r, kb, K, acc[r], vec_ok);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_score_nich_pack: a state of plain nich features only (two or more: a mixture of independent Gaussians per dimension).
 // The tile plan has no first phase then, and what the role-split kernels' nich waves do needs neither the table slot nor
 // a barrier: here ALL sixteen waves of a workgroup are such waves -- 16 rows each (32 in PAIR mode, at most 128 groups),
@@ -1106,7 +1189,7 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
 // PAIR mode of the role-split kernels: one k-tile of at most 128 groups, rows enough for the role-split kernels at all
 bool pair_mode_ok(int path, uint32_t K, bool few_rows) {
   static const bool off = std::getenv("MSC_NO_PAIR") != nullptr;     // (A/B knob)
-  return !off && (path == MSC_PATH_TILE_ROLES || path == MSC_PATH_NICH_PACK) && tile_roles_enabled() && K <= 128 && !few_rows;
+  return !off && (path == MSC_PATH_TILE_ROLES || path == MSC_PATH_NICH_PACK || path == MSC_PATH_LOOKUPS) && tile_roles_enabled() && K <= 128 && !few_rows;
 }
 bool tile_roles_enabled() {
   static const bool on = [] {
@@ -1621,6 +1704,12 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (path == MSC_PATH_TILE_DM)
       hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
+    else if (path == MSC_PATH_LOOKUPS && pair)
+      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 511) / 512, cap), 1), dim3(1024), 0, stream,
+                         feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
+    else if (path == MSC_PATH_LOOKUPS && !small4)
+      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, false>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), grid.y), dim3(1024), 0, stream,
+                         feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (pair && path == MSC_PATH_NICH_PACK)
     {
       const dim3 g((unsigned)std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)), 1);

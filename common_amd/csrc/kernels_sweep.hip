@@ -1176,6 +1176,78 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep_lookups: the fused assignment step of a state of staged lookup features only (kernels_score.hip k_score_lookups):
+// sixteen lookup waves of 16 sums -- 16 rows, or 32 in PAIR mode -- a workgroup; prior + lookups, the leave-one-out entry,
+// the draw.  K <= 256; PAIR: K <= 128.
+// ---------------------------------------------------------------------------
+template <bool PAIR>
+__global__ __launch_bounds__(1024, 4) void k_sweep_lookups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
+                                                            uint64_t nrows, uint64_t row_id0, int32_t *__restrict__ z,
+                                                            const float *__restrict__ own, const float *__restrict__ crp,
+                                                            const uint64_t *__restrict__ rng, ZeroSpans zero) {
+  constexpr int R = 16, RW = PAIR ? 32 : 16;
+  const uint64_t seed = rng[0], sweep = rng[1];
+  zero_spans(zero);
+  __shared__ float4 lds[kGrpRows * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t kb = PAIR ? lane * 2 : lane * 4;
+  const uint64_t rows_per_wg = 16 * RW;
+  const uint64_t nchunks = (nrows + rows_per_wg - 1) / rows_per_wg;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * RW;
+    const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+    int gz = -1;
+    float sloo = 0.f;
+    float4 acc[R];
+    {
+      const float4 logcnt = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
+      const float le0 = crp[2 * (size_t)kpad], le1 = crp[2 * (size_t)kpad + 1];
+      float erow = le0;                                   // (a row that is its group's only member leaves one more empty group)
+      if (lane < nr) {
+        gz = z[rb + lane];
+        if ((uint32_t)gz >= K) gz = -1;                   // (an id outside the table: not assigned)
+        if (gz >= 0) {
+          sloo = own[rb + lane];
+          if (__builtin_isinf(crp[kpad + gz])) erow = le1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        acc[r] = PAIR ? crp_prior_pair(make_float2(logcnt.x, logcnt.y), lane_bcast(erow, 2 * r), lane_bcast(erow, 2 * r + 1))
+                      : crp_prior4(logcnt, lane_bcast(erow, r));
+    }
+    score_tile_groups<R, 16, false, false, PAIR>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
+    const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
+    int znew = gz;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float4 s4 = acc[r];
+      if constexpr (PAIR) {
+        replace_own_pair(s4, lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
+        float sa[2] = {s4.x, s4.y}, sb[2] = {s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          if (kb + j >= K) sa[j] = sb[j] = -INFINITY;
+        const int pa = sample_from_scores<2>(sa, lane_bcast(u01, 2 * r), lane, K);
+        const int pb = sample_from_scores<2>(sb, lane_bcast(u01, 2 * r + 1), lane, K);
+        if (lane == 2 * r) znew = pa;
+        if (lane == 2 * r + 1) znew = pb;
+      } else {
+        const int g = lane_bcast(gz, r);
+        if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
+        float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kb + j >= K) sc[j] = -INFINITY;
+        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        if (lane == r) znew = pick;
+      }
+    }
+    if (lane < nr) z[rb + lane] = znew;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_sweep_nich_pack: the fused assignment step of a state of plain nich features only (kernels_score.hip
 // k_score_nich_pack, where the why is written down): sixteen nich waves a workgroup, no LDS, no barrier; nich sums + prior,
 // the leave-one-out entry, the draw.  K <= 256; PAIR: K <= 128, two groups a lane, 32 rows a wave.
@@ -1745,7 +1817,7 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, bool lookups_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
@@ -1763,6 +1835,12 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   if (has_dm)
     hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
+  else if (lookups_only && pair && K <= 128)
+    hipLaunchKernelGGL((k_sweep_lookups<true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 511) / 512, cap))), dim3(1024), 0, stream,
+                       feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+  else if (lookups_only && !small && !pair)
+    hipLaunchKernelGGL((k_sweep_lookups<false>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap))), dim3(1024), 0, stream,
+                       feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   else if (nich_only && pair && K <= 128)                 // (PAIR follows the view's rows, whatever this call's are: see below)
   {
     const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves))));

@@ -57,7 +57,7 @@ int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_d
 // which scoring kernel a state takes (abi.cpp decides from its feature list)
 // (TILE_ROLES: a tile state whose first phase is lookup runs only and whose second phase is not empty -- with enough
 // rows its workgroups split the phases between their waves, k_score_tile_roles)
-enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TILE_ROLES = 3, MSC_PATH_NICH_PACK = 4 };
+enum { MSC_PATH_NICH1 = 0, MSC_PATH_TILE = 1, MSC_PATH_TILE_DM = 2, MSC_PATH_TILE_ROLES = 3, MSC_PATH_NICH_PACK = 4, MSC_PATH_LOOKUPS = 5 };
 // k_score_nich1 launch shapes: a wave visits `visits` blocks of q consecutive rows (index 0 = the default)
 struct Nich1Shape { int q, visits; };
 constexpr int kNich1NumShapes = 8;
@@ -138,7 +138,7 @@ constexpr int kNichPackWaves = MSC_NICH_PACK_WAVES;   // waves a workgroup of th
 constexpr int kPackMaxLookups = 4;                      // lookup features (after fusing the bool columns) a plan may hold and still take the nich-only kernels
 constexpr int kNichPackNC = MSC_NICH_PACK_NC;          // groups of the lane a block part of the nich-only kernels takes (256 registers a wave there)
 constexpr double kPairTileShare = 0.62;     // what a pass of the role-split kernels costs in PAIR mode (<= 128 groups), of a full tile pass
-int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
+int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, bool lookups_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero);
 int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,

@@ -443,6 +443,7 @@ struct msc_state {
   float *own = nullptr;           // per-row leave-one-out values (k_loo_own)
   bool tile_roles_ok = false;     // plan_groups: lookup runs only before tile_split, unmasked nich features after it
   msc::PlanCost plan_cost;            // plan_groups: what a round of the tile kernels / a launch of the lane <-> row kernel costs for THIS plan
+  bool tile_lookups_only = false;     // plan_groups: staged lookup features and nothing else (k_score_lookups)
   bool tile_nich_only = false;    // plan_groups: no first phase at all, two or more plain nich features (k_score_nich_pack)
   bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail_rows
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;   // the lookup tables of the tile plan's first phase: the largest, all together

@@ -352,6 +352,7 @@ def test_niw_every_kernel_by_dimension(gpu_ctx, dim, K):
 BITS_PLANS = {
     "mixed": [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 7), (orc.NICH, 0), (orc.BB, 0), (orc.NICH, 0)],
     "nich_only": [(orc.NICH, 0)] * 5,       # (no first phase at all: k_score_nich_pack, every wave a nich wave; blocks of 3 + 2)
+    "lookups_only": [(orc.BB, 0)] * 5 + [(orc.DD, 9), (orc.GP, 0), (orc.BB, 0), (orc.DD, 70)],   # (k_score_lookups: every wave a lookup wave)
 }
 
 
@@ -360,8 +361,8 @@ BITS_PLANS = {
 def test_a_rows_score_is_the_same_bits_from_every_tile_kernel(gpu_ctx, K, plan):
     """40k rows take the kernel whose waves split the lookup and the nich phase between them (k_score_tile_roles; up to 128
     groups in its PAIR mode: two groups a lane, two rows a float4 of sums) -- a state of plain nich features alone the one
-    whose waves are all nich waves (k_score_nich_pack) --, a few hundred rows the ones that run the phases one after the
-    other: (prior + lookups) + (nich) in all of them, so the same row must come out bit for bit -- plain, leave-one-out,
+    whose waves are all nich waves (k_score_nich_pack), one of staged lookup features alone the one whose waves are all
+    lookup waves (k_score_lookups) --, a few hundred rows the ones that run the phases one after the other: (prior + lookups) + (nich) in all of them, so the same row must come out bit for bit -- plain, leave-one-out,
     with the prior"""
     import common_amd
     rng = np.random.default_rng(K)

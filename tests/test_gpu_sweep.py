@@ -563,6 +563,14 @@ def test_sweep_of_a_nich_only_state_matches_oracle_and_its_shards(gpu_ctx, K, em
     _pair_sweep_case(gpu_ctx, [(orc.NICH, 0)] * 6, K, empty)
 
 
+@pytest.mark.parametrize("K,empty", [(100, 7), (128, 0), (200, 30), (256, 1)])
+def test_sweep_of_a_lookups_only_state_matches_oracle_and_its_shards(gpu_ctx, K, empty):
+    """a state of staged lookup features alone (a mixture of categoricals and counts) with rows enough: the fused step on
+    k_sweep_lookups -- every wave a lookup wave of 16 sums; up to 128 groups in PAIR mode -- against the oracle's sweep, and
+    three shards of the view draw what the whole draws"""
+    _pair_sweep_case(gpu_ctx, [(orc.BB, 0)] * 5 + [(orc.DD, 9), (orc.GP, 0), (orc.BB, 0), (orc.DD, 70)], K, empty)
+
+
 @pytest.mark.parametrize("K,empty", [(65, 0), (100, 20), (127, 3), (128, 1)])
 def test_sweep_in_pair_mode_matches_oracle_and_its_shards(gpu_ctx, K, empty):
     """65 .. 128 groups and rows enough for the role-split kernels (40k; no kernel forced): k_sweep_tile_roles<0, PAIR> -- a
