@@ -1089,8 +1089,8 @@ static int plan_groups(msc_state *st) {
     const double first = 6.0 + 0.45 * lookups + 0.012 * rows;
     pc.tile_round_us = facts.nich_only ? 6.0 + 1.3 * nich + 3.0 * lookups : facts.roles_ok ? first + 0.75 * nich : facts.lookups_only ? 0.75 * first : first + 1.5 * nich;
     pc.sweep_round_us = 1.1 * pc.tile_round_us;
-    pc.tail_fixed_us = 37.0;
-    pc.tail_group_us = 0.032 * lookups + 0.026 * nich;
+    pc.tail_fixed_us = 2.0;                                  // (per launch and round of 1024 rows a CU: tools/scans/grid_scan.py at 1M rows,
+    pc.tail_group_us = 0.5 + 0.03 * lookups + 0.057 * nich;  //  K = 8 against K = 32 for six feature lists; C3: 2 + 2.5 a group)
     st->plan_cost = pc;
   }
   st->tile_narrow_tail_ok = facts.tail_ok;

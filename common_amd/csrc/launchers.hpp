@@ -75,8 +75,8 @@ constexpr uint64_t kTailMinRows = 16384;     // fewer rows always stay with the 
 //   staged table row + 1.5 a nich feature (the role-split kernels overlap the two halves: half the nich share; the
 //   nich-only kernels 1.3 a feature); C3: 50 us a round of a scoring pass, 55 of a fused sweep; at most 128 groups on the
 //   role-split / nich-only kernels (PAIR mode, 256 rows a workgroup): kPairTileShare of that;
-//   lane <-> row kernel: a launch of g groups takes ~37 us + g (0.032 a lookup feature + 0.026 a nich feature) per round
-//   of 1024 rows a CU (two workgroups of 512); C3: 30 + 1.7 g.
+//   lane <-> row kernel: a launch of g groups takes ~2 us + g (0.5 + 0.03 a lookup feature + 0.057 a nich feature) per round
+//   of 1024 rows a CU (two workgroups of 512); C3: 2 + 2.5 g (round 3 priced it 30 + 1.7 g: the same at 32-48 groups).
 // (struct PlanCost: msc_internal.hpp -- the state keeps its plan's)
 inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep, const PlanCost &pc = PlanCost()) {
   return (sweep ? pc.sweep_round_us : pc.tile_round_us) * (double)((workgroups + (uint64_t)num_cus - 1) / (uint64_t)num_cus);
@@ -84,10 +84,10 @@ inline double tile_rounds_us(uint64_t workgroups, int num_cus, bool sweep, const
 inline double tail_rows_us(uint32_t groups, bool exact, uint64_t nrows, int num_cus, const PlanCost &pc = PlanCost()) {
   const uint32_t widest = exact ? 32u : 64u, nblk = (groups + widest - 1) / widest;      // (as launch_score_tail cuts them)
   const uint32_t per = ((groups + nblk - 1) / nblk + 15u) / 16u * 16u;
-  // (a round of 1024 rows a CU that is not full costs its share -- the workgroups are 512 rows, most CUs get none -- but no
-  // launch is cheaper than ~a third of a round: 70k rows of sixteen dd columns took the tile kernels at 0.050 ms where this
-  // kernel takes 0.02-0.03)
-  const double rounds = std::max(0.3, (double)nrows / (1024.0 * num_cus));
+  // (a round of 1024 rows a CU that is not full costs less than a whole one -- the workgroups are 512 rows, most CUs get
+  // none -- but not in proportion: sixteen dd columns, two exact launches: 0.066 ms at 262k rows, 0.050 at 100k, ~0.04 at 70k)
+  const double frac = (double)nrows / (1024.0 * num_cus);
+  const double rounds = frac >= 1.0 ? frac : std::max(0.6, 0.4 + 0.6 * frac);      // (100k rows, 0.38 of a round: 0.75 of its price)
   return (double)nblk * (pc.tail_fixed_us + pc.tail_group_us * per) * rounds;
 }
 // narrow_tail: score a partly filled last tile (<= kTailMaxGroups groups) with the narrow kernel, k_score_tail_rows (abi.cpp: the plan's
