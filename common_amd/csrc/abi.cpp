@@ -2313,7 +2313,9 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   }
   if (rc == -2) {
     // generic shape: score a chunk of rows (leave-one-out + prior) into scratch, then sample it
-    const uint64_t ld = st->kpad;
+    // (rows of K rounded up to 64 floats, not of the padded table width: at K = 300 the chunk is 320 wide, not 512 --
+    // neither the score kernels nor the sampler touch a row beyond K)
+    const uint64_t ld = std::min<uint64_t>(st->kpad, ((uint64_t)st->K + 63) & ~63ull);
     // Up to 4 GiB of scores per chunk (288 GB of HBM: the scratch is not what runs out): fewer and larger launches beat
     // keeping the chunk cache-resident (single nich, 1M rows x 300 groups, 32 / 64 / 128 / 256 / 512 MiB: 1.88 / 1.55 /
     // 1.28 / 1.13 / 1.05 ms), a state with niw features wants >= 4 waves per SIMD on its MFMA kernel, and the
