@@ -2280,7 +2280,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
   // 256 < K <= 384 on a role-split state: the groups beyond the tile from the narrow kernel (leave-one-out value and prior
   // included) into 64 or 128 floats per row, then the fused kernel over the tile draws over both -- nothing materialised
   // but that.  Where it pays (sweep_rows_pays: by the view's row count, so that a shard draws from the same bits as the whole).
-  if (rc == -2 && !nich1 && !has_dm && st->tile_roles_ok && st->tile_narrow_tail_ok && tile_roles_enabled() && st->K > 256 &&
+  if (rc == -2 && !nich1 && !has_dm && (st->tile_roles_ok || st->tile_nich_only || st->tile_lookups_only) && st->tile_narrow_tail_ok && tile_roles_enabled() && st->K > 256 &&
       st->K <= (uint32_t)kGroupTile + kTailMaxGroups && std::getenv("MSC_NO_FUSED_TAIL") == nullptr &&
       sweep_rows_pays(st, st->K - kGroupTile)) {
     const uint64_t tail_ld = st->K <= (uint32_t)kGroupTile + 64 ? 64 : 128;
@@ -2305,7 +2305,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       tail.exact = false;                                  // (nothing else scores these groups for a draw: one sum per group)
       if (launch_score_tail(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad,
                             kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld) == 0) {
-        rc = launch_sweep_roles_tail(s, cus, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0,
+        rc = launch_sweep_roles_tail(s, cus, st->tile_roles_ok ? 0 : st->tile_nich_only ? 1 : 2, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0,
                                      z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);
         if (zeroed) *zeroed = rc == 0;
       }

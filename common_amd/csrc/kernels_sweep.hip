@@ -1180,11 +1180,16 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
 // sixteen lookup waves of 16 sums -- 16 rows, or 32 in PAIR mode -- a workgroup; prior + lookups, the leave-one-out entry,
 // the draw.  K <= 256; PAIR: K <= 128.
 // ---------------------------------------------------------------------------
-template <bool PAIR>
+// TAILP = 1, 2 (not PAIR): 256 < K <= 320, 384 -- the groups beyond the tile scored by k_score_tail_rows into `tail`, 64 TAILP
+// floats a row, and drawn over together with the tile (k_sweep_tile_roles has the same)
+template <bool PAIR, int TAILP = 0>
 __global__ __launch_bounds__(1024, 4) void k_sweep_lookups(const FeatDesc *__restrict__ feats, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
                                                             uint64_t nrows, uint64_t row_id0, int32_t *__restrict__ z,
                                                             const float *__restrict__ own, const float *__restrict__ crp,
-                                                            const uint64_t *__restrict__ rng, ZeroSpans zero) {
+                                                            const uint64_t *__restrict__ rng, ZeroSpans zero, const float *__restrict__ tail = nullptr) {
+  static_assert(!PAIR || TAILP == 0, "PAIR mode: one tile of at most 128 groups");
+  constexpr bool TAIL = TAILP > 0;
+  constexpr int TL = 16 * (TAIL ? TAILP : 1);
   constexpr int R = 16, RW = PAIR ? 32 : 16;
   const uint64_t seed = rng[0], sweep = rng[1];
   zero_spans(zero);
@@ -1219,6 +1224,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_lookups(const FeatDesc *__res
     score_tile_groups<R, 16, false, false, PAIR>(feats, nfeat, kpad, 0, lane, row0 + rb, nr, row0, lds, acc);
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
+    [[maybe_unused]] float4 t4[4];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float4 s4 = acc[r];
@@ -1236,10 +1242,28 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_lookups(const FeatDesc *__res
         const int g = lane_bcast(gz, r);
         if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
         float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+        int pick;
+        if constexpr (TAIL) {
+          if ((r & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (kb + j >= K) sc[j] = -INFINITY;
-        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+            for (int j = 0; j < 4; j++) {
+              uint64_t tr = rb + (uint64_t)(r + j);
+              tr = tr < nrows ? tr : nrows - 1;
+              t4[j] = gld4(as_global(tail) + tr * (uint64_t)(4 * TL) + 4 * (lane % TL));
+            }
+          }
+          const float4 tq = t4[r & 3];
+          float st[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (lane >= TL || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
+          pick = sample_tile_and_tail<TAIL ? TAILP : 1>(sc, st, lane_bcast(u01, r), lane, K);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (kb + j >= K) sc[j] = -INFINITY;
+          pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        }
         if (lane == r) znew = pick;
       }
     }
@@ -1252,11 +1276,14 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_lookups(const FeatDesc *__res
 // k_score_nich_pack, where the why is written down): sixteen nich waves a workgroup, no LDS, no barrier; nich sums + prior,
 // the leave-one-out entry, the draw.  K <= 256; PAIR: K <= 128, two groups a lane, 32 rows a wave.
 // ---------------------------------------------------------------------------
-template <bool PAIR, bool LOOK>
+template <bool PAIR, bool LOOK, int TAILP = 0>
 __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sweep_nich_pack(const FeatDesc *__restrict__ feats, int nsplit, uint32_t K, uint32_t kpad, uint64_t row0,
                                                               uint64_t nrows, uint64_t row_id0, int32_t *__restrict__ z,
                                                               const float *__restrict__ own, const float *__restrict__ crp,
-                                                              const uint64_t *__restrict__ rng, ZeroSpans zero) {
+                                                              const uint64_t *__restrict__ rng, ZeroSpans zero, const float *__restrict__ tail = nullptr) {
+  static_assert(!PAIR || TAILP == 0, "PAIR mode: one tile of at most 128 groups");
+  constexpr bool TAIL = TAILP > 0;                       // (256 < K <= 384: the groups beyond the tile from `tail`, as k_sweep_tile_roles)
+  constexpr int TL = 16 * (TAIL ? TAILP : 1);
   constexpr int R = 16, RW = PAIR ? 32 : 16;
   const uint64_t seed = rng[0], sweep = rng[1];
   zero_spans(zero);
@@ -1298,6 +1325,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
     const float erow = (gz >= 0 && __builtin_isinf(prior[kpad + (gz >= 0 ? gz : 0)])) ? le1 : le0;   // (its group's only member: one more empty group)
     const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
     int znew = gz;
+    [[maybe_unused]] float4 t4[4];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float4 s4 = acc[r];
@@ -1321,10 +1349,28 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
         const int g = lane_bcast(gz, r);
         if (g >= 0) replace_own(s4, kb, g, lane_bcast(sloo, r));
         float sc[4] = {s4.x, s4.y, s4.z, s4.w};
+        int pick;
+        if constexpr (TAIL) {
+          if ((r & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (kb + j >= K) sc[j] = -INFINITY;
-        const int pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+            for (int j = 0; j < 4; j++) {
+              uint64_t tr = rb + (uint64_t)(r + j);
+              tr = tr < nrows ? tr : nrows - 1;
+              t4[j] = gld4(as_global(tail) + tr * (uint64_t)(4 * TL) + 4 * (lane % TL));
+            }
+          }
+          const float4 tq = t4[r & 3];
+          float st[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (lane >= TL || (uint32_t)kGroupTile + 4 * (uint32_t)lane + j >= K) st[j] = -INFINITY;
+          pick = sample_tile_and_tail<TAIL ? TAILP : 1>(sc, st, lane_bcast(u01, r), lane, K);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (kb + j >= K) sc[j] = -INFINITY;
+          pick = sample_from_scores<4>(sc, lane_bcast(u01, r), lane, K);
+        }
         if (lane == r) znew = pick;
       }
     }
@@ -1882,12 +1928,32 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
 
 // 256 < K <= 384 (abi.cpp decides on the bound view's row count, so that a shard draws from the same bits as the whole): the role-split kernel
 // over the full tile, the tail's scores from `tail` (k_score_tail_rows wrote them)
-int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+// (kind: 0 the role-split kernel, 1 the nich-only kernel -- with a few lookups when nsplit > 0 --, 2 the lookups-only kernel)
+int launch_sweep_roles_tail(hipStream_t stream, int num_cus, int kind, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                             uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
                             const float *crp, const uint64_t *rng, ZeroSpans zero, const float *tail) {
   uint64_t gx = (nrows + 127) / 128;
   const uint64_t cap = (uint64_t)num_cus * 4;
   if (gx > cap) gx = cap;
+  const bool wide = K > (uint32_t)kGroupTile + 64;
+  if (kind == 2) {
+    const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap)));
+    if (!wide) hipLaunchKernelGGL((k_sweep_lookups<false, 1>), g, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    else hipLaunchKernelGGL((k_sweep_lookups<false, 2>), g, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  if (kind == 1) {
+    const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves))));
+    const dim3 b(kNichPackWaves * 64);
+    if (nsplit > 0) {
+      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 1>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      else hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 2>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    } else {
+      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 1>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      else hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 2>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (K <= (uint32_t)kGroupTile + 64)
     hipLaunchKernelGGL(k_sweep_tile_roles<1>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
                        row0, nrows, row_id0, z, own, crp, rng, zero, tail);

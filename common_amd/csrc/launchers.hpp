@@ -141,7 +141,7 @@ constexpr double kPairTileShare = 0.62;     // what a pass of the role-split ker
 int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_ok, bool pair, bool nich_only, bool lookups_only, const FeatDesc *feats_dev, int nfeat, int nsplit,
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero);
-int launch_sweep_roles_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+int launch_sweep_roles_tail(hipStream_t stream, int num_cus, int kind, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                             uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own,
                             const float *crp, const uint64_t *rng, ZeroSpans zero, const float *tail);
 int sweep_niw1_max_groups(uint32_t dim);

@@ -143,6 +143,15 @@ MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint3
     else *reinterpret_cast<f32x4 *>(p) = v;
   } else if (kb < K) {
     const uint32_t rem = K - kb;
+    // (rows that start on 8 but not on 16 bytes -- a caller's [N, K] matrix with K = 350 --: two 8-byte stores, not four
+    // 4-byte ones: the scoring pass of such a matrix ran at twice the time of its neighbours K = 320 / 384)
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    if (rem >= 4 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+      const f32x2s a = {s.x, s.y}, b = {s.z, s.w};
+      *reinterpret_cast<f32x2s *>(p) = a;
+      *reinterpret_cast<f32x2s *>(p + 2) = b;
+      return;
+    }
     p[0] = s.x;
     if (rem > 1) p[1] = s.y;
     if (rem > 2) p[2] = s.z;

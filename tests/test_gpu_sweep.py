@@ -499,8 +499,17 @@ def test_large_and_small_mixed_sweeps_draw_the_same_assignments(gpu_ctx):
     assert (whole.cpu().numpy() != z).mean() > 0.05
 
 
+TAIL_PLANS = {
+    "mixed": [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 9), (orc.NICH, 0), (orc.BB, 0), (orc.BNB, 0)],
+    "lookups_only": [(orc.BB, 0), (orc.GP, 0), (orc.DD, 9), (orc.BB, 0), (orc.BNB, 0)],      # (k_sweep_lookups<false, 1 | 2>)
+    "nich_only": [(orc.NICH, 0)] * 3,                                                        # (k_sweep_nich_pack<false, false, 1 | 2>)
+    "mostly_nich": [(orc.DD, 9)] + [(orc.NICH, 0)] * 4,                                      # (k_sweep_nich_pack<false, true, 1 | 2>)
+}
+
+
+@pytest.mark.parametrize("plan", sorted(TAIL_PLANS))
 @pytest.mark.parametrize("K,empty", [(257, 0), (300, 3), (320, 40), (321, 0), (350, 5), (384, 70)])
-def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty, monkeypatch):
+def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K, empty, plan, monkeypatch):
     """256 < K <= 384 on a state of lookup + nich features: the groups beyond the first tile are scored by the narrow kernel
     (k_score_tail_rows: 64 or 128 floats per row, leave-one-out value and prior included) and the role-split sweep kernel
     draws over tile + tail (k_sweep_tile_roles<1 | 2>, sample_tile_and_tail) -- for every row range of a view.  Against the oracle's sweep
@@ -508,7 +517,7 @@ def test_fused_sweep_with_a_narrow_tail_matches_oracle_and_its_shards(gpu_ctx, K
     same sweep in three shards draws the same assignments."""
     import common_amd
     monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "1")            # (3000 and 20k rows here; the library's own mark: ~770 rows a tail group)
-    specs = [(orc.BB, 0), (orc.GP, 0), (orc.NICH, 0), (orc.DD, 9), (orc.NICH, 0), (orc.BB, 0), (orc.BNB, 0)]
+    specs = TAIL_PLANS[plan]
     got, want, scores, z = _run(gpu_ctx, specs, 3000, K, seed=40 + K, sweep_idx=2, alpha=0.8, empty=empty)
     assert (z >= 256).any() or K - empty <= 256
     _check_agreement(got, want, scores, 40 + K, 2, 0.995)
