@@ -586,6 +586,29 @@ def extra_c3(a, torch, common_amd, ctx):
                       "sweep_rows_per_s": N / (sw_avg * 1e-3)})
         del o2, s2
     r["other_table_sizes"] = other
+    # other feature lists on the same rows (not BASELINE configs; the kernels round 4 added for them): categoricals only
+    # (k_score_lookups), independent Gaussians only (k_score_nich_pack), mostly Gaussians (the same with a few lookups from L2)
+    del view
+    plans = []
+    BB, NICH = common_amd.BB, common_amd.NICH
+    for name, sp in (("32 bb", [(BB, 0)] * 32), ("16 nich", [(NICH, 0)] * 16), ("8 bb + 8 nich", [(BB, 0)] * 8 + [(NICH, 0)] * 8)):
+        cols2, z3 = make_columns(ctx, sp, N, K, 79)
+        v2 = common_amd.DataView.from_tensors(ctx, cols2)
+        s3 = common_amd.State(ctx, sp, K)
+        s3.set_alpha(1.0)
+        s3.accumulate(v2, z3)
+        o3 = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
+        _, sc_avg, _ = timed(torch, lambda: s3.score_value(v2, out=o3), max(3, steps // 2), 2)
+        zz3, it3 = z3.clone(), [0]
+
+        def step3():
+            s3.sweep_step(v2, zz3, seed=79, sweep=it3[0])
+            it3[0] += 1
+        _, sw_avg, _ = timed(torch, step3, max(3, steps // 2), 2)
+        plans.append({"features": name, "K": K, "score_ms": sc_avg, "sweep_ms": sw_avg, "evals_per_s": float(N) * K * len(sp) / (sc_avg * 1e-3),
+                      "sweep_rows_per_s": N / (sw_avg * 1e-3)})
+        del o3, s3, v2, cols2
+    r["other_feature_lists"] = plans
     return r
 
 
