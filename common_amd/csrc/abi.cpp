@@ -1088,7 +1088,7 @@ static int plan_groups(msc_state *st) {
     PlanCost pc;
     const double first = 6.0 + 0.45 * lookups + 0.012 * rows;
     pc.tile_round_us = facts.nich_only ? 6.0 + 1.3 * nich + 3.0 * lookups : facts.roles_ok ? first + 0.75 * nich : facts.lookups_only ? 0.75 * first : first + 1.5 * nich;
-    pc.sweep_round_us = 1.1 * pc.tile_round_us;
+    pc.sweep_round_us = pc.tile_round_us + 2.5;              // (+ the draws)
     pc.tail_fixed_us = 2.0;                                  // (per launch and round of 1024 rows a CU: tools/scans/grid_scan.py at 1M rows,
     pc.tail_group_us = 0.5 + 0.03 * lookups + 0.057 * nich;  //  K = 8 against K = 32 for six feature lists; C3: 2 + 2.5 a group)
     st->plan_cost = pc;
@@ -2178,7 +2178,11 @@ static bool sweep_rows_pays(const msc_state *st, uint32_t groups) {
     tile_us = tile_rounds_us(c128, cus, false, st->plan_cost) + sample_us;                    // one more tile pass, then the sampler over K floats a row
   } else {
     if (groups > 64) rows_us += sample_us;
-    tile_us = tile_rounds_us(c128, cus, true, st->plan_cost) * (sweep_pair_mode(st) ? kPairTileShare : 1.0);
+    // (a fused sweep round = the scoring round -- its PAIR share up to 128 groups -- + the draws, which do not shrink with the
+    // plan or the mode: ~2.5 us a round; 8 bb columns at K = 64: 0.18 ms in PAIR mode, 0.10 on the lane <-> row kernel)
+    PlanCost pc = st->plan_cost;
+    pc.sweep_round_us = pc.tile_round_us * (sweep_pair_mode(st) ? kPairTileShare : 1.0) + 2.5;
+    tile_us = tile_rounds_us(c128, cus, true, pc);
   }
   return rows_us < tile_us;
 }
