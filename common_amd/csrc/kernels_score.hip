@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_sco
     }
     if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     float4 acc[R];
-    const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
+    const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes and idle waves)
     [[maybe_unused]] float4 accl[LOOK ? R : 1];
     if constexpr (LOOK) {
 #pragma unroll

@@ -1294,6 +1294,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)wave * RW;
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+    if (nr == 0) continue;                                // (wave-uniform; nothing in this kernel waits for another wave)
     // (across the nich phase only the row's group and its leave-one-out value stay in registers -- the phase has the 4 R
     // sums, a block's constants and nothing to spare: with the prior's terms and the uniform held too the PAIR
     // instantiation spilled 403 registers and ran 1.04 ms where the scoring kernel takes 0.45)
@@ -1305,7 +1306,7 @@ __global__ __launch_bounds__(kNichPackWaves * 64, kNichPackWaves / 4) void k_swe
       if (gz >= 0) sloo = own[rb + lane];
     }
     float4 acc[R];
-    const uint64_t myrow = row0 + (lane < nr ? rb + lane : rb);
+    const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes and idle waves)
     [[maybe_unused]] float4 accl[LOOK ? R : 1];
     if constexpr (LOOK) {                                   // a first phase of a few lookup features: prior + lookups, from L2
       const float4 lc = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);

@@ -119,3 +119,81 @@ def test_random_sweeps_draw_the_oracles_assignments(gpu_ctx, seed):
     K = int(rng.choice([2, 17, 40, 64, 256, 300]))
     got, want, scores, _ = _run(gpu_ctx, spec, N, K, seed=300 + seed, sweep_idx=seed % 5, alpha=0.9, empty=min(2, K - 1))
     _check_agreement(got, want, scores, 300 + seed, seed % 5, 0.98)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MSC_FUZZ_ROWS_SEEDS", "16"))))
+def test_random_scalar_feature_lists_on_many_rows(gpu_ctx, seed):
+    """The kernels a plan takes when the rows fill the chip -- role-split, nich-only (with or without a few lookups from L2),
+    lookups-only, each in PAIR mode up to 128 groups, the lane <-> row kernel, the fused tail -- chosen by the plan's prices:
+    random lists of scalar families (some columns masked), 33k-70k rows, 40-384 groups.  A sample of rows against the oracle
+    (plain and leave-one-out + prior), slices of a few hundred rows -- the kernels that run the phases one after the other
+    -- bit for bit equal to the whole, and a sweep in three shards equal to the whole's."""
+    import common_amd
+    rng = np.random.default_rng(7000 + seed)
+    fams = [orc.BB, orc.BB, orc.GP, orc.BNB, orc.DD, orc.NICH, orc.NICH, orc.BBNC]
+    kind = seed % 4                                              # 0 mixed, 1 lookups only, 2 nich only, 3 mostly nich
+    nf = int(rng.integers(2, 14))
+    spec = []
+    for i in range(nf):
+        fam = fams[int(rng.integers(0, len(fams)))]
+        if kind == 1 and fam == orc.NICH:
+            fam = orc.GP
+        if kind == 2 or (kind == 3 and i >= 2):
+            fam = orc.NICH
+        spec.append((fam, int(rng.choice([2, 9, 33, 100])) if fam == orc.DD else 0))
+    N = int(rng.choice([33_000, 50_000, 70_000]))
+    K = int(rng.choice([40, 64, 100, 128, 200, 256, 300, 384]))
+    feats = [make_feature(f, N, K, rng, d) for f, d in spec]
+    z = rng.integers(0, K, N).astype(np.int32)
+    z[7] = -1
+    masked = [kind == 0 and f["family"] != orc.NICH and rng.random() < 0.2 for f in feats]       # (masked lookup columns keep the fast kernels)
+    dev = gpu_ctx.torch_device
+    cols = [torch.from_numpy(np.ascontiguousarray(f["values"])).to(dev) for f in feats]
+    rowmask = [(rng.random(N) < 0.2) if m else np.zeros(N, dtype=bool) for m in masked]
+    mts = [torch.from_numpy(m.astype(np.uint8)).to(dev) if mk else None for m, mk in zip(rowmask, masked)]
+    view = common_amd.DataView.from_tensors(gpu_ctx, cols, mts)
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    fs = []
+    for f, m in zip(feats, rowmask):
+        F = orc.Family(f["family"], f["hp"], f["dim"], "f64")
+        init = None
+        if f["family"] == orc.BBNC:
+            init = np.zeros(K, dtype=orc.ss_dtype(orc.BBNC, 0, "f64"))
+            init["p"] = np.random.default_rng(K).uniform(0.05, 0.95, K).astype(np.float32)
+        ss32 = orc.narrow_ss(f["family"], F.accumulate(K, f["values"], np.where(m, -1, z).astype(np.int32), ss_init=init), f["dim"])
+        fs.append((F, orc.widen_ss(f["family"], ss32, f["dim"]), ss32))
+    load_state(st, fs)
+    cnt = np.bincount(z[z >= 0], minlength=K).astype(np.uint32)
+    st.set_group_counts(cnt)
+    st.set_alpha(1.3)
+    zt = torch.from_numpy(z).to(dev)
+    rows = np.unique(np.concatenate([[0, 7, N - 1], rng.choice(N, 200, replace=False)]))
+
+    def twin(zz):
+        total, mag = None, None
+        for f, m, (F, ss64, _) in zip(feats, rowmask, fs):
+            sc = F.score_matrix(ss64, f["values"][rows], None if zz is None else np.where(m, -1, zz).astype(np.int32)[rows])
+            sc[m[rows]] = 0.0
+            total = sc if total is None else total + sc
+            mag = np.maximum(1.0, np.abs(sc)) if mag is None else mag + np.maximum(1.0, np.abs(sc))
+        return total, mag
+    plain = st.score_value(view)
+    want, mag = twin(None)
+    audit("fuzz_rows.sum_of_features", (np.abs(plain.cpu().numpy()[rows] - want) / mag).max(), TOL)
+    both = st.score_value(view, z=zt, crp_prior=True)
+    want, mag = twin(z)
+    want = want + crp_prior_matrix(cnt, 1.3, z[rows])
+    audit("fuzz_rows.sum_of_features_loo_prior", (np.abs(both.cpu().numpy()[rows] - want) / np.maximum(mag, np.abs(want))).max(), TOL)
+    for row0, n in ((0, 300), (N // 2 + 3, 129), (N - 70, 70)):
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n]), (seed, spec, K, row0)
+        assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True), both[row0:row0 + n]), (seed, spec, K, row0)
+    whole = zt.clone()
+    st.sweep_assign(view, whole, seed=11, sweep=2)
+    parts = zt.clone()
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        zs = parts[lo:lo + n].contiguous()
+        st.sweep_assign(view, zs, seed=11, sweep=2, row0=lo, nrows=n, row_id0=lo)
+        parts[lo:lo + n] = zs
+    assert torch.equal(whole, parts), (seed, spec, K)
+    w = whole.cpu().numpy()
+    assert w.min() >= 0 and w.max() < K
