@@ -198,3 +198,26 @@ def test_random_scalar_feature_lists_on_many_rows(gpu_ctx, seed):
     assert torch.equal(whole, parts), (seed, spec, K)
     w = whole.cpu().numpy()
     assert w.min() >= 0 and w.max() < K
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MSC_FUZZ_ROWS_SWEEP_SEEDS", "8"))))
+def test_random_sweeps_on_many_rows_draw_the_oracles_assignments(gpu_ctx, seed):
+    """the same kinds of feature lists, 33k-40k rows: one fused assignment step against the oracle's sweep -- every
+    disagreeing draw on a CDF step -- on whichever kernel the plan's prices pick"""
+    from tests.test_gpu_sweep import _check_agreement, _run
+    rng = np.random.default_rng(9000 + seed)
+    fams = [orc.BB, orc.BB, orc.GP, orc.BNB, orc.DD, orc.NICH, orc.NICH, orc.BBNC]
+    kind = seed % 4                                              # 0 mixed, 1 lookups only, 2 nich only, 3 mostly nich
+    spec = []
+    for i in range(int(rng.integers(2, 10))):
+        fam = fams[int(rng.integers(0, len(fams)))]
+        if kind == 1 and fam == orc.NICH:
+            fam = orc.GP
+        if kind == 2 or (kind == 3 and i >= 2):
+            fam = orc.NICH
+        spec.append((fam, int(rng.choice([2, 9, 33])) if fam == orc.DD else 0))
+    N = 33_000 + int(rng.integers(0, 7000))
+    K = int(rng.choice([40, 64, 100, 128, 200, 256, 300, 384])) - int(rng.integers(0, 3))
+    empty = int(rng.integers(0, max(1, K // 8)))
+    got, want, scores, z = _run(gpu_ctx, spec, N, K, seed=900 + seed, sweep_idx=3, alpha=0.9, empty=empty)
+    _check_agreement(got, want, scores, 900 + seed, 3, 0.995)
