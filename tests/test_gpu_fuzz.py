@@ -185,7 +185,8 @@ def test_random_scalar_feature_lists_on_many_rows(gpu_ctx, seed):
     want, mag = twin(z)
     want = want + crp_prior_matrix(cnt, 1.3, z[rows])
     audit("fuzz_rows.sum_of_features_loo_prior", (np.abs(both.cpu().numpy()[rows] - want) / np.maximum(mag, np.abs(want))).max(), TOL)
-    for row0, n in ((0, 300), (N // 2 + 3, 129), (N - 70, 70)):
+    big0 = int(rng.integers(1, N // 3))                          # (a large range off the view's start: the same kernels, another row0)
+    for row0, n in ((0, 300), (N // 2 + 3, 129), (N - 70, 70), (big0, N - big0 - int(rng.integers(0, 200)))):
         assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n]), (seed, spec, K, row0)
         assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True), both[row0:row0 + n]), (seed, spec, K, row0)
     whole = zt.clone()
