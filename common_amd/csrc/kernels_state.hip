@@ -574,12 +574,18 @@ __global__ __launch_bounds__(256) void k_fuse_tables(const FeatDesc *__restrict_
         for (uint32_t j = blockIdx.x + 1; j < fd.blk_end; j++) same &= __float_as_uint(feats[j].tab[(size_t)NICH_C1LN2 * kpad + k]) == mine;
       }
     }
-    __shared__ float s_s[256], s_b[256];
-    s_s[threadIdx.x] = smax;
-    s_b[threadIdx.x] = bmax;
+    // (maxima over the block: across a wave by shuffles, the four waves through LDS -- thread 0 walking 256 LDS entries one
+    // after the other was 10 of this kernel's 18 us, at the head of every scoring / sweep call)
+    __shared__ float s_s[4], s_b[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      smax = fmaxf(smax, __shfl_xor(smax, off));
+      bmax = fmaxf(bmax, __shfl_xor(bmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) s_s[threadIdx.x >> 6] = smax, s_b[threadIdx.x >> 6] = bmax;
     const int all_fine = __syncthreads_and(fine ? 1 : 0), all_same = __syncthreads_and(same ? 1 : 0);
     if (threadIdx.x == 0) {
-      for (int i = 1; i < 256; i++) smax = fmaxf(smax, s_s[i]), bmax = fmaxf(bmax, s_b[i]);
+      for (int i = 1; i < 4; i++) smax = fmaxf(smax, s_s[i]), bmax = fmaxf(bmax, s_b[i]);
       const float xlim = (all_fine && bmax < kNichFarA) ? (kNichFarA - bmax) / smax : -1.f;
       fd.nich_info->xlim = xlim;
       fd.nich_info->blk_ok = (leads && all_same) ? 1u : 0u;
