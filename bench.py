@@ -79,21 +79,40 @@ def cpu_baseline(K, sample_rows):
     }
 
 
-def pmc_entry(kernel_substr, key):
-    """(value per launch, file) of `key` for the kernel from the newest committed PMC summary (profiles/*_pmc.json,
-    written by tools/summarize_prof.py from separate rocprofv3 --pmc passes)."""
+class PmcLookupError(RuntimeError):
+    pass
+
+
+def pmc_entry(kernel, key):
+    """(value per launch, file) of counter `key` for the kernel INSTANTIATION `kernel` -- the exact name, as the library reports
+    it (Context.last_kernel) and rocprofv3 spells it, e.g. "k_score_tile_roles<false, false, false>" -- from the newest
+    committed PMC summary that holds it (profiles/*_pmc.json, written by tools/summarize_prof.py from separate rocprofv3
+    --pmc passes).  (None, None) when no committed summary has that instantiation; PmcLookupError when a summary holds it
+    more than once -- never a neighbouring instantiation's counters (round 4 matched by substring and printed the PAIR
+    kernel's instruction count for C3: VERDICT r04)."""
     import glob
+    want = kernel if kernel.startswith("msc::") else "msc::" + kernel
     best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        for name, e in d.items():
-            if kernel_substr in name and key in e:
-                v = e[key]
-                best = (v["total"] if "total" in v else v["avg"], os.path.basename(f))
+        hits = [e for name, e in d.items() if name.replace("void ", "").strip() == want and key in e]
+        if len(hits) > 1:
+            raise PmcLookupError("%s holds %d entries named %s" % (f, len(hits), want))
+        if hits:
+            v = hits[0][key]
+            best = (v["total"] if "total" in v else v["avg"], os.path.basename(f))
     return best
+
+
+def traffic_of(kernel, alg_bytes):
+    """{"traffic": HBM bytes per launch from the committed counters (corrected as MI355X_MICROARCH.md prescribes), "traffic_ratio":
+    traffic / algorithmic bytes, "traffic_source": file} for the kernel instantiation, or traffic None"""
+    t, src = pmc_entry(kernel, "hbm_bytes_per_launch")
+    return {"traffic": t, "traffic_ratio": (t / alg_bytes) if (t is not None and alg_bytes) else None, "traffic_source": src,
+            "traffic_kernel": kernel}
 
 
 def timed(torch, fn, steps, warmup):
@@ -270,30 +289,33 @@ def sweep_kernel_ms(torch, st, view, z, steps=20):
     of z -- outside the timed region; the rocprof summary in profiles/ must agree"""
     zc = z.clone()
     _, avg, mn = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), steps, 5)
-    return avg, mn
+    return avg, mn, st.ctx.last_kernel("sweep")
 
 
 def sweep_roofline(nrows, K, kern_ms, kernel):
+    """`kernel`: the instantiation the library launched (Context.last_kernel("sweep")), e.g. "k_sweep_nich1_t<16>" """
     evals = float(nrows) * K
     alg_bytes = 12.0 * nrows                                  # SURVEY 8d: x, z in, z out
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    # (the committed counters are per launch of this very shape: <16> = K 1024 on the 12.5 M-row shard, <4> = C2)
-    insts, src = pmc_entry(kernel + ("<16>" if K == C5_GROUPS else "<4>"), "SQ_INSTS_VALU")
+    # (the committed counters are per launch of this very shape and instantiation: <16> = K 1024 on the 12.5 M-row shard,
+    # <4> = C2's 1M rows; other row counts get no counter-derived figure)
+    standard = (nrows, K) in ((C5_ROWS_PER_RANK, C5_GROUPS), (1_000_000, 256))
+    insts, src = pmc_entry(kernel, "SQ_INSTS_VALU") if standard else (None, None)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": pmc_entry(kernel + "<16>", "hbm_bytes_per_launch")[0] if (nrows, K) == (C5_ROWS_PER_RANK, C5_GROUPS) else None,
          "kernel": kernel, "kernel_avg_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
          "note": "the fused sweep materialises nothing: 12 B per row of HBM traffic, so HBM is not what binds it "
                  "(SURVEY 8d: transcendental / vector issue rate); valu_issue = SQ_INSTS_VALU of the committed PMC pass "
                  "over this run's kernel time, against one wave instruction per SIMD per 4 cycles",
          "evals_per_s": evals / (kern_ms * 1e-3)}
-    if insts is not None and (nrows, K) in ((C5_ROWS_PER_RANK, C5_GROUPS), (1_000_000, 256)):
+    r.update(traffic_of(kernel, alg_bytes) if standard else {"traffic": None})
+    if insts is not None:
         # SQ_INSTS_VALU counts wave instructions; the roof is one per SIMD every 4 cycles
         r["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "achieved": insts / (kern_ms * 1e-3),
                            "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
                            "frac": insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK}
         # SQ_ACTIVE_INST_VALU counts the 4-cycle slots the vector ALUs were held (a transcendental holds two): the same
         # roof with every instruction at its own issue cost
-        busy, _ = pmc_entry(kernel + ("<16>" if K == C5_GROUPS else "<4>"), "SQ_ACTIVE_INST_VALU")
+        busy, _ = pmc_entry(kernel, "SQ_ACTIVE_INST_VALU")
         if busy is not None:
             r["valu_issue"]["busy_slots_per_launch"] = busy
             r["valu_issue"]["busy_frac"] = busy / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
@@ -344,7 +366,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_
     devices = [None] * world
     dist.all_gather_object(devices, "%s cuda:%d %s" % (os.uname().nodename, ctx.device,
                                                         torch.cuda.get_device_properties(ctx.device).name))
-    kern_ms, kern_min = sweep_kernel_ms(torch, st, view, z)
+    kern_ms, kern_min, kern_name = sweep_kernel_ms(torch, st, view, z)
     # every rank holds the same tables after the exchange: group sizes sum to the global row count
     total = int(st.get_group_counts().astype("int64").sum())
     assert total == nrows * world, (total, nrows * world)
@@ -377,7 +399,7 @@ def run_c5(a, torch, dist, common_amd, ctx, world, rank, backend, sync_all, one_
         "note": "weak_scaling_eff = value / (n_gpus * one_rank_reference.value); the N = 1 line reports the same one-rank "
                 "workload as c5_shard, its own `value` is the C2 scoring pass (evals/s), the metric BASELINE.json quotes "
                 "for one GPU",
-        "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t"),
+        "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, kern_name),
     }
 
 
@@ -420,7 +442,9 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     precondition = 200
     for _ in range(precondition + a.warmup):
         st.score_value(view, out=out)
-    launched = 1 + precondition + a.warmup + (7 * 8 if a.tune else 0)   # launches of the headline kernel so far (for the trace summary)
+    # launches of the headline kernel so far (for the trace summary): msc_score_tune times seven shapes x eight passes and then
+    # non-temporal against plain stores with the winning shape, 2 x 7 more
+    launched = 1 + precondition + a.warmup + (7 * 8 + 2 * 7 if a.tune else 0)
 
     def region(buf, steps):
         """HIP events over the timed region, on the stream the library launches on: ONE pair around the launches (a
@@ -436,6 +460,7 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
         sync_all()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
     dt, kern_avg_ms = region(out, a.steps)
+    headline_kernel = ctx.last_kernel("score")              # the instantiation the timed region ran, as rocprofv3 spells it
     timed_from = launched
     launched += a.steps
     long_region = None
@@ -460,15 +485,17 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
     evals = float(N) * K
     alg_bytes = 4.0 * N + 4.0 * N * K          # 4.016 B per eval for C2
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_entry("k_score_nich1", "hbm_bytes_per_launch")
+    traffic, traffic_src = pmc_entry(headline_kernel, "hbm_bytes_per_launch")
     # the same pass into a caller-owned torch.empty (what a caller gets who does not ask the library for the matrix)
     caller = None
+    if "stores" in placement:                               # (what the library did, not what the probe's figure suggests)
+        placement["stores"] = "non-temporal" if headline_kernel.endswith("true>") else "plain"
     if a.alloc != "torch":
         tbuf = torch.empty((N, K), dtype=torch.float32, device=dev)
         for _ in range(50):
             st.score_value(view, out=tbuf)
         _, c_ms = region(tbuf, max(200, min(a.steps, 500)))
-        caller = {"allocator": "torch.empty", "stores": "plain", "kernel_avg_ms": c_ms, "achieved": alg_bytes / (c_ms * 1e-3) / 1e9,
+        caller = {"allocator": "torch.empty", "stores": "plain", "kernel": ctx.last_kernel("score"), "kernel_avg_ms": c_ms, "achieved": alg_bytes / (c_ms * 1e-3) / 1e9,
                   "frac": alg_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del tbuf
     line = {
@@ -487,8 +514,9 @@ def run_c2(a, torch, dist, common_amd, ctx, sync_all):
                      "frac": achieved / HBM_PEAK_GBS,
                      "frac_caller_alloc": caller["frac"] if caller else None, "caller_alloc": caller,
                      "traffic": traffic if (N, K) == (1_000_000, 256) else None,
+                     "traffic_ratio": (traffic / alg_bytes) if (traffic is not None and (N, K) == (1_000_000, 256)) else None,
                      "traffic_source": traffic_src,
-                     "kernel": "k_score_nich1", "kernel_avg_ms": kern_avg_ms,
+                     "kernel": headline_kernel, "kernel_avg_ms": kern_avg_ms,
                      "timed_region_launches": [timed_from, timed_from + a.steps],   # of this kernel, in launch order
 
                      "kernel_min_ms_single_launch_events": kern_ms[0], "algorithmic_bytes_per_launch": alg_bytes,
@@ -523,10 +551,10 @@ def c2_sweep(a, torch, common_amd, ctx, st, view, z):
         idx[0] += 1
     steps = max(1, min(a.steps, 100))
     wall_ms, avg, mn = timed(torch, one, steps, min(20, steps))
-    kern_ms, _ = sweep_kernel_ms(torch, st, view, zs)
+    kern_ms, _, kern_name = sweep_kernel_ms(torch, st, view, zs)
     return {"metric": "Gibbs-sweep rows/sec", "value": N / (wall_ms * 1e-3), "unit": "rows/s",
-            "ms_per_sweep": wall_ms, "steps": steps, "kernel": "k_sweep_nich1_t", "kernel_avg_ms": kern_ms,
-            "roofline": sweep_roofline(N, st.K, kern_ms, "k_sweep_nich1_t"),
+            "ms_per_sweep": wall_ms, "steps": steps, "kernel": kern_name, "kernel_avg_ms": kern_ms,
+            "roofline": sweep_roofline(N, st.K, kern_ms, kern_name),
             "includes": "leave-one-out score + CRP prior + sample (fused, nothing materialised), accumulate, "
                         "commit + prepare; one rank: no exchange (msc_sweep_step)"}
 
@@ -543,18 +571,29 @@ def extra_c3(a, torch, common_amd, ctx):
     out = torch.empty((N, K), dtype=torch.float32, device=ctx.torch_device)
     steps = max(3, min(a.steps, 20))
     wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out), steps, 10)
+    kern = ctx.last_kernel("score")                          # "k_score_tile_roles<false, false, false>"
     rowbytes = sum(c.element_size() * (c.shape[1] if c.dim() > 1 else 1) for c in cols)
     alg = float(N) * rowbytes + 4.0 * N * K
-    insts, src = pmc_entry("k_score_tile", "SQ_INSTS_VALU")
+
+    def valu(kernel, ms):
+        """vector-issue figures of the kernel instantiation from the committed counters, over this run's time"""
+        insts, src = pmc_entry(kernel, "SQ_INSTS_VALU")
+        if insts is None:
+            return {"error": "no committed counters for %s" % kernel}
+        v = {"kernel": kernel, "wave_insts_per_launch": insts, "source": src, "peak": VALU_ISSUE_PEAK,
+             "achieved": insts / (ms * 1e-3), "frac": insts / (ms * 1e-3) / VALU_ISSUE_PEAK, "unit": "wave-instructions/s"}
+        busy, _ = pmc_entry(kernel, "SQ_ACTIVE_INST_VALU")
+        if busy is not None:
+            v["busy_slots_per_launch"] = busy
+            v["busy_frac"] = busy / (ms * 1e-3) / VALU_ISSUE_PEAK
+        return v
     r = {"workload": "C3 mixed bb+gp+dd32+nich x16, N=1M, K=256, D=64, scoring pass", "ms": avg, "ms_min": mn,
-         "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": "k_score_tile_roles",
+         "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": kern,
          "roofline": {"bound": "hbm", "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
                       "note": "not what binds it (SURVEY 8d): vector issue rate, see valu_issue"}}
-    if insts is not None:
-        r["roofline"]["valu_issue"] = {"wave_insts_per_launch": insts, "source": src, "peak": VALU_ISSUE_PEAK,
-                                       "achieved": insts / (avg * 1e-3), "frac": insts / (avg * 1e-3) / VALU_ISSUE_PEAK,
-                                       "unit": "wave-instructions/s"}
+    r["roofline"].update(traffic_of(kern, alg))
+    r["roofline"]["valu_issue"] = valu(kern, avg)
     st.set_alpha(1.0)
     zs = z.clone()
     idx = [0]
@@ -565,6 +604,15 @@ def extra_c3(a, torch, common_amd, ctx):
     w, savg, smn = timed(torch, one, max(3, steps // 2), 1)
     r["sweep_ms"] = savg
     r["sweep_rows_per_s"] = N / (savg * 1e-3)
+    # the fused assignment kernel of the step alone (leave-one-out pass, accumulate and commit are the step's other launches)
+    zc = zs.clone()
+    _, kavg, _ = timed(torch, lambda: st.sweep_assign(view, zc, seed=11, sweep=0), max(3, steps // 2), 2)
+    skern = ctx.last_kernel("sweep")                         # "k_sweep_tile_roles<0, false>"
+    salg = float(N) * (rowbytes + 8.0)                       # N (rowbytes + 4 + 4): the rows, z in, z out
+    r["sweep"] = {"kernel": skern, "assign_ms": kavg, "note": "assign = k_loo_own_lds + this kernel; step = assign + k_accumulate + commit",
+                  "roofline": dict({"bound": "hbm", "achieved": salg / (kavg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": salg / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": salg,
+                                    "valu_issue": valu(skern, kavg)}, **traffic_of(skern, salg))}
     # the same columns at other table sizes (a CRP table is not a multiple of 256): at most 128 groups and the groups
     # beyond a tile up to 384 run on the lane <-> row kernel (k_score_tail_rows), whose cost follows the groups
     del out, st
@@ -632,31 +680,36 @@ def extra_c4(a, torch, common_amd, ctx):
     nb = (d + 15) // 16
     executed = flops * (nb + 1) / (2.0 * nb)    # blocks on or below the diagonal of the triangular factor (3/4 at dim 32)
 
-    def leg(f32, peak, kernel):
+    def leg(f32, peak):
         wall, avg, mn = timed(torch, lambda: st.score_value(view, out=out, niw_f32=f32), steps, 10)
+        kernel = ctx.last_kernel("score")                    # "k_score_niw64<2, 4, false, false>" / "k_score_niw<2, false, false>"
         tf = flops / (avg * 1e-3) / 1e12
         busy, src = pmc_entry(kernel, "SQ_VALU_MFMA_BUSY_CYCLES")
-        waves_cycles, _ = pmc_entry(kernel, "SQ_BUSY_CYCLES")
+        cycles, _ = pmc_entry(kernel, "GRBM_GUI_ACTIVE")
         r = {"ms": avg, "ms_min": mn, "kernel": kernel, "tflops_survey_count": tf, "peak": peak, "unit": "TFLOP/s",
              "frac_survey_count": tf / peak,
              "frac_executed": (executed if not f32 else flops) / (avg * 1e-3) / 1e12 / peak,
              "flops_executed_per_launch": executed if not f32 else flops}
-        if busy is not None and waves_cycles:
-            r["mfma_busy"] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "source": src,
-                              "note": "committed PMC pass of this kernel; busy cycles / (4 SIMDs x 256 CUs x kernel cycles) in DESIGN.md section 5"}
+        r.update(traffic_of(kernel, 4.0 * d * N + 4.0 * N * K))
+        if busy is not None:
+            # (counters of a COMMITTED profile of this instantiation -- profiles/<source>, its tag names the round --, not of
+            # this run: GRBM_GUI_ACTIVE sums the eight XCDs' busy cycles, the matrix pipe's over 4 SIMDs x 256 CUs)
+            r["mfma_busy"] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": cycles, "source": src,
+                              "frac": (busy / (1024.0 * cycles / 8.0)) if cycles else None,
+                              "note": "committed PMC pass of this instantiation; busy cycles / (4 SIMDs x 256 CUs x kernel cycles)"}
         return r
-    f64 = leg(False, MFMA_F64_PEAK_TF, "k_score_niw64")
+    f64 = leg(False, MFMA_F64_PEAK_TF)
     ref = out.clone()
-    f32 = leg(True, MFMA_F32_PEAK_TF, "k_score_niw")
+    f32 = leg(True, MFMA_F32_PEAK_TF)
     # what the f32 pipe costs in accuracy, against the f64 kernel's own output on the same state (the f64 kernel is the
     # one held to the twin at 1e-6: tests/test_gpu_score.py)
     diff = (out - ref).abs() / ref.abs().clamp_min(1.0)
     f32["max_rel_err_vs_f64_kernel"] = float(diff.max().item())
     return {"workload": "C4 NIW dim=32, N=256k, K=128, scoring pass", "ms": f64["ms"], "ms_min": f64["ms_min"],
-            "evals_per_s": float(N) * K / (f64["ms"] * 1e-3), "kernel": "k_score_niw64",
+            "evals_per_s": float(N) * K / (f64["ms"] * 1e-3), "kernel": f64["kernel"],
             "roofline": {"bound": "mfma", "achieved": f64["tflops_survey_count"], "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
                          "frac": f64["frac_survey_count"], "frac_executed": f64["frac_executed"],
-                         "algorithmic_flops_per_launch": flops,
+                         "algorithmic_flops_per_launch": flops, "traffic": f64["traffic"], "traffic_ratio": f64["traffic_ratio"],
                          "note": "frac counts flops as SURVEY 8d does (2 d^2 per pair); the kernel skips the zero "
                                  "upper-right block of the triangular factor and executes 3/4 of them: frac_executed"},
             "f64": f64, "f32": f32}
@@ -673,11 +726,11 @@ def extra_c5(a, torch, common_amd, ctx):
         idx[0] += 1
     steps = max(3, min(a.steps, 20))
     wall_ms, avg, mn = timed(torch, one, steps, 5)
-    kern_ms, _ = sweep_kernel_ms(torch, st, view, z)
+    kern_ms, _, kern_name = sweep_kernel_ms(torch, st, view, z)
     return {"workload": "C5 shard: NICH %d rows x K=%d, one rank's sweep step (no exchange at one rank)" % (nrows, C5_GROUPS),
             "metric": "Gibbs-sweep rows/sec", "value": nrows / (wall_ms * 1e-3), "unit": "rows/s", "ms_per_sweep": wall_ms,
             "evals_per_s": float(nrows) * C5_GROUPS / (wall_ms * 1e-3),
-            "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, "k_sweep_nich1_t")}
+            "roofline": sweep_roofline(nrows, C5_GROUPS, kern_ms, kern_name)}
 
 
 if __name__ == "__main__":

@@ -41,6 +41,7 @@ _SIGS = {
     "msc_abi_version": (C.c_int, []),
     "msc_last_error": (C.c_char_p, []),
     "msc_build_info": (C.c_char_p, []),
+    "msc_last_kernel": (C.c_char_p, [C.c_int]),
     "msc_context_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "msc_context_destroy": (C.c_int, [C.c_void_p]),
     "msc_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

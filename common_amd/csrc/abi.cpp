@@ -59,6 +59,7 @@ using namespace msc;
 // library / context
 // ---------------------------------------------------------------------------
 extern "C" int msc_abi_version(void) { return MSC_ABI_VERSION; }
+extern "C" const char *msc_last_kernel(int which) { return msc::last_kernel(which); }
 extern "C" const char *msc_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char *msc_build_info(void) {
   return "microscopes_hip abi " "1" " gfx950 (CDNA4) hipcc " __VERSION__;
@@ -341,7 +342,9 @@ static int alloc_placed(msc_context *ctx, size_t nbytes, uint32_t max_candidates
   if (bufs[best].vmm) ctx->vmm.push_back(bufs[best].v);
   ctx->last_alloc_rates = rate;
   ctx->last_alloc_chosen = (uint32_t)best;
-  ctx->placed.push_back(msc_context::Placed{bufs[best].p, nbytes, max_candidates > 1 && rate[best] >= kNtFastGbps});
+  // (the stores' mark follows the accept mark when a caller lowers that one -- MSC_ALLOC_ACCEPT_GBPS: the evidence runs of
+  // tools/profile_round.sh trace the non-temporal instantiation on boxes without a fast stretch that way)
+  ctx->placed.push_back(msc_context::Placed{bufs[best].p, nbytes, max_candidates > 1 && rate[best] >= std::min(kNtFastGbps, accept_gbps)});
   if (rates_gbps)
     for (uint32_t i = 0; i < max_candidates; i++) rates_gbps[i] = i < rate.size() ? rate[i] : 0.f;
   if (chosen) *chosen = (uint32_t)best;
@@ -356,14 +359,14 @@ extern "C" int msc_device_alloc(msc_context *ctx, size_t nbytes, void **out) {
   MSC_HIP(hipSetDevice(ctx->device));
   // MSC_ALLOC_CANDIDATES (default 12; 1 = no probing, 0 = plain hipMalloc) / MSC_ALLOC_ACCEPT_GBPS (default 6650: a
   // candidate that fills at 6.7 TB/s takes the C2 pass at 0.87-0.88 of the HBM roof, one at 6.5 at 0.83-0.87, one at 6.2
-  // at 0.80-0.83; when none reaches the mark the best of all is kept, ~1 ms a candidate and GB) / MSC_ALLOC_FLAT_AFTER
-  // (default 6: candidates after which a box whose rates all lie within 6 % is taken to have no fast stretch).
+  // at 0.80-0.83; when none reaches the mark the best of all is kept, ~1 ms a candidate and GB); after six candidates
+  // whose rates all lie within 6 % the box is taken to have no fast stretch.
   // Candidates held side by side walk through physical memory, and where the fast stretches lie differs from box to
   // box: one box offered one within six candidates in ten processes of ten, another none within twelve in one process
   // of twelve (profiles/r03_alloc_distribution.jsonl), the round-3 driver's none within 24
   static const int cand = std::getenv("MSC_ALLOC_CANDIDATES") ? std::atoi(std::getenv("MSC_ALLOC_CANDIDATES")) : 12;
   static const float accept = std::getenv("MSC_ALLOC_ACCEPT_GBPS") ? (float)std::atof(std::getenv("MSC_ALLOC_ACCEPT_GBPS")) : 6650.f;
-  static const int flat = std::getenv("MSC_ALLOC_FLAT_AFTER") ? std::atoi(std::getenv("MSC_ALLOC_FLAT_AFTER")) : 6;
+  constexpr int flat = 6;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if (nbytes >= (64u << 20) && cand >= 1 && !capturing)
@@ -641,6 +644,7 @@ extern "C" int msc_dataview_invalidate(msc_dataview *view) {
   view->sentinels.clear();
   view->packed_bits.clear();
   view->nich_x.clear();
+  view->look_idx.clear();
   view->col_max.assign(view->cols.size(), -1);
   view->dm_max.assign(view->cols.size(), std::vector<uint32_t>());
   view->dm_tot.assign(view->cols.size(), nullptr);
@@ -845,25 +849,88 @@ static int packed_column(const msc_dataview *view, const void *const *cols, int 
 // the float columns `cols` (n2 of them; device, one float a row) as one matrix float [nrows][n2p], n2p = n2 rounded up to
 // four and the padding zero: what the role-split kernels' nich waves read a row's second-phase values from (msc::NichPos).
 // Kept by the view like the packed bool columns; a copy of those columns (64 MB for C3's sixteen on a million rows).
-static int nich_x_matrix(const msc_dataview *view, const std::vector<const void *> &cols, const float **out) {
+// A view keeps at most kViewPackCap matrices of either kind (one per distinct column list a state bound it with); a
+// plan that would need one more, or whose allocation fails, does without -- the kernels that run the phases one after
+// the other need neither (the copies are an optimisation, never a reason for a call to fail).
+constexpr size_t kViewPackCap = 8;
+static bool nich_x_matrix(const msc_dataview *view, const std::vector<const void *> &cols, const float **out) {
   for (const auto &e : view->nich_x)
     if (e.first == cols) {
       *out = e.second;
-      return MSC_OK;
+      return true;
     }
+  if (view->nich_x.size() >= kViewPackCap) return false;
   const uint32_t n2 = (uint32_t)cols.size(), n2p = (n2 + 3u) & ~3u;
   void *dst = nullptr, *ptrs = nullptr;
-  MSC_HIP(hipMalloc(&dst, std::max<size_t>(16, (size_t)view->nrows * n2p * sizeof(float))));
+  if (hipMalloc(&dst, std::max<size_t>(16, (size_t)view->nrows * n2p * sizeof(float))) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  bool ok = hipMalloc(&ptrs, sizeof(void *) * n2) == hipSuccess;
+  ok = ok && hipMemcpyAsync(ptrs, cols.data(), sizeof(void *) * n2, hipMemcpyHostToDevice, view->ctx->stream) == hipSuccess;
+  ok = ok && launch_pack_nich_x(view->ctx->stream, static_cast<const float *const *>(ptrs), n2, n2p, view->nrows, static_cast<float *>(dst)) == 0;
+  ok = (hipStreamSynchronize(view->ctx->stream) == hipSuccess) && ok;      // (`cols` is the caller's, `ptrs` this function's)
+  if (ptrs != nullptr) (void)hipFree(ptrs);
+  if (!ok) {
+    (void)hipGetLastError();
+    (void)hipFree(dst);
+    return false;
+  }
   view->owned_lazy.push_back(dst);
-  MSC_HIP(hipMalloc(&ptrs, sizeof(void *) * n2));
-  view->owned_lazy.push_back(ptrs);                       // (the kernel reads the list after this call has returned)
-  MSC_HIP(hipMemcpyAsync(ptrs, cols.data(), sizeof(void *) * n2, hipMemcpyHostToDevice, view->ctx->stream));
-  MSC_HIP(hipStreamSynchronize(view->ctx->stream));       // (`cols` is the caller's)
-  if (launch_pack_nich_x(view->ctx->stream, static_cast<const float *const *>(ptrs), n2, n2p, view->nrows, static_cast<float *>(dst)))
-    return fail(MSC_EHIP, "k_pack_nich_x launch failed");
   view->nich_x.emplace_back(cols, static_cast<const float *>(dst));
   *out = static_cast<const float *>(dst);
-  return MSC_OK;
+  return true;
+}
+
+// The lookup index matrix of a plan's first phase tf[0 .. split) (msc::FeatDesc::lk_idx): a row's record is the groups'
+// features side by side, a byte each, every group from a dword boundary on; sets lk_goff at every group's first feature.
+// Kept by the view like the x matrix (C3: 36 features in ten groups, 48 bytes a row).  false: no matrix (cap reached, or no
+// memory) -- the plan does not take the kernels that read one.
+static bool look_idx_matrix(const msc_dataview *view, std::vector<FeatDesc> &tf, uint32_t split, const uint32_t **out, uint32_t *l4_out) {
+  std::vector<LookIdxSrc> src(split);
+  std::vector<uint64_t> key;
+  uint32_t l4 = 0;
+  for (uint32_t f0 = 0; f0 < split;) {
+    const uint32_t f1 = tf[f0].grp_end;
+    tf[f0].lk_goff = l4;
+    for (uint32_t i = f0; i < f1; i++) {
+      const FeatDesc &d = tf[i];
+      if (d.kind == MSC_KIND_GENERIC || d.col == nullptr || d.grp_off + d.run_clamp >= 256u) return false;
+      src[i] = LookIdxSrc{d.col, d.kind, d.run_clamp, d.grp_off, 4u * l4 + (i - f0)};
+      key.push_back(reinterpret_cast<uint64_t>(d.col));
+      key.push_back((uint64_t)d.kind | (uint64_t)d.run_clamp << 8 | (uint64_t)d.grp_off << 32);
+      key.push_back(src[i].byte_at);
+    }
+    l4 += (f1 - f0 + 3u) / 4u;
+    f0 = f1;
+  }
+  *l4_out = l4;
+  for (const auto &e : view->look_idx)
+    if (e.first == key) {
+      *out = e.second;
+      return true;
+    }
+  if (view->look_idx.size() >= kViewPackCap || split == 0) return false;
+  void *dst = nullptr, *srcs = nullptr;
+  if (hipMalloc(&dst, ((size_t)view->nrows * l4 + 4u) * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  bool ok = hipMalloc(&srcs, sizeof(LookIdxSrc) * split) == hipSuccess;
+  ok = ok && hipMemcpyAsync(srcs, src.data(), sizeof(LookIdxSrc) * split, hipMemcpyHostToDevice, view->ctx->stream) == hipSuccess;
+  ok = ok && hipMemsetAsync(static_cast<uint32_t *>(dst) + (size_t)view->nrows * l4, 0, 4u * sizeof(uint32_t), view->ctx->stream) == hipSuccess;
+  ok = ok && launch_pack_look_idx(view->ctx->stream, static_cast<const LookIdxSrc *>(srcs), split, l4, view->nrows, static_cast<uint32_t *>(dst)) == 0;
+  ok = (hipStreamSynchronize(view->ctx->stream) == hipSuccess) && ok;
+  if (srcs != nullptr) (void)hipFree(srcs);
+  if (!ok) {
+    (void)hipGetLastError();
+    (void)hipFree(dst);
+    return false;
+  }
+  view->owned_lazy.push_back(dst);
+  view->look_idx.emplace_back(key, static_cast<const uint32_t *>(dst));
+  *out = static_cast<const uint32_t *>(dst);
+  return true;
 }
 
 static int plan_groups(msc_state *st) {
@@ -1021,8 +1088,7 @@ static int plan_groups(msc_state *st) {
     std::vector<FeatDesc> &ta = st->desc_acc_host;
     ta.clear();
     std::vector<bool> covered(n, false);
-    static const bool no_acc_fuse = std::getenv("MSC_NO_ACC_FUSE") != nullptr;       // (A/B knob)
-    for (size_t q = 0; q < quads.size() && !no_acc_fuse; q++) {
+    for (size_t q = 0; q < quads.size(); q++) {
       const Fused &fq = quads[q];
       if ((size_t)st->K * 8u * fq.m * 4u > 64u * 1024u) continue;
       const std::vector<uint32_t> &mem = members[fq.radix - 2];
@@ -1068,11 +1134,22 @@ static int plan_groups(msc_state *st) {
       } else q.blk = i | 1u << 16, q.seg_end = n2p;
     }
     const float *xm = nullptr;
-    MSC_TRY(nich_x_matrix(bview, xcols, &xm));
-    MSC_HIP(hipMemcpyAsync(st->rn_pos, pos.data(), sizeof(NichPos) * n2p, hipMemcpyHostToDevice, st->ctx->stream));
-    MSC_HIP(hipStreamSynchronize(st->ctx->stream));           // (`pos` is this function's)
-    FeatDesc &h = tf[s0];
-    h.rn_pack = st->rn_pack, h.rn_pos = st->rn_pos, h.rn_x = xm, h.rn_n2 = n2, h.rn_n2p = n2p;
+    if (nich_x_matrix(bview, xcols, &xm)) {
+      MSC_HIP(hipMemcpyAsync(st->rn_pos, pos.data(), sizeof(NichPos) * n2p, hipMemcpyHostToDevice, st->ctx->stream));
+      MSC_HIP(hipStreamSynchronize(st->ctx->stream));           // (`pos` is this function's)
+      FeatDesc &h = tf[s0];
+      h.rn_pack = st->rn_pack, h.rn_pos = st->rn_pos, h.rn_x = xm, h.rn_n2 = n2, h.rn_n2p = n2p;
+    } else facts.roles_ok = facts.nich_only = false;           // (no copy: the kernels that stage the nich constants need none)
+  }
+  // ... and what their lookup waves read (FeatDesc::lk_idx): the first phase's slot rows, row by row
+  for (FeatDesc &d : tf) d.lk_idx = nullptr, d.lk_l4 = d.lk_goff = 0;
+  for (FeatDesc &d : t) d.lk_idx = nullptr, d.lk_l4 = d.lk_goff = 0;
+  if (bview == nullptr) facts.lookups_only = false;
+  if (facts.roles_ok || facts.lookups_only) {
+    const uint32_t *im = nullptr;
+    uint32_t l4 = 0;
+    if (look_idx_matrix(bview, tf, st->fuse_split, &im, &l4)) tf[0].lk_idx = im, tf[0].lk_l4 = l4;
+    else facts.roles_ok = facts.lookups_only = false;
   }
   st->tile_roles_ok = facts.roles_ok;
   st->tile_nich_only = facts.nich_only;
@@ -1654,8 +1731,6 @@ static uint32_t dm_value_slices(const msc_feature_host &h) {
 
 // threads per (feature, group) that share the rows of a count / categorical table in the prepare kernels: ~4 rows each
 static uint32_t prepare_value_slices(const msc_state *st) {
-  static const int forced = std::getenv("MSC_PREPARE_SLICES") ? std::atoi(std::getenv("MSC_PREPARE_SLICES")) : 0;   // tuning knob
-  if (forced > 0) return (uint32_t)forced;
   uint32_t rows = 1;
   for (uint32_t f = 0; f < st->nfeat; f++) {
     const int fam = st->feats[f].family;
@@ -1820,12 +1895,7 @@ static int narrow_lanes(const msc_state *st, uint32_t *table_rows) {
 // either way; what decides between 5.6 and 7.0 TB/s is where the driver placed the buffer.)
 static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, uint32_t K) {
   // which stores the pass uses (bit 8 of the launch code: plain): what msc_score_tune found for this very buffer; else
-  // non-temporal into a buffer this context placed and probed fast, plain into everything else (msc_context::placed);
-  // MSC_NICH1_STORES = nt | plain overrides
-  static const int forced_stores = [] {
-    const char *e = std::getenv("MSC_NICH1_STORES");
-    return !e ? -1 : (e[0] == 'p' ? 1 : 0);
-  }();
+  // non-temporal into a buffer this context placed and probed fast, plain into everything else (msc_context::placed)
   int plain = 1;
   for (const msc_context::Placed &p : ctx->placed)
     if (out >= p.base && static_cast<const char *>(out) < static_cast<const char *>(p.base) + p.size) plain = p.nt_fast ? 0 : 1;
@@ -1842,7 +1912,6 @@ static int nich1_shape_for(msc_context *ctx, const void *out, uint64_t nrows, ui
   }
   if (shape < 0) shape = by_size < 0 ? 0 : by_size;
   if (fixed >= 0 && fixed < kNich1NumShapes) shape = fixed;
-  if (forced_stores >= 0) plain = forced_stores;
   return shape | (plain ? 0x100 : 0);
 }
 
@@ -2148,8 +2217,7 @@ extern "C" int msc_score_data(msc_state *st, float *out_dev) {
 // score + sample in one kernel; niw and gp-beyond-table features and wide K need the materialised path
 // one niw feature of small dimension on few groups: the fused k_sweep_niw1
 static bool sweep_is_niw1(const msc_state *st) {
-  static const bool off = std::getenv("MSC_NIW_NO_SMALL") != nullptr;
-  return !off && st->nfeat == 1 && st->feats[0].family == MSC_NIW && (int)st->K <= sweep_niw1_max_groups(st->feats[0].dim);
+  return st->nfeat == 1 && st->feats[0].family == MSC_NIW && (int)st->K <= sweep_niw1_max_groups(st->feats[0].dim);
 }
 
 // the lane <-> row kernel fills the chip from ~260k rows on; with fewer the tile kernels' rounds of 128-row chunks can be

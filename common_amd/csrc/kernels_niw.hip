@@ -809,13 +809,11 @@ static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc 
   // Row blocks of 16 per wave: four up to dim 32 (C4: 179 + 64 registers, two waves per SIMD, 0.88 of the f64 matrix
   // peak), two beyond -- with four the wave's features, sums and epilogue take 290-512 registers and the kernel runs one
   // wave per SIMD: dim 64 4.94 ms; with two (and the operand stream pipelined, PIPE in the kernel) 3.06 ms, three
-  // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).  MSC_NIW_JB = 2 | 4 forces one (tuning knob).
-  static const int forced = std::getenv("MSC_NIW_JB") ? std::atoi(std::getenv("MSC_NIW_JB")) : 0;
-  const int jb = forced == 2 || forced == 4 ? forced : (NB > 2 ? 2 : 4);
-  if (jb == 2)
-    hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), dim3(grid.x * 2), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).
+  if constexpr (NB > 2)
+    hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 2, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   else
-    hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), grid, dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 4, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
 }
 template <bool LOO, bool ACCUM>
 static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, uint32_t dim, const FeatDesc *feats_dev,
@@ -828,7 +826,7 @@ static void launch_niw_score_t(hipStream_t stream, int num_cus, bool f32_fast, u
   if (gx > cap) gx = cap;
   const dim3 grid((unsigned)(gx ? gx : 1)), block(256);
   if (f32_fast && dim <= (uint32_t)kNiwPad)
-    hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), grid, block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
+    hipLaunchKernelGGL((k_score_niw<2, LOO, ACCUM>), (note_kernel(0, "k_score_niw<2, %s, %s>", tf(LOO), tf(ACCUM)), grid), block, 0, stream, feats_dev, f, K, kpad, row0, nrows, z, out, ld);
   else {
     switch (niw_blocks(dim)) {
       case 1: launch_niw64_nb<1, LOO, ACCUM>(stream, grid, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld); break;
@@ -863,8 +861,7 @@ static void launch_niw_small(hipStream_t stream, int num_cus, const FeatDesc *fe
 int launch_niw_score(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t f, uint32_t dim, uint32_t K,
                      uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z, bool accum, bool f32_fast,
                      double *qown, float *out, uint64_t ld) {
-  static const bool no_small = std::getenv("MSC_NIW_NO_SMALL") != nullptr;      // (A/B knob)
-  if (!f32_fast && !no_small && dim >= 1 && dim <= 8 && nrows > 0) {
+  if (!f32_fast && dim >= 1 && dim <= 8 && nrows > 0) {
     switch (dim) {
       case 1: launch_niw_small<1>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;
       case 2: launch_niw_small<2>(stream, num_cus, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld, accum); break;

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
 template <bool LOO, bool CRP, int Q, bool NT>
 __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict__ feats,
                                                       uint32_t K, uint32_t kpad, uint64_t row0,
-                                                      uint64_t nrows, uint64_t nslots, uint32_t spread, uint64_t per, int flavour,
+                                                      uint64_t nrows, uint64_t nslots,
                                                       const int32_t *__restrict__ z,
                                                       const float *__restrict__ own,
                                                       const float *__restrict__ crp,
@@ -556,16 +556,14 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   const bool tile_full = (kt + 1) * kGroupTile <= K;
   const float *xcol = reinterpret_cast<const float *>(fd.col) + row0;
   // everything the wave's rows need, fetched at once: lane i holds row r = i % Q of visit k = i / Q
-  // SPREAD (an experiment knob, MSC_NICH1_SPREAD = S regions; 0: off): block L of the launch order is block
-  // (L % S) * per + L / S of the matrix -- the waves resident at one moment write S windows `per` blocks apart instead of
-  // one dense window (profiles/r04_spread_store.txt: does the write stream's rate still depend on where the driver put
-  // the pages when the window is spread over the whole buffer?)
-  const uint64_t nblocks = spread ? (uint64_t)spread * per : (nrows + Q - 1) / Q;
-  auto block_of = [&](uint64_t L) -> uint64_t { return spread ? (L % spread) * per + L / spread : L; };
+  // (a spread launch order -- the resident waves writing S windows far apart instead of one dense one -- and the stores'
+  // cache policies were measured in round 4 and are kept as a patch: tools/microbench/r04_store_policy_experiment.patch,
+  // profiles/r04_spread_store.txt, r04_store_policy.txt)
+  const uint64_t nblocks = (nrows + Q - 1) / Q;
   const uint32_t nvis = (uint32_t)((nblocks + nslots - 1) / nslots);      // <= 64 / Q (launcher)
   const uint32_t vk = (uint32_t)lane / Q, vr = (uint32_t)lane % Q;
   const uint64_t myblock = slot + (uint64_t)vk * nslots;
-  const uint64_t myrow = block_of(myblock) * Q + vr;
+  const uint64_t myrow = myblock * Q + vr;
   const bool mine = vk < nvis && myblock < nblocks && myrow < nrows;
   const float xv = mine ? xcol[myrow] : 0.0f;
   const unsigned long long mbits_all =
@@ -584,7 +582,7 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
   for (uint32_t k = 0; k < nvis; k++) {
     const uint64_t L = slot + (uint64_t)k * nslots;
     if (L >= nblocks) break;
-    const uint64_t rb = block_of(L) * Q;
+    const uint64_t rb = L * Q;
     if (rb >= nrows) continue;
     const int nr = (int)((nrows - rb) < (uint64_t)Q ? (nrows - rb) : (uint64_t)Q);
     const int l0 = (int)(k * Q);                              // first lane of this visit's values
@@ -608,20 +606,8 @@ __global__ __launch_bounds__(256) void k_score_nich1(const FeatDesc *__restrict_
         }
         const f32x4 v = {s.x, s.y, s.z, s.w};
         f32x4 *p = reinterpret_cast<f32x4 *>(out + (rb + r) * ld + kb);
-        if (flavour == 0) {
-          if (NT) __builtin_nontemporal_store(v, p);
-          else *p = v;
-        } else {
-          // (experiment, MSC_NICH1_STORE: the store's cache policy -- tools/scans/spread_store.py)
-          typedef __attribute__((address_space(1))) f32x4 *gp;
-          const gp q = (gp)p;
-          if (flavour == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(q), "v"(v) : "memory");
-          else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
-          else if (flavour == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
-          else if (flavour == 4) asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(q), "v"(v) : "memory");
-          else if (flavour == 5) asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1" ::"v"(q), "v"(v) : "memory");
-          else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(q), "v"(v) : "memory");
-        }
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
       }
     } else {
       for (int r = 0; r < nr; r++) {
@@ -819,39 +805,41 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
   }
   // ---- the nich waves: the second phase from the pack, no LDS and no barrier until the hand-over; block by block
   // (score_block.hpp nich_phase_packed: the steps every tile kernel takes); then the rows' finish ----
-  float4 hi = make_float4(0, 0, 0, 0);
-  float le0 = 0, le1 = 0;
-  if (CRP) {
-    hi = PAIR ? pair_dup(ld2(crp + kb)) : ld4(crp + kb);
-    le0 = crp[2 * (size_t)kpad];
-    le1 = crp[2 * (size_t)kpad + 1];
-  }
+  // Little of the finish is alive during the phase (round 5): the prior's high half and what depends on it are fetched
+  // AFTER it, through a pointer the compiler cannot see through.  Fetched up front they were held across the block loops
+  // in registers the loops did not have.
   for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;        // relative to row0
     const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
-    // what the finish needs of the rows, fetched before the arithmetic (its latency under the nich phase)
+    // (the rows' groups and leave-one-out values stream in from HBM: asked for before the phase, two registers across it;
+    // what comes out of the small, cache-resident prior table is fetched after it)
     int gz = -1, single = 0;
     float sloo = 0.f;
     if (LOO && lane < nr) {
       gz = z[rb + lane];
       sloo = own[rb + lane];
-      if (CRP) single = gz >= 0 && (uint32_t)gz < K && __builtin_isinf(crp[kpad + gz]) ? 1 : 0;
     }
-    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     float4 acc[R];
     const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
-#ifdef MSC_EXP_NO_NICH                                    // (timing experiment)
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
-#else
     nich_phase_packed<R, false, PAIR>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);
-#endif
+    const float *crpq = crp;
+    asm volatile("" : "+s"(crpq));
+    float4 hi = make_float4(0, 0, 0, 0);
+    float le0 = 0, le1 = 0;
+    if (CRP) {
+      hi = PAIR ? pair_dup(ld2(crpq + kb)) : ld4(crpq + kb);
+      le0 = crpq[2 * (size_t)kpad];
+      le1 = crpq[2 * (size_t)kpad + 1];
+    }
+    if (LOO && CRP && lane < nr) single = gz >= 0 && (uint32_t)gz < K && __builtin_isinf(crpq[kpad + gz]) ? 1 : 0;
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
     __syncthreads();                                      // (1) the lookup sums are in the slot
 #pragma unroll
     for (int r = 0; r < R; r++) {                         // (prior lo + lookups) + (nich features)
       float4 t = handover[r * 64];
       add4(t, acc[r]);
       acc[r] = t;
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four reads in flight: sixteen beside the sixteen sums spill)
     }
     __syncthreads();                                      // (2) read: the lookup waves go on
     // the rows' finish: + hi of the prior, then the own group's entry becomes the row's leave-one-out value (the lane and
@@ -1191,21 +1179,9 @@ bool pair_mode_ok(int path, uint32_t K, bool few_rows) {
   static const bool off = std::getenv("MSC_NO_PAIR") != nullptr;     // (A/B knob)
   return !off && (path == MSC_PATH_TILE_ROLES || path == MSC_PATH_NICH_PACK || path == MSC_PATH_LOOKUPS) && tile_roles_enabled() && K <= 128 && !few_rows;
 }
-bool tile_roles_enabled() {
-  static const bool on = [] {
-    const char *e = std::getenv("MSC_TILE_ROLES");      // A/B knob: 0 keeps every wave on both phases (k_score_tile)
-    return !(e && std::atoi(e) == 0);
-  }();
-  return on;
-}
-
-int tile_rows_per_wave() {
-  static const int r = [] {
-    const char *e = std::getenv("MSC_TILE_ROWS");   // tuning knob: rows per wave, 8 (default) | 16
-    return (e && std::atoi(e) == 16) ? 16 : 8;
-  }();
-  return r;
-}
+// (the A/B switch between these kernels and the ones that run the phases one after the other is the plan's: MSC_NO_ROLES,
+// abi.cpp plan_groups)
+bool tile_roles_enabled() { return true; }
 
 // (blocks of one row, like a memset's, lose in this kernel although they win as a bare fill: a wave that visits only a few
 // rows does not pay for loading the group constants, and with many visits the fronts are too many)
@@ -1645,13 +1621,7 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     const bool plain_stores = (nich1_shape & 0x100) != 0;
     nich1_shape &= 0xff;
     const Nich1Shape sh = kNich1Shapes[nich1_shape >= 0 && nich1_shape < kNich1NumShapes ? nich1_shape : 0];
-    const char *spread_env = std::getenv("MSC_NICH1_SPREAD");             // (read per launch: the experiments change them between passes)
-    const uint32_t spread = spread_env ? (uint32_t)std::atoi(spread_env) : 0u;
-    const char *store_env = std::getenv("MSC_NICH1_STORE");
-    const int flavour = store_env ? std::atoi(store_env) : 0;
-    const uint64_t nblocks_real = (nrows + sh.q - 1) / sh.q;
-    const uint64_t per = spread ? (nblocks_real + spread - 1) / spread : 0;
-    const uint64_t nvisits_all = spread ? (uint64_t)spread * per : nblocks_real;
+    const uint64_t nvisits_all = (nrows + sh.q - 1) / sh.q;
     const uint64_t max_slots = ((uint64_t)1 << 32) / ktiles;          // keeps grid.x below 2^30 workgroups
     uint64_t visits = sh.visits;
     while ((nvisits_all + visits - 1) / visits > max_slots && visits * sh.q < 64) visits++;
@@ -1659,21 +1629,20 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (nslots == 0) nslots = 1;
     const uint64_t gx = (nslots * ktiles + 3) / 4;
     if (plain_stores)
-      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, false>), dim3((unsigned)gx), dim3(256), 0, stream,
-                         feats_dev, K, kpad, row0, nrows, nslots, spread, per, flavour, z, own, crp, out, ld);
+      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, false>), (note_kernel(0, "k_score_nich1<%s, %s, 4, false>", tf(LOO), tf(CRP)), dim3((unsigned)gx)), dim3(256), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, nslots, z, own, crp, out, ld);
     else
-      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), dim3((unsigned)gx), dim3(256), 0, stream,
-                         feats_dev, K, kpad, row0, nrows, nslots, spread, per, flavour, z, own, crp, out, ld);
+      hipLaunchKernelGGL((k_score_nich1<LOO, CRP, 4, true>), (note_kernel(0, "k_score_nich1<%s, %s, 4, true>", tf(LOO), tf(CRP)), dim3((unsigned)gx)), dim3(256), 0, stream,
+                         feats_dev, K, kpad, row0, nrows, nslots, z, own, crp, out, ld);
   } else {
     // one workgroup per CU (2 x 64 KiB of LDS), 128 rows per workgroup, two tilings:
     // 16 waves x 8 rows (4 waves/SIMD, default) or 8 waves x 16 rows (2 waves/SIMD)
     // states with a dm feature: 8 waves x 8 rows (64 rows per workgroup, 256-register budget for the hi/lo sums)
     // few rows: a chunk is a serial chain (feature after feature, the code fetched once), so what counts is that
     // the chunks spread over the chip in ONE round: 4 or 2 rows per wave while that still fits
-    const int R = tile_rows_per_wave();
     const bool dm = path == MSC_PATH_TILE_DM;
     const uint64_t round = (uint64_t)num_cus / ktiles;
-    static const uint64_t rounds4 = std::getenv("MSC_TILE_R4_ROUNDS") ? std::atoi(std::getenv("MSC_TILE_R4_ROUNDS")) : 1;
+    constexpr uint64_t rounds4 = 1;
     // (4 rows per wave only while the 64-row workgroups themselves fit one round: 20000 rows made 313 of them -- two
     // rounds, 0.113 ms -- where 157 workgroups of 128 rows take one)
     const bool small4 = !dm && (nrows + 63) / 64 <= round * rounds4, small2 = small4 && (nrows + 31) / 32 <= round;
@@ -1702,47 +1671,44 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     if (tail && ktiles == 1) return;
     const dim3 grid((unsigned)gx, tail ? ktiles - 1 : ktiles);
     if (path == MSC_PATH_TILE_DM)
-      hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 8, LOO, CRP, true>), (note_kernel(0, "k_score_tile<8, 8, %s, %s, true>", tf(LOO), tf(CRP)), grid), dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (path == MSC_PATH_LOOKUPS && pair)
-      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 511) / 512, cap), 1), dim3(1024), 0, stream,
+      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, true>), (note_kernel(0, "k_score_lookups<%s, %s, true>", tf(LOO), tf(CRP)), dim3((unsigned)std::min<uint64_t>((nrows + 511) / 512, cap), 1)), dim3(1024), 0, stream,
                          feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (path == MSC_PATH_LOOKUPS && !small4)
-      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, false>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), grid.y), dim3(1024), 0, stream,
+      hipLaunchKernelGGL((k_score_lookups<LOO, CRP, false>), (note_kernel(0, "k_score_lookups<%s, %s, false>", tf(LOO), tf(CRP)), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), grid.y)), dim3(1024), 0, stream,
                          feats_dev, nfeat, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (pair && path == MSC_PATH_NICH_PACK)
     {
       const dim3 g((unsigned)std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves)), 1);
       if (nsplit > 0)
-        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, true>), (note_kernel(0, "k_score_nich_pack<%s, %s, true, true>", tf(LOO), tf(CRP)), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
       else
-        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, true, false>), (note_kernel(0, "k_score_nich_pack<%s, %s, true, false>", tf(LOO), tf(CRP)), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
     }
     else if (path == MSC_PATH_NICH_PACK && !small4)
     {
       const dim3 g((unsigned)std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves)), grid.y);
       if (nsplit > 0)
-        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, true>), (note_kernel(0, "k_score_nich_pack<%s, %s, false, true>", tf(LOO), tf(CRP)), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
       else
-        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+        hipLaunchKernelGGL((k_score_nich_pack<LOO, CRP, false, false>), (note_kernel(0, "k_score_nich_pack<%s, %s, false, false>", tf(LOO), tf(CRP)), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
     }
     else if (pair)
-      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1), dim3(1024), 0, stream,
+      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), (note_kernel(0, "k_score_tile_roles<%s, %s, true>", tf(LOO), tf(CRP)), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1)), dim3(1024), 0, stream,
                          feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
     else if (!small4 && path == MSC_PATH_TILE_ROLES && tile_roles_enabled())
-      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), (note_kernel(0, "k_score_tile_roles<%s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (small2)
-      hipLaunchKernelGGL((k_score_tile<2, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<2, 16, LOO, CRP, false>), (note_kernel(0, "k_score_tile<2, 16, %s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else if (small4)
-      hipLaunchKernelGGL((k_score_tile<4, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
-                         nrows, z, own, crp, out, ld);
-    else if (R == 16)
-      hipLaunchKernelGGL((k_score_tile<16, 8, LOO, CRP, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<4, 16, LOO, CRP, false>), (note_kernel(0, "k_score_tile<4, 16, %s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
     else
-      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
+      hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), (note_kernel(0, "k_score_tile<8, 16, %s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
   }
 }

@@ -7,6 +7,8 @@
 #include "commit_ops.hpp"
 #include "device_error.hpp"
 #include "family_math.hpp"
+#include <cstdarg>
+#include <cstdio>
 #include "launchers.hpp"
 
 namespace msc {
@@ -519,6 +521,40 @@ int launch_pack_nich_x(hipStream_t stream, const float *const *cols_dev, uint32_
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the lookup index matrix of a plan's first phase (FeatDesc::lk_idx): byte `byte_at` of row r's record = the feature's slot
+// row for that row -- grp_off + min(max(value, 0), clamp), the value a byte (bool / fused digits) or a 32-bit integer as the
+// lookup runs read it (score_block.hpp).  One thread a row; the record's unused bytes are zero.
+__global__ __launch_bounds__(256) void k_pack_look_idx(const LookIdxSrc *__restrict__ src, uint32_t nsrc, uint32_t l4, uint64_t n,
+                                                       uint32_t *__restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  uint32_t *rec = out + r * l4;
+  uint32_t word = 0u, at = 0u;                           // the dword being filled and its index
+  for (uint32_t i = 0; i < nsrc; i++) {
+    const LookIdxSrc f = src[i];
+    const int v = f.kind == MSC_KIND_LOOKUP_U8 ? (int)static_cast<const uint8_t *>(f.col)[r] : static_cast<const int *>(f.col)[r];
+    const uint32_t row = f.grp_off + (uint32_t)(v < 0 ? 0 : (v > (int)f.clamp ? (int)f.clamp : v));
+    const uint32_t dw = f.byte_at >> 2;                  // (byte_at ascends with i)
+    while (at < dw) rec[at++] = word, word = 0u;
+    word |= (row & 0xffu) << (8u * (f.byte_at & 3u));
+  }
+  while (at < l4) rec[at++] = word, word = 0u;
+}
+static char g_last_kernel[2][160] = {"", ""};
+void note_kernel(int slot, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_kernel[slot & 1], sizeof g_last_kernel[0], fmt, ap);
+  va_end(ap);
+}
+const char *last_kernel(int slot) { return g_last_kernel[slot & 1]; }
+
+int launch_pack_look_idx(hipStream_t stream, const LookIdxSrc *src_dev, uint32_t nsrc, uint32_t l4, uint64_t n, uint32_t *out) {
+  if (n == 0 || nsrc == 0) return 0;
+  hipLaunchKernelGGL(k_pack_look_idx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src_dev, nsrc, l4, n, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_t radix, uint64_t n, void *out) {
   if (n == 0) return 0;
   PackCols pc;
@@ -829,8 +865,7 @@ int launch_accumulate(hipStream_t stream, int num_cus, const FeatDesc *feats_dev
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // a workgroup per (feature, slice of rows): ~8 workgroups per CU in all, a slice never shorter than 4096 rows (fewer
   // when that would leave most of the chip idle) -- C3: 65 x 31 workgroups of 32k rows, C2: 2 x 245 of 4096.
-  // MSC_ACC_WGS_PER_CU: tuning knob
-  static const int wgs_per_cu = std::getenv("MSC_ACC_WGS_PER_CU") ? std::max(1, std::atoi(std::getenv("MSC_ACC_WGS_PER_CU"))) : 8;
+  constexpr int wgs_per_cu = 8;                             // (tools/scans/acc_scan.sh: 4 ... 16 within noise of each other)
   const uint64_t nf1 = (uint64_t)nfeat + 1;
   uint64_t slices = std::max<uint64_t>(1, ((uint64_t)num_cus * wgs_per_cu + nf1 - 1) / nf1);
   uint64_t per = std::max<uint64_t>((nrows + slices - 1) / slices, 4096);

@@ -1105,23 +1105,28 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
     for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
       const uint64_t rb = chunk * rows_per_wg + (uint64_t)pair * RW;
       const int nr = rb >= nrows ? 0 : (int)((nrows - rb) < (uint64_t)RW ? (nrows - rb) : (uint64_t)RW);
+      // (the rows' groups and leave-one-out values stream in from HBM: asked for before the phase, two registers across
+      // it; the uniforms are made after it -- kernels_score.hip k_score_tile_roles says why)
       int gz = -1;
       float sloo = 0.f;
       if (lane < nr) {
         gz = z[rb + lane];
-        if ((uint32_t)gz >= K) gz = -1;                   // (an id outside the table: not assigned)
-        if (gz >= 0) sloo = own[rb + lane];
+        sloo = own[rb + lane];
       }
-      const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
       float4 acc[R];
       const uint64_t myrow = row0 + (lane < nr ? rb + lane : (nr ? rb : 0));   // (a row of the call's range for idle lanes)
       nich_phase_packed<R, true, PAIR>(feats, nsplit, kpad, kb, row0 + rb, nr, myrow, acc);      // (EST: the sweeps' form)
+      int32_t *zq = z;
+      asm volatile("" : "+s"(zq));
+      if ((uint32_t)gz >= K) gz = -1, sloo = 0.f;         // (an id outside the table: not assigned)
+      const float u01 = philox_uniform01(seed, sweep, row_id0 + rb + lane);
       __syncthreads();                                    // (1)
 #pragma unroll
       for (int r = 0; r < R; r++) {                       // (prior + lookups) + (nich features)
         float4 t = handover[r * 64];
         add4(t, acc[r]);
         acc[r] = t;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four reads in flight: sixteen beside the sixteen sums spill)
       }
       __syncthreads();                                    // (2)
       int znew = gz;
@@ -1170,7 +1175,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep_tile_roles(const FeatDesc *__
           if (lane == r) znew = pick;
         }
       }
-      if (lane < nr) z[rb + lane] = znew;
+      if (lane < nr) zq[rb + lane] = znew;
     }
   }
 }
@@ -1833,15 +1838,15 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
     const uint64_t gxt = grid_for((nrows + kTRows - 1) / kTRows, num_cus, K <= 256 ? 16 : K <= 512 ? 12 : 8);
     const dim3 gridt((unsigned)gxt), blockt(256);
     if (K <= 64)
-      hipLaunchKernelGGL(k_sweep_nich1_t<1>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+      hipLaunchKernelGGL(k_sweep_nich1_t<1>, (note_kernel(1, "k_sweep_nich1_t<1>"), gridt), blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
     else if (K <= 128)
-      hipLaunchKernelGGL(k_sweep_nich1_t<2>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+      hipLaunchKernelGGL(k_sweep_nich1_t<2>, (note_kernel(1, "k_sweep_nich1_t<2>"), gridt), blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
     else if (K <= 256)
-      hipLaunchKernelGGL(k_sweep_nich1_t<4>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+      hipLaunchKernelGGL(k_sweep_nich1_t<4>, (note_kernel(1, "k_sweep_nich1_t<4>"), gridt), blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
     else if (K <= 512)
-      hipLaunchKernelGGL(k_sweep_nich1_t<8>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+      hipLaunchKernelGGL(k_sweep_nich1_t<8>, (note_kernel(1, "k_sweep_nich1_t<8>"), gridt), blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
     else
-      hipLaunchKernelGGL(k_sweep_nich1_t<16>, gridt, blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
+      hipLaunchKernelGGL(k_sweep_nich1_t<16>, (note_kernel(1, "k_sweep_nich1_t<16>"), gridt), blockt, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, crp, rng, zero);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   // 64 rows per wave visit once there are enough rows for ~8 waves per SIMD; fewer rows: halve the visit down to 4
@@ -1850,15 +1855,15 @@ int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_de
   const uint64_t gx = grid_for((nrows + chunk_rows - 1) / chunk_rows, num_cus, 16);
   const dim3 grid((unsigned)gx), block(256);
   if (K <= 64)
-    hipLaunchKernelGGL(k_sweep_nich1<1>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+    hipLaunchKernelGGL(k_sweep_nich1<1>, (note_kernel(1, "k_sweep_nich1<1>"), grid), block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 128)
-    hipLaunchKernelGGL(k_sweep_nich1<2>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+    hipLaunchKernelGGL(k_sweep_nich1<2>, (note_kernel(1, "k_sweep_nich1<2>"), grid), block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 256)
-    hipLaunchKernelGGL(k_sweep_nich1<4>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+    hipLaunchKernelGGL(k_sweep_nich1<4>, (note_kernel(1, "k_sweep_nich1<4>"), grid), block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 512)
-    hipLaunchKernelGGL(k_sweep_nich1<8>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+    hipLaunchKernelGGL(k_sweep_nich1<8>, (note_kernel(1, "k_sweep_nich1<8>"), grid), block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else if (K <= 1024)
-    hipLaunchKernelGGL(k_sweep_nich1<16>, grid, block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
+    hipLaunchKernelGGL(k_sweep_nich1<16>, (note_kernel(1, "k_sweep_nich1<16>"), grid), block, 0, stream, feats_dev, K, kpad, row0, nrows, row_id0, z, own, crp, rng, chunk_rows, zero);
   else
     return -2;
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1868,7 +1873,6 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
                        uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z,
                        const float *own, const float *crp, const uint64_t *rng, ZeroSpans zero) {
   if (K > 256) return -2;
-  const int R = tile_rows_per_wave();
   // few rows: 2 rows per wave instead of 8, so that the chunks -- each a serial chain of feature lookups and R
   // draws -- spread over the chip instead of queueing in a quarter of it (N = 10k, 12 features: 26 -> ? us)
   // (and 4 rows per wave only while the 64-row workgroups fit one round themselves)
@@ -1880,49 +1884,46 @@ int launch_sweep_mixed(hipStream_t stream, int num_cus, bool has_dm, bool roles_
   if (gx > cap) gx = cap;
   const dim3 grid((unsigned)(gx ? gx : 1));
   if (has_dm)
-    hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<8, 8, true>), (note_kernel(1, "k_sweep_tile<8, 8, true>"), grid), dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (lookups_only && pair && K <= 128)
-    hipLaunchKernelGGL((k_sweep_lookups<true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 511) / 512, cap))), dim3(1024), 0, stream,
+    hipLaunchKernelGGL((k_sweep_lookups<true>), (note_kernel(1, "k_sweep_lookups<true, 0>"), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 511) / 512, cap)))), dim3(1024), 0, stream,
                        feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   else if (lookups_only && !small && !pair)
-    hipLaunchKernelGGL((k_sweep_lookups<false>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap))), dim3(1024), 0, stream,
+    hipLaunchKernelGGL((k_sweep_lookups<false>), (note_kernel(1, "k_sweep_lookups<false, 0>"), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap)))), dim3(1024), 0, stream,
                        feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   else if (nich_only && pair && K <= 128)                 // (PAIR follows the view's rows, whatever this call's are: see below)
   {
     const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 32 * kNichPackWaves - 1) / (32 * kNichPackWaves), cap * (16 / kNichPackWaves))));
     if (nsplit > 0)
-      hipLaunchKernelGGL((k_sweep_nich_pack<true, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+      hipLaunchKernelGGL((k_sweep_nich_pack<true, true>), (note_kernel(1, "k_sweep_nich_pack<true, true, 0>"), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
     else
-      hipLaunchKernelGGL((k_sweep_nich_pack<true, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+      hipLaunchKernelGGL((k_sweep_nich_pack<true, false>), (note_kernel(1, "k_sweep_nich_pack<true, false, 0>"), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   }
   else if (nich_only && !small && !pair)
   {
     const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves))));
     if (nsplit > 0)
-      hipLaunchKernelGGL((k_sweep_nich_pack<false, true>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+      hipLaunchKernelGGL((k_sweep_nich_pack<false, true>), (note_kernel(1, "k_sweep_nich_pack<false, true, 0>"), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
     else
-      hipLaunchKernelGGL((k_sweep_nich_pack<false, false>), g, dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
+      hipLaunchKernelGGL((k_sweep_nich_pack<false, false>), (note_kernel(1, "k_sweep_nich_pack<false, false, 0>"), g), dim3(kNichPackWaves * 64), 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero);
   }
   else if (pair && roles_ok && K <= 128)
     // PAIR mode (abi.cpp decides on the bound view's rows, not this call's: its draw sums a row's entries two to a lane
     // where the other tile kernels sum four, so every row range of a view must take the same one)
-    hipLaunchKernelGGL((k_sweep_tile_roles<0, true>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap))), dim3(1024), 0,
+    hipLaunchKernelGGL((k_sweep_tile_roles<0, true>), (note_kernel(1, "k_sweep_tile_roles<0, true>"), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap)))), dim3(1024), 0,
                        stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, static_cast<const float *>(nullptr));
   else if (small4)
-    hipLaunchKernelGGL((k_sweep_tile<4, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<4, 16, false>), (note_kernel(1, "k_sweep_tile<4, 16, false>"), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (small)
-    hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<2, 16, false>), (note_kernel(1, "k_sweep_tile<2, 16, false>"), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   else if (roles_ok && tile_roles_enabled())
-    hipLaunchKernelGGL(k_sweep_tile_roles<0>, grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL(k_sweep_tile_roles<0>, (note_kernel(1, "k_sweep_tile_roles<0, false>"), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero, static_cast<const float *>(nullptr));
-  else if (R == 16)
-    hipLaunchKernelGGL((k_sweep_tile<16, 8, false>), grid, dim3(512), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
-                       row_id0, z, own, crp, rng, zero);
   else
-    hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), grid, dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
+    hipLaunchKernelGGL((k_sweep_tile<8, 16, false>), (note_kernel(1, "k_sweep_tile<8, 16, false>"), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows,
                        row_id0, z, own, crp, rng, zero);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1939,27 +1940,27 @@ int launch_sweep_roles_tail(hipStream_t stream, int num_cus, int kind, const Fea
   const bool wide = K > (uint32_t)kGroupTile + 64;
   if (kind == 2) {
     const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap)));
-    if (!wide) hipLaunchKernelGGL((k_sweep_lookups<false, 1>), g, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
-    else hipLaunchKernelGGL((k_sweep_lookups<false, 2>), g, dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    if (!wide) hipLaunchKernelGGL((k_sweep_lookups<false, 1>), (note_kernel(1, "k_sweep_lookups<false, 1>"), g), dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+    else hipLaunchKernelGGL((k_sweep_lookups<false, 2>), (note_kernel(1, "k_sweep_lookups<false, 2>"), g), dim3(1024), 0, stream, feats_dev, nfeat, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (kind == 1) {
     const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 16 * kNichPackWaves - 1) / (16 * kNichPackWaves), cap * (16 / kNichPackWaves))));
     const dim3 b(kNichPackWaves * 64);
     if (nsplit > 0) {
-      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 1>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
-      else hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 2>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 1>), (note_kernel(1, "k_sweep_nich_pack<false, true, 1>"), g), b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      else hipLaunchKernelGGL((k_sweep_nich_pack<false, true, 2>), (note_kernel(1, "k_sweep_nich_pack<false, true, 2>"), g), b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
     } else {
-      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 1>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
-      else hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 2>), g, b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      if (!wide) hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 1>), (note_kernel(1, "k_sweep_nich_pack<false, false, 1>"), g), b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
+      else hipLaunchKernelGGL((k_sweep_nich_pack<false, false, 2>), (note_kernel(1, "k_sweep_nich_pack<false, false, 2>"), g), b, 0, stream, feats_dev, nsplit, K, kpad, row0, nrows, row_id0, z, own, crp, rng, zero, tail);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (K <= (uint32_t)kGroupTile + 64)
-    hipLaunchKernelGGL(k_sweep_tile_roles<1>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
+    hipLaunchKernelGGL(k_sweep_tile_roles<1>, (note_kernel(1, "k_sweep_tile_roles<1, false>"), dim3((unsigned)(gx ? gx : 1))), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
                        row0, nrows, row_id0, z, own, crp, rng, zero, tail);
   else
-    hipLaunchKernelGGL(k_sweep_tile_roles<2>, dim3((unsigned)(gx ? gx : 1)), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
+    hipLaunchKernelGGL(k_sweep_tile_roles<2>, (note_kernel(1, "k_sweep_tile_roles<2, false>"), dim3((unsigned)(gx ? gx : 1))), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad,
                        row0, nrows, row_id0, z, own, crp, rng, zero, tail);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

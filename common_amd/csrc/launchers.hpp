@@ -49,7 +49,6 @@ int launch_crp_prepare(hipStream_t stream, const uint32_t *cnt, uint32_t K, uint
 int launch_entity_op(hipStream_t stream, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row,
                      uint32_t group, int sign, long long *cnt_acc, uint32_t *cnt_u32, float alpha, float *crp, int32_t *z_slot);
 int launch_set_i32(hipStream_t stream, int32_t *dst, int32_t value);
-int tile_rows_per_wave();   // tile kernels: rows per wave, 8 (16 waves, default) or 16 (8 waves) via MSC_TILE_ROWS
 int launch_loo_own(hipStream_t stream, int num_cus, bool heavy, bool staged, const FeatDesc *feats_dev, int nfeat, uint32_t K, uint32_t kpad, uint64_t row0,
                    uint64_t nrows, const int32_t *z, const float *crp, float *own);
 int launch_gp_large_fix(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int f, uint32_t K,
@@ -121,6 +120,13 @@ int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const
 int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);
+
+// which kernel INSTANTIATION the library chose for the most recent scoring pass (slot 0) / fused assignment pass (slot 1),
+// spelled as rocprofv3 spells it ("k_score_tile_roles<false, false, false>"): bench.py and tools/ key the committed
+// counter summaries by it (msc_last_kernel, include/microscopes_hip.h).  Process-wide, set by the launchers.
+void note_kernel(int slot, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+const char *last_kernel(int slot);
+inline const char *tf(bool b) { return b ? "true" : "false"; }
 
 // kernels_sweep.hip  (return -2: shape not covered by this kernel)
 int launch_sweep_nich1(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, uint32_t K,
@@ -204,6 +210,7 @@ int launch_col_max_u32(hipStream_t stream, const uint32_t *col, uint64_t n, uint
 int launch_mask_sentinel(hipStream_t stream, const void *col, const uint8_t *mask, uint64_t n, bool bytes, uint32_t sentinel, void *out);
 int launch_pack_bits(hipStream_t stream, const void *const *cols, int m, uint32_t radix, uint64_t n, void *out);
 int launch_pack_nich_x(hipStream_t stream, const float *const *cols_dev, uint32_t n2, uint32_t n2p, uint64_t n, float *out);
+int launch_pack_look_idx(hipStream_t stream, const LookIdxSrc *src_dev, uint32_t nsrc, uint32_t l4, uint64_t n, uint32_t *out);
 int launch_fuse_tables(hipStream_t stream, const FeatDesc *feats_dev, int nsplit, int nblocks, uint32_t kpad);
 int launch_unpack(hipStream_t stream, const uint8_t *records, const uint8_t *mask, uint64_t nrows,
                   uint32_t rowsize, uint32_t maskrowsize, const void *feats_dev, uint32_t nfeat);

@@ -193,6 +193,21 @@ struct FeatDesc {
   // the accumulate pass's copy of a fused bb feature (abi.cpp plan_groups, desc_acc): the members' additive tables, in the
   // members' order -- one read of the byte column and of z feeds all of them (k_accumulate)
   long long *fuse_acc[4];
+  // the first phase's LOOKUP INDEX MATRIX (round 5; abi.cpp look_idx_matrix, k_pack_look_idx): for the kernels whose first
+  // phase is staged lookup runs only (role-split, lookups-only; PAIR mode too) every row's lookups as ready-made SLOT ROWS --
+  // grp_off + the value clamped into the feature's block, one byte a feature, the features of an LDS feature group side by
+  // side from a dword boundary on -- so a lookup wave fetches a group's indices for its rows with ONE load per group and
+  // lane instead of a descriptor head, a value load, a clamp and a broadcast per feature.  Kept by the view (key: columns,
+  // kinds, clamps and slot offsets).  lk_idx / lk_l4 at the plan's FIRST feature (null: the plan does not take those
+  // kernels), lk_goff at every group's first feature.
+  const uint32_t *lk_idx;  // uint32 [view rows][lk_l4] (+ 3 dwords of slack)
+  uint32_t lk_l4;          // dwords per row
+  uint32_t lk_goff;        // the group's first dword inside a row's record
+};
+// one feature of the index matrix as k_pack_look_idx reads it
+struct LookIdxSrc {
+  const void *col;
+  uint32_t kind, clamp, grp_off, byte_at;   // byte_at: the feature's byte inside a row's record
 };
 constexpr uint32_t kLooSlotFloats = 32768;   // 128 KiB: one workgroup of k_loo_own_lds (1024 threads) per CU
 constexpr int kLooStageFeats = 6;            // features a stage holds at most (their row values travel in registers)
@@ -371,6 +386,9 @@ struct msc_dataview {
   mutable std::vector<std::pair<std::vector<const void *>, const void *>> packed_bits;
   // float [nrows][n2p] of the columns in the key, position-major (msc::NichPos; abi.cpp nich_x_matrix)
   mutable std::vector<std::pair<std::vector<const void *>, const float *>> nich_x;
+  // uint32 [nrows][l4] lookup index matrices (msc::FeatDesc::lk_idx; abi.cpp look_idx_matrix); key: per feature
+  // {column, kind, clamp, slot offset, byte} flattened
+  mutable std::vector<std::pair<std::vector<uint64_t>, const uint32_t *>> look_idx;
 };
 
 struct msc_feature_host {

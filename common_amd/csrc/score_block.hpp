@@ -134,9 +134,6 @@ template <bool NT = true>
 MSC_DEV void store_row(float *__restrict__ out, uint64_t ld, uint64_t row, uint32_t kb, uint32_t K,
                        float4 s, bool vec_ok) {
   float *p = out + row * ld + kb;
-#ifdef MSC_EXP_NO_STORE                                   // (timing experiment: only a NaN row is stored)
-  if (!(s.x != s.x)) return;
-#endif
   if (vec_ok && kb + 3 < K) {
     const f32x4 v = {s.x, s.y, s.z, s.w};
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
@@ -410,9 +407,6 @@ struct WaveSubsetBarrier {
   uint32_t *counter;                                    // in LDS, zeroed by the workgroup before first use
   uint32_t passed;
   MSC_DEV void operator()() {
-#ifdef MSC_EXP_NO_LBAR                                    // (timing experiment)
-    return;
-#endif
     passed++;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -443,19 +437,15 @@ MSC_DEV void stage_group(const FeatDesc *__restrict__ feats, int f0, int f1, uin
       // the first 128 groups of two table rows per wave instruction: lanes 0-31 row 2 q, lanes 32-63 row 2 q + 1; in the
       // slot a table row is 32 float4 (an odd block's last instruction writes with its upper half masked off)
       float4 *dst = lds + (size_t)fd.grp_off * 32;
-#ifndef MSC_EXP_NO_COPY
       for (uint32_t q = (uint32_t)wave; 2u * q < fd.grp_rows; q += W) {
         const uint32_t row = 2u * q + ((uint32_t)lane >> 5);
         if (row < fd.grp_rows) glds16(tile + (size_t)row * kpad + 4 * (lane & 31), dst + q * 64);
       }
-#endif
       continue;
     }
     float4 *dst = lds + (size_t)fd.grp_off * 64;
-#ifndef MSC_EXP_NO_COPY                                   // (timing experiment: DESIGN.md section 5, round 4)
     for (uint32_t row = (uint32_t)wave; row < fd.grp_rows; row += W)     // one 1 KiB table row per wave instruction
       glds16(tile + (size_t)row * kpad + 4 * lane, dst + row * 64);
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the group's tables has landed
   bar();                                                // ... everyone's
@@ -525,33 +515,45 @@ template <int C> MSC_DEV float &comp(float4 &v) {
 }
 // (PAIR: sums r holds the wave's rows 2 r -- components 0, 1 -- and 2 r + 1 -- components 2, 3 --, against the SAME two
 // groups: the part for C0 = 2 takes the same constants and the other row's values)
-template <int M, int R, int C0, int NC, bool EST, bool PAIR = false>
-MSC_DEV void nich_block_rows(const float (&xv)[M], const float (&mh)[M][NC], const float (&ml)[M][NC], const float (&sc)[M][NC],
-                             const float (&c1l)[NC], float4 (&acc)[R]) {
-#pragma unroll
-  for (int r = 0; r < R; r++) {
+// (XS: the source hands out a wave row's values as SCALAR operands -- NichPacked::xs, s_load from the x matrix --; without
+// it they are broadcast from the lanes that hold them, one v_readlane per use)
+template <int M, int R, int C0, int NC, bool EST, bool PAIR = false, typename Src>
+MSC_DEV void nich_block_rows(const Src &src, int f, const float (&xv)[M], const float (&mh)[M][NC], const float (&ml)[M][NC],
+                             const float (&sc)[M][NC], const float (&c1l)[NC], float4 (&acc)[R]) {
+  auto squares = [&](int r, float (&t)[NC][M]) {
     float x[M];
+    if constexpr (Src::kScalarX) {
+      src.template xs<M>(f, PAIR ? 2 * r + C0 / 2 : r, x);
+    } else {
 #pragma unroll
-    for (int j = 0; j < M; j++) x[j] = lane_bcast(xv[j], PAIR ? 2 * r + C0 / 2 : r);
-    float p[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-      float t[M];
-#pragma unroll
-      for (int j = 0; j < M; j++) t[j] = nich_t(x[j], mh[j][c], ml[j][c], sc[j][c]);
-      p[c] = nich_block_product<M>(t);
+      for (int j = 0; j < M; j++) x[j] = lane_bcast(xv[j], PAIR ? 2 * r + C0 / 2 : r);
     }
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+      for (int j = 0; j < M; j++) t[c][j] = nich_t(x[j], mh[j][c], ml[j][c], sc[j][c]);
+  };
+  auto finish = [&](int r, const float (&p)[NC]) {
     if constexpr (NC >= 1) comp<C0>(acc[r]) = nich_block_finish<EST>(comp<C0>(acc[r]), p[0], c1l[0]);
     if constexpr (NC >= 2) comp<C0 + 1>(acc[r]) = nich_block_finish<EST>(comp<C0 + 1>(acc[r]), p[1], c1l[1]);
     if constexpr (NC >= 4) {
       comp<C0 + 2>(acc[r]) = nich_block_finish<EST>(comp<C0 + 2>(acc[r]), p[2], c1l[2]);
       comp<C0 + 3>(acc[r]) = nich_block_finish<EST>(comp<C0 + 3>(acc[r]), p[3], c1l[3]);
     }
+  };
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    float t[NC][M], p[NC];
+    squares(r, t);
+#pragma unroll
+    for (int c = 0; c < NC; c++) p[c] = nich_block_product<M>(t[c]);
+    finish(r, p);
     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four rows of temporaries at a time)
   }
 }
 // where a block's constants come from: the tables in L2 (the role-split kernels' nich waves) ...
 struct NichFromGlobal {
+  static constexpr bool kScalarX = false;
   const FeatDesc *__restrict__ feats;
   uint32_t kpad, kb;
   // BUFFER loads: the feature's table as a raw buffer (scalar descriptor: base and size), the row and pair as the scalar
@@ -584,10 +586,23 @@ struct NichFromGlobal {
 // for the whole phase -- its descriptor four scalar registers for the kernel's life, a row's offset scalar arithmetic --
 // and the rows' values from the x matrix; `f` is a POSITION of the second phase here.  (Through the plan's descriptors
 // every block began with a dozen scalar loads, each waiting for the one before: the nich waves issued half the time.)
+typedef const __attribute__((address_space(4))) float *scalar_floats;
 struct NichPacked {
+  static constexpr bool kScalarX = true;
   __amdgpu_buffer_rsrc_t pack;
   const float *__restrict__ xrow;                          // this lane's row of the x matrix
   uint32_t kpad, kb;
+  // the wave's rows of the x matrix as SCALAR operands (round 5): row r of the wave's, positions f .. f + M - 1, by s_load
+  // from (wave-uniform) xwave + min(r, last) * n2p + f.  (Broadcast from the lanes that hold them they cost a v_readlane per
+  // use on the vector pipe -- and the compiler kept the 64 broadcasts of a block across its two parts in scalar registers
+  // it did not have: 110-134 of them spilled through v_writelane, profiles/r05_regs.txt.)
+  scalar_floats xwave;
+  int n2p, last;                                           // last: the wave's last row with data (rows beyond repeat it)
+  template <int M> MSC_DEV void xs(int f, int r, float (&o)[M]) const {
+    const scalar_floats q = xwave + (size_t)((r < last ? r : last) * n2p + f);
+#pragma unroll
+    for (int j = 0; j < M; j++) o[j] = q[j];
+  }
   typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
   static MSC_DEV int pack_row(int nich_row) {
@@ -621,6 +636,7 @@ struct NichPacked {
 };
 // ... or the staged feature group in LDS (the kernels that run the phases one after the other)
 struct NichFromLds {
+  static constexpr bool kScalarX = false;
   const FeatDesc *__restrict__ feats;
   const float4 *__restrict__ lds;
   int lane;
@@ -655,14 +671,14 @@ MSC_DEV void nich_block_part(const FeatDesc *__restrict__ feats, int f, const Sr
     src.template comps<NC>(f + j, NICH_C2, CG, sc[j]);
   }
   src.template comps<NC>(f, NICH_C1LN2, CG, c1l);
-  nich_block_rows<M, R, C0, NC, EST, PAIR>(xv, mh, ml, sc, c1l, acc);
+  nich_block_rows<M, R, C0, NC, EST, PAIR>(src, f, xv, mh, ml, sc, c1l, acc);
   __builtin_amdgcn_sched_barrier(0);                          // (the next part's constants after this part's rows)
 }
 template <int M, int R, bool EST, typename Src, bool PAIR = false, int NCSEL = MSC_NICH_NC>
 MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &src, uint64_t myrow, float4 (&acc)[R]) {
   float xv[M];
 #pragma unroll
-  for (int j = 0; j < M; j++) xv[j] = src.x(f + j, myrow);
+  for (int j = 0; j < M; j++) xv[j] = Src::kScalarX ? 0.f : src.x(f + j, myrow);
   if constexpr (PAIR) {
     // the lane's two groups against one row of every pair, then against the other.  The constants are fetched again for
     // the second half (an L1 hit), as the four-group form fetches its second part's: kept across both halves they cost the
@@ -789,7 +805,10 @@ MSC_DEV void nich_phase_packed(const FeatDesc *__restrict__ feats, int f0, uint3
   const scalar_pos pos = (scalar_pos)sf[f0].rn_pos;
   const int n2 = uniform((int)sf[f0].rn_n2), n2p = uniform((int)sf[f0].rn_n2p);
   const float *const xrow = sf[f0].rn_x + myrow * (uint64_t)n2p;
-  const NichPacked src{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packp), 0, 0x7fffffff, 0x00020000), xrow, kpad, kb};
+  // (lane 0's row is the wave's first: its own first row, or -- a wave without rows -- the call's first)
+  const uint64_t wave_row = ((uint64_t)(uint32_t)uniform((int)(myrow >> 32)) << 32) | (uint32_t)uniform((int)(uint32_t)myrow);
+  const NichPacked src{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packp), 0, 0x7fffffff, 0x00020000), xrow, kpad, kb,
+                       (scalar_floats)(sf[f0].rn_x + wave_row * (uint64_t)n2p), n2p, (nr > 0 ? nr : 1) - 1};
   // far rows (bit r: the wave's row r; NaN included): the row's values a quad at a time against the positions' limits
   // (the padding: value 0 against +inf)
   bool far = false;
@@ -931,6 +950,68 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
   const uint32_t kb = ktile * kGroupTile + lane * 4;
   const bool has_row = lane < nr;
   const uint64_t myrow = row_abs0 + lane;
+  if constexpr (!GENERIC) {
+    // ---- lookup runs from the plan's INDEX MATRIX (round 5; FeatDesc::lk_idx, abi.cpp look_idx_matrix) ----
+    // A feature used to be a chain descriptor head -> value load -> clamp -> broadcast -> LDS reads (the pipeline below,
+    // which the kernels with generic features keep); here a row's lookups arrive ready-made: per feature group ONE 16-byte
+    // load per lane (lane r: row r's slot rows for up to sixteen features of the group, a byte each), issued before the
+    // group's table copies so that its latency lies under theirs.  A dword of it serves four features: its sixteen
+    // (PAIR: thirty-two) rows' words are broadcast once (v_readlane) and a lookup is then s_bfe (scalar unit) +
+    // v_lshl_add + ds_read + the adds.  Same table rows added in the same order: same bits.
+    constexpr int RWI = PAIR ? 2 * R : R;
+    typedef uint32_t u32x4i __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4i *gu32x4_p;
+    typedef const __attribute__((address_space(1))) uint32_t *gu32_p;
+    const scalar_feats sf = as_scalar(feats);
+    const uint32_t l4 = (uint32_t)uniform((int)sf[0].lk_l4);
+    const gu32_p rec = (gu32_p)sf[0].lk_idx + (has_row ? myrow : row_safe) * (uint64_t)l4;
+    for (int f0 = 0; f0 < nfeat;) {
+      const int f1 = uniform((int)sf[f0].grp_end), ng = f1 - f0;
+      const uint32_t goff = (uint32_t)uniform((int)sf[f0].lk_goff);
+      u32x4i w = *(gu32x4_p)(rec + goff);                // (dword-aligned; the matrix ends in three dwords of slack)
+      stage_group<W, PAIR>(feats, f0, f1, kpad, ktile, lane, wave, lds, bar);
+      for (int q = 0; 4 * q < ng; q = uniform(q + 1)) {
+        if (q != 0 && (q & 3) == 0) w = *(gu32x4_p)(rec + goff + q);       // (a group of more than sixteen features)
+        const int c = q & 3;
+        const uint32_t word = c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w;
+        uint32_t sw[RWI];
+#pragma unroll
+        for (int r = 0; r < RWI; r++) sw[r] = (uint32_t)lane_bcast((int)word, r);
+        const int nj = ng - 4 * q < 4 ? ng - 4 * q : 4;
+        for (int j = 0; j < nj; j = uniform(j + 1)) {
+          const uint32_t sh = 8u * (uint32_t)j;
+          if constexpr (PAIR) {
+            const float2 *buf2 = reinterpret_cast<const float2 *>(lds) + lane;
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += 4) {
+              float2 ta[4], tb[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) {
+                ta[jj] = buf2[((sw[2 * (r0 + jj)] >> sh) & 0xffu) * 64u];
+                tb[jj] = buf2[((sw[2 * (r0 + jj) + 1] >> sh) & 0xffu) * 64u];
+              }
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) add4(acc[r0 + jj], make_float4(ta[jj].x, ta[jj].y, tb[jj].x, tb[jj].y));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+            const float4 *buf = lds + lane;
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += 4) {
+              float4 t[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) t[jj] = buf[((sw[r0 + jj] >> sh) & 0xffu) * 64u];
+#pragma unroll
+              for (int jj = 0; jj < 4; jj++) add4(acc[r0 + jj], t[jj]);
+              __builtin_amdgcn_sched_barrier(0);          // four reads in flight, not eight: 16 fewer live registers
+            }
+          }
+        }
+      }
+      f0 = f1;
+    }
+    return;
+  }
   int f0 = 0;
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].grp_end;
@@ -962,9 +1043,6 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
         const uint64_t byte = u8 ? ldrow : ldrow * 4;
         const uint64_t base = reinterpret_cast<uint64_t>(h.col);
         const uint64_t at = (base + byte) & ~(uint64_t)3;     // (the columns are dword-aligned for 32-bit types anyway)
-#ifdef MSC_EXP_NO_VALUES                                  // (timing experiment: no value loads, every row looks up entry `lane & 1`)
-        return (uint32_t)(at & 4u) >> 2;
-#endif
         return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((g_u8)at);
       };
       auto index_of = [&](const Head &h, uint32_t word) -> uint32_t {
@@ -975,10 +1053,6 @@ MSC_DEV void score_tile_groups(const FeatDesc *__restrict__ feats, int nfeat, ui
       };
       auto lookups = [&](const Head &h, uint32_t idx) {
         const float4 *buf = lds + (size_t)h.off * 64 + lane;
-#ifdef MSC_EXP_NO_LOOKUPS                                 // (timing experiment: the value is still fetched and used)
-        acc[0].x += __uint_as_float(idx & 1u);
-        return;
-#endif
         if constexpr (PAIR) {
           const float2 *buf2 = reinterpret_cast<const float2 *>(lds) + (size_t)h.off * 64 + lane;
 #pragma unroll

@@ -86,6 +86,11 @@ class Context(object):
     def build_info(self):
         return self.lib.msc_build_info().decode()
 
+    def last_kernel(self, which="score"):
+        """the kernel instantiation of this process's most recent scoring ("score") or fused assignment ("sweep") pass, as
+        rocprofv3 spells it (msc_last_kernel): what bench.py keys the committed counter summaries by"""
+        return self.lib.msc_last_kernel(0 if which == "score" else 1).decode()
+
     def value_op(self, family, dim, op, hp, ss_record, value=None):
         """One group::{add_value, remove_value, score_value, score_data} call (base.hpp:25-28) as a batch
         of one on the device.  op: "add" | "remove" | "score_value" | "score_data".  `ss_record` is a

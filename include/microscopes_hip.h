@@ -85,6 +85,14 @@ typedef struct msc_state msc_state;
 int msc_abi_version(void);
 const char *msc_last_error(void);
 const char *msc_build_info(void); /* "gfx950 hipcc <ver> ..." */
+/*
+ * Which kernel INSTANTIATION the library chose for this process's most recent scoring pass (which = 0: msc_score_value)
+ * or fused assignment pass (which = 1: msc_sweep_assign / msc_sweep_step), spelled as rocprofv3 spells it, e.g.
+ * "k_score_tile_roles<false, false, false>" ("" before the first such call).  Measurement tooling only: bench.py keys the
+ * committed counter summaries (profiles/ *_pmc.json) by it, so that a roofline figure is always the figure of the kernel
+ * that ran.  Nothing comparable upstream (the reference has no kernels).
+ */
+const char *msc_last_kernel(int which);
 
 /* stream: a hipStream_t (may be NULL = the device's null stream). */
 int msc_context_create(int device, void *stream, msc_context **out);

@@ -71,6 +71,38 @@ def main():
                     r = d[region[0]:region[1]]
                     fh.write("    bench.py's timed region = launches [%d, %d) of this kernel: avg %10.1f min %9d max %9d\n"
                              % (region[0], region[1], sum(r) / len(r), min(r), max(r)))
+    # further kernel traces of the same bench under other allocation regimes (tools/profile_round.sh: MSC_EXTRA_TRACES =
+    # "label=dir label=dir"): the headline kernel's instantiation differs with the regime (plain / non-temporal stores), and
+    # the line's `frac` must be reproducible from this file whichever regime the driver's box offers
+    for item in os.environ.get("MSC_EXTRA_TRACES", "").split():
+        label, d = item.split("=", 1)
+        tr = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)
+        if not tr:
+            continue
+        region2, headline2 = None, None
+        lg = os.path.join(out, "kt_%s.log" % label)
+        if os.path.exists(lg):
+            for ln in open(lg):
+                if ln.startswith("{"):
+                    try:
+                        roof = json.loads(ln).get("roofline", {})
+                        region2, headline2 = roof.get("timed_region_launches"), roof.get("kernel")
+                    except ValueError:
+                        pass
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr[0])):
+            if "k_score_nich1" in r["Kernel_Name"]:
+                dur[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        with open(os.path.join(out, tag + "_timed_region.txt"), "a") as fh:
+            fh.write("\n== the same bench command, regime \"%s\" (headline kernel: %s)\n" % (label, headline2))
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(d_ for _, d_ in kv[1])):
+                v.sort()
+                d_ = [x for _, x in v]
+                fh.write("%-60s launches %5d avg %10.1f\n" % (k[:60], len(d_), sum(d_) / len(d_)))
+                if region2 and headline2 and headline2 in k and len(d_) >= region2[1]:
+                    r = d_[region2[0]:region2[1]]
+                    fh.write("    bench.py's timed region = launches [%d, %d) of this kernel: avg %10.1f min %9d max %9d\n"
+                             % (region2[0], region2[1], sum(r) / len(r), min(r), max(r)))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in sys.argv[3:]:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
