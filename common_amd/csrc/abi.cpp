@@ -2375,8 +2375,17 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
       TailPlan tail;
       MSC_TRY(tail_plan(st, tail));
       tail.exact = false;                                  // (nothing else scores these groups for a draw: one sum per group)
-      if (launch_score_tail(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad,
-                            kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld) == 0) {
+      // (65 .. 128 groups beyond the tile on a role-split plan: ONE pass of the role-split kernel in PAIR mode at tile 1
+      // instead of three launches of the lane <-> row kernel -- round 5; by the plan and K alone, so a shard takes what the
+      // whole takes)
+      int tail_rc = -2;
+      if (st->tile_roles_ok && tail_ld == 128 && std::getenv("MSC_NO_PAIR") == nullptr)
+        tail_rc = launch_score_pair_tail(s, cus, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows,
+                                         z_dev, st->own, st->logpc, st->tail_scores, tail_ld);
+      if (tail_rc == -2)
+        tail_rc = launch_score_tail(s, cus, tail, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad,
+                                    kGroupTile, row0, nrows, z_dev, st->own, st->logpc, st->tail_scores - kGroupTile, tail_ld);
+      if (tail_rc == 0) {
         rc = launch_sweep_roles_tail(s, cus, st->tile_roles_ok ? 0 : st->tile_nich_only ? 1 : 2, st->desc_fuse_dev, (int)st->fuse_nfeat, (int)st->fuse_split, st->K, st->kpad, row0, nrows, row_id0,
                                      z_dev, st->own, st->logpc, st->rng_dev, zero, st->tail_scores);
         if (zeroed) *zeroed = rc == 0;
@@ -2607,6 +2616,13 @@ extern "C" int msc_state_reduce_unpack(msc_state *st) {
 // here, once; 0 = back to the view's count.
 extern "C" int msc_state_set_sweep_rows(msc_state *st, uint64_t global_rows) {
   MSC_REQUIRE(st, "null state");
+  if (st->sweep_rows_hint != global_rows && st->step_graph.exec) {
+    // (the hint chooses kernels -- lane <-> row or tile, PAIR mode, the narrow tiling -- for every view the state scores:
+    // a captured step holds the old choice, and replaying it would draw other bits than the whole does.  ADVICE r04)
+    (void)hipGraphExecDestroy(st->step_graph.exec);
+    st->step_graph.exec = nullptr;
+    st->step_graph.seen = 0;
+  }
   st->sweep_rows_hint = global_rows;
   return MSC_OK;
 }

@@ -390,6 +390,8 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   const float *X = reinterpret_cast<const float *>(fd.col);
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  // (round 5: giving the two waves of a SIMD different priorities (s_setprio by the parity of their slot) or starting one
+  // of them 2000 cycles late changed nothing -- 0.98-1.00 ms either way, profiles/r05_c4_notes.txt: they are not in lockstep)
   for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
     const uint64_t rb = blk * 16 * JB;
     float xf[JB][NS];            // this lane's feature of every step, for its row of each block

@@ -466,16 +466,30 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
     // 148 -> 164-177 us, the heads live in scalar registers that the evaluation then spills).  No branch around a load: a
     // slot past the stage's end reads the stage's last column again; a column of any type holds at least one dword per
     // row but a bool column, which is read by the byte.
+    // (Round 5: ONE dword load per value whatever the column's type -- a byte column: the aligned dword around the byte, the
+    // byte picked afterwards, as the tile kernels' lookup runs do.  Written as `u8 ? byte load : dword load` the compiler
+    // made a branch per feature with a full wait behind each: six exposed memory latencies a stage instead of one.)
     uint32_t w[kLooStageFeats][kLooRows];
+    uint32_t sh8[kLooStageFeats][kLooRows];                // byte columns: the byte's shift inside its dword, | 0x100
 #pragma unroll
     for (int fi = 0; fi < kLooStageFeats; fi++) {
       const FeatDesc &fd = feats[f0 + fi < f1 ? f0 + fi : f1 - 1];
       const bool u8 = fd.col_type == MSC_TYPE_B || fd.col_type == MSC_TYPE_I8 || fd.col_type == MSC_TYPE_U8;
+      const uint64_t cbase = reinterpret_cast<uint64_t>(fd.col);
 #pragma unroll
-      for (int j = 0; j < kLooRows; j++)
-        w[fi][j] = u8 ? (uint32_t)reinterpret_cast<const uint8_t *>(fd.col)[row[j]] : reinterpret_cast<const uint32_t *>(fd.col)[row[j]];
+      for (int j = 0; j < kLooRows; j++) {
+        const uint64_t at = cbase + (u8 ? row[j] : row[j] * 4);
+        w[fi][j] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(
+            (const __attribute__((address_space(1))) unsigned char *)(at & ~(uint64_t)3));
+        sh8[fi][j] = u8 ? (uint32_t)(at & 3u) * 8u + 0x100u : 0u;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my share of the blocks, and the values
+#pragma unroll
+    for (int fi = 0; fi < kLooStageFeats; fi++)
+#pragma unroll
+      for (int j = 0; j < kLooRows; j++)
+        if (sh8[fi][j] & 0x100u) w[fi][j] = (w[fi][j] >> (sh8[fi][j] & 31u)) & 0xffu;
     __syncthreads();
 #pragma unroll
     for (int fi = 0; fi < kLooStageFeats; fi++) {
@@ -751,7 +765,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
                                                                uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows,
                                                                const int32_t *__restrict__ z, const float *__restrict__ own,
                                                                const float *__restrict__ crp, float *__restrict__ out,
-                                                               uint64_t ld) {
+                                                               uint64_t ld, uint32_t kt0) {
   constexpr int R = kRoleRows, RW = PAIR ? 2 * kRoleRows : kRoleRows;   // sums / rows per wave
   __shared__ float4 lds[kGrpRows * 64];                   // the table slot; between chunks the hand-over
   __shared__ uint32_t lookers_arrived;                    // the lookup waves' own barrier (WaveSubsetBarrier)
@@ -761,7 +775,12 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
   __syncthreads();
   WaveSubsetBarrier<8> lbar{&lookers_arrived, 0u};
   const int pair = wave & 7;
-  const uint32_t kb = PAIR ? (uint32_t)lane * 2u : blockIdx.y * kGroupTile + lane * 4;
+  // kt: the k-tile.  PAIR mode takes the FIRST 128 groups of tile kt0 (round 5: kt0 = 1 scores a last tile of 65-128 groups
+  // beyond a full one -- 321 <= K <= 384 -- into a matrix of its own, `out` column j = group 256 kt0 + j: the fused sweeps'
+  // tail); Kt: the groups of that tile
+  const uint32_t kt = blockIdx.y + kt0;
+  const uint32_t kb = kt * kGroupTile + (PAIR ? (uint32_t)lane * 2u : (uint32_t)lane * 4u);
+  const uint32_t Kt = PAIR ? K - kt * kGroupTile : K;
   const bool vec_ok = PAIR ? ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0)
                            : ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const uint64_t rows_per_wg = 8 * RW;
@@ -794,7 +813,7 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = make_float4(0, 0, 0, 0);
       }
-      score_tile_groups<R, 8, false, false, PAIR>(feats, nsplit, kpad, blockIdx.y, lane, row0 + rb, nr, row0, lds, acc, lbar);
+      score_tile_groups<R, 8, false, false, PAIR>(feats, nsplit, kpad, kt, lane, row0 + rb, nr, row0, lds, acc, lbar);
       lbar();                                             // every lookup wave is done reading the slot's tables
 #pragma unroll
       for (int r = 0; r < R; r++) handover[r * 64] = acc[r];
@@ -832,7 +851,8 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
       le1 = crpq[2 * (size_t)kpad + 1];
     }
     if (LOO && CRP && lane < nr) single = gz >= 0 && (uint32_t)gz < K && __builtin_isinf(crpq[kpad + gz]) ? 1 : 0;
-    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != blockIdx.y)) gz = -1;   // not in this k-tile
+    if (LOO && gz >= 0 && ((uint32_t)gz >= K || (uint32_t)gz / kGroupTile != kt)) gz = -1;   // not in this k-tile
+    if (PAIR && gz >= 0) gz -= (int)(kt * kGroupTile);     // (PAIR: the lane that holds a group goes by its index in the tile)
     __syncthreads();                                      // (1) the lookup sums are in the slot
 #pragma unroll
     for (int r = 0; r < R; r++) {                         // (prior lo + lookups) + (nich features)
@@ -852,8 +872,8 @@ __global__ __launch_bounds__(1024, 4) void k_score_tile_roles(const FeatDesc *__
                                       LOO && lane_bcast(single, 2 * r + 1) ? le1 : le0));
         if (LOO)
           replace_own_pair(acc[r], lane, lane_bcast(gz, 2 * r), lane_bcast(sloo, 2 * r), lane_bcast(gz, 2 * r + 1), lane_bcast(sloo, 2 * r + 1));
-        if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, K, acc[r].x, acc[r].y, vec_ok);
-        if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, K, acc[r].z, acc[r].w, vec_ok);
+        if (2 * r < nr) store_half_row(out, ld, rb + 2 * r, lane, Kt, acc[r].x, acc[r].y, vec_ok);
+        if (2 * r + 1 < nr) store_half_row(out, ld, rb + 2 * r + 1, lane, Kt, acc[r].z, acc[r].w, vec_ok);
       } else {
         if (CRP) add4(acc[r], crp_prior4(hi, LOO && lane_bcast(single, r) ? le1 : le0));
         if (LOO) {
@@ -1666,8 +1686,18 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
                            (tile_rounds_us(c128 * ktiles, num_cus, false, narrow_tail.cost) - (ktiles > 1 ? tile_rounds_us(c128 * (ktiles - 1), num_cus, false, narrow_tail.cost) : 0.0));
     const bool many_rows = forced ? nrows >= (uint64_t)std::atoll(forced)
                                   : nrows >= kTailMinRows && tail_rows_us(K - (ktiles - 1) * kGroupTile, true, nrows, num_cus, narrow_tail.cost) < tile_us;
-    const bool tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
-                                                     (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
+    // a LAST tile of 65 .. 128 groups beyond full ones on the role-split kernels: PAIR mode at that tile (round 5) -- about
+    // 0.62 of a full tile's price, the tile kernels' own bits, where the lane <-> row kernel takes two or three launches
+    const uint32_t last_groups = K - (ktiles - 1) * kGroupTile;
+    bool tail = false;
+    if (ktiles > 1 && path == MSC_PATH_TILE_ROLES && !small4 && last_groups > 64 && last_groups <= 128 && pair_mode_ok(path, last_groups, false)) {
+      hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), (note_kernel(0, "k_score_tile_roles<%s, %s, true>", tf(LOO), tf(CRP)), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1)), dim3(1024), 0, stream,
+                         feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out + (size_t)(ktiles - 1) * kGroupTile, ld, ktiles - 1);
+      tail = true;
+    }
+    if (!tail)
+      tail = many_rows && launch_score_tail(stream, num_cus, narrow_tail, feats_dev, nfeat, nsplit, K, kpad,
+                                            (ktiles - 1) * kGroupTile, row0, nrows, z, own, crp, out, ld) == 0;
     if (tail && ktiles == 1) return;
     const dim3 grid((unsigned)gx, tail ? ktiles - 1 : ktiles);
     if (path == MSC_PATH_TILE_DM)
@@ -1697,10 +1727,10 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
     }
     else if (pair)
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP, true>), (note_kernel(0, "k_score_tile_roles<%s, %s, true>", tf(LOO), tf(CRP)), dim3((unsigned)std::min<uint64_t>((nrows + 255) / 256, cap), 1)), dim3(1024), 0, stream,
-                         feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld);
+                         feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, out, ld, 0u);
     else if (!small4 && path == MSC_PATH_TILE_ROLES && tile_roles_enabled())
       hipLaunchKernelGGL((k_score_tile_roles<LOO, CRP>), (note_kernel(0, "k_score_tile_roles<%s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
-                         nrows, z, own, crp, out, ld);
+                         nrows, z, own, crp, out, ld, 0u);
     else if (small2)
       hipLaunchKernelGGL((k_score_tile<2, 16, LOO, CRP, false>), (note_kernel(0, "k_score_tile<2, 16, %s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
@@ -1711,6 +1741,18 @@ static void launch_score_t(hipStream_t stream, int num_cus, int path, const Tail
       hipLaunchKernelGGL((k_score_tile<8, 16, LOO, CRP, false>), (note_kernel(0, "k_score_tile<8, 16, %s, %s, false>", tf(LOO), tf(CRP)), grid), dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0,
                          nrows, z, own, crp, out, ld);
   }
+}
+
+// The groups 256 .. K - 1 (65 .. 128 of them) of a role-split plan, leave-one-out value and prior included, into
+// tail[row * ld + (group - 256)]: the role-split kernel in PAIR mode at k-tile 1 (round 5) -- one pass at about 0.62 of a
+// full tile's price where the lane <-> row kernel took three launches of up to 48 groups.  The tile kernels' sums.
+int launch_score_pair_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K, uint32_t kpad,
+                           uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp, float *tail, uint64_t ld) {
+  if (K <= (uint32_t)kGroupTile + 64u || K > (uint32_t)kGroupTile + 128u || z == nullptr || crp == nullptr) return -2;
+  const uint64_t cap = (uint64_t)num_cus * 4;
+  hipLaunchKernelGGL((k_score_tile_roles<true, true, true>), (note_kernel(0, "k_score_tile_roles<true, true, true>"), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nrows + 255) / 256, cap)), 1)),
+                     dim3(1024), 0, stream, feats_dev, nfeat, nsplit, K, kpad, row0, nrows, z, own, crp, tail, ld, 1u);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // own: per-row leave-one-out values from launch_loo_own (required when z != null)

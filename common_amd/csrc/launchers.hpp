@@ -117,6 +117,8 @@ struct ZeroSpans {
 int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                       uint32_t kpad, uint64_t row0, uint64_t nrows, uint64_t row_id0, int32_t *z, const float *own, const float *crp,
                       const uint64_t *rng, ZeroSpans zero);
+int launch_score_pair_tail(hipStream_t stream, int num_cus, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K, uint32_t kpad,
+                           uint64_t row0, uint64_t nrows, const int32_t *z, const float *own, const float *crp, float *tail, uint64_t ld);
 int launch_score(hipStream_t stream, int num_cus, int path, const TailPlan &narrow_tail, int nich1_shape, const FeatDesc *feats_dev, int nfeat, int nsplit,
                  uint32_t K, uint32_t kpad, uint64_t row0, uint64_t nrows, const int32_t *z,
                  const float *own, const float *crp, float *out, uint64_t ld);

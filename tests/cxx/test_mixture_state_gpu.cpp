@@ -76,6 +76,7 @@ int main() {
   hy[0]->get_hp_mutator("alpha").set<float>(2.f);
   hy[0]->get_hp_mutator("beta").set<float>(2.f);
   std::map<size_t, std::vector<models::group_shared_ptr>> twin;
+  std::map<size_t, int> twin_updates;                        // per gid: add / remove calls the twin's groups have lived through
   auto twin_group = [&](size_t gid) -> std::vector<models::group_shared_ptr> & {
     auto it = twin.find(gid);
     if (it == twin.end()) {
@@ -88,6 +89,7 @@ int main() {
   auto twin_apply = [&](size_t gid, size_t eid, bool add) {
     auto acc = data.get(eid);
     auto &gs = twin_group(gid);
+    twin_updates[gid]++;
     for (size_t f = 0; f < 4; f++, acc.bump()) {
       if (add) gs[f]->add_value(*hy[f], acc.get(), rng);
       else gs[f]->remove_value(*hy[f], acc.get(), rng);
@@ -132,6 +134,14 @@ int main() {
         mag += std::max(1.0, std::fabs(s));
       }
       CHECK(audit::sum("mixture_state.score_value.prior_plus_4_components", sc.second[i], want, mag));
+      // ... and END TO END against the independent twin, whose groups lived through the same add / remove calls value by
+      // value and never saw the device's tables (a wrong but self-consistent table passes the check above).
+      // Its float fields are a chain of float roundings where the state's are one rounding of double sums: 2e-5 of the
+      // terms' magnitudes, the gate rounds 1-3 held this comparison to (the difference of STATE is gated on its own below)
+      double indep = std::log(cnt ? double(cnt) : 1.5 / double(iface.empty_groups().size()));
+      auto acc2 = data.get(e);
+      for (size_t f = 0; f < 4; f++, acc2.bump()) indep += twin_group(gid)[f]->score_value(*hy[f], acc2.get(), rng);
+      CHECK(audit::check("mixture_state.score_value.vs_independent_twin_2e-5", std::fabs(sc.second[i] - indep) / std::fmax(mag, std::fabs(indep)), 2e-5));
     }
     // the state's float fields against the value-by-value twin (nich: mean, count_times_variance; gp: log_prod): one
     // half-ulp per update the twin has seen; the integer fields byte for byte
@@ -141,7 +151,7 @@ int main() {
         if (f == 0 || f == 2) { CHECK(iface.get_suffstats(f, gid) == twin_group(gid)[f]->get_ss()); continue; }
         auto own = hy[f]->create_group(rng);
         own->set_ss(iface.get_suffstats(f, gid));
-        const int nupd = int(2 * N);                             // (an upper bound on the updates any twin group has seen)
+        const int nupd = twin_updates[gid];                      // (the updates THIS group's twin has lived through)
         if (f == 1) {
           const auto &a = static_cast<models::distributions_group<distributions::GammaPoisson> &>(*own).repr_;
           const auto &b = static_cast<models::distributions_group<distributions::GammaPoisson> &>(*twin_group(gid)[f]).repr_;

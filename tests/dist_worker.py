@@ -63,6 +63,8 @@ def main():
     dist.all_gather_object(gathered, [t.cpu().numpy() for t in z_after])
     counts = st.get_group_counts()
     ss = [st.get_ss(f) for f in range(len(spec))]
+    seen = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)             # every rank adds 1 over the group the sweeps' all-reduce used
     res = None
     if rank == 0:
         z_sharded = [np.concatenate([gathered[r][s] for r in range(world)]) for s in range(nsweeps)]
@@ -77,7 +79,7 @@ def main():
             st1.sweep_step(view1, z1, seed=5, sweep=s)
             same.append(float((z1.cpu().numpy() == z_sharded[s]).mean()))
         zf = z_sharded[-1]
-        res = {"world": world, "backend": backend, "N": N, "K": K, "which": which,
+        res = {"world": world, "ranks_seen": int(seen.item()), "backend": backend, "N": N, "K": K, "which": which,
                "same_fraction_per_sweep": same,
                "counts_equal_bincount": bool(np.array_equal(counts, np.bincount(zf, minlength=K))),
                "counts_equal_unsharded": bool(np.array_equal(counts, st1.get_group_counts())),
