@@ -444,9 +444,19 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
     }
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // The values of this thread's rows for every feature of a stage are fetched in one breath: one exposed memory latency per
+  // stage instead of one per feature.  ONE dword load per value whatever the column's type (round 5) -- a byte column: the
+  // aligned dword around the byte, the byte picked afterwards, as the tile kernels' lookup runs do; written as
+  // `u8 ? byte load : dword load` the compiler made a branch per feature with a full wait behind each.  No branch around a
+  // load: a slot past the stage's end reads the stage's last column again.
+  // (Fetching them a stage AHEAD -- asked for right after this stage's block copies, waited for a stage later -- does not
+  // pay: round 3 measured 148 -> 162 us with four rows a thread (126 registers); round 5, with the single-load form, 139 ->
+  // 241 us at four rows (69 spilled registers) and 171 -> 174 us at two rows a thread, where two rows without it take 171:
+  // the value latency is not what a stage waits for.  profiles/r05_loo_accumulate.txt)
   int f0 = 0;
   while (f0 < nfeat) {
     const int f1 = (int)feats[f0].loo_stage_end;           // (at most kLooStageFeats features: abi.cpp plan_groups)
+    uint32_t w[kLooStageFeats][kLooRows];
     __syncthreads();                                      // the slot's previous readers are done
     // the blocks, 1 KiB per wave instruction straight into LDS (global_load_lds_dwordx4) ...
     for (int f = f0; f < f1; f++) {
@@ -459,17 +469,7 @@ __global__ __launch_bounds__(kLooThreads) void k_loo_own_lds(const FeatDesc *__r
       for (uint32_t c = (uint32_t)wave; c < nchunks; c += kLooThreads / 64)
         glds16(src + (size_t)c * 256 + 4 * lane, dst + (size_t)c * 64);
     }
-    // ... and, in the same breath, the values of this thread's rows for every feature of the stage: one exposed memory
-    // latency per stage instead of one per feature (fetching them a stage AHEAD, under the evaluation of the stage
-    // before, measured slower: 148 -> 162 us on C3, 126 registers; so did what the kernel needs of a descriptor packed
-    // into a 48-byte head and the stage's heads read up front: a stage of sixteen bool columns 33 -> 18 us, C3's mix
-    // 148 -> 164-177 us, the heads live in scalar registers that the evaluation then spills).  No branch around a load: a
-    // slot past the stage's end reads the stage's last column again; a column of any type holds at least one dword per
-    // row but a bool column, which is read by the byte.
-    // (Round 5: ONE dword load per value whatever the column's type -- a byte column: the aligned dword around the byte, the
-    // byte picked afterwards, as the tile kernels' lookup runs do.  Written as `u8 ? byte load : dword load` the compiler
-    // made a branch per feature with a full wait behind each: six exposed memory latencies a stage instead of one.)
-    uint32_t w[kLooStageFeats][kLooRows];
+    // ... and, in the same breath, this stage's values
     uint32_t sh8[kLooStageFeats][kLooRows];                // byte columns: the byte's shift inside its dword, | 0x100
 #pragma unroll
     for (int fi = 0; fi < kLooStageFeats; fi++) {
