@@ -541,6 +541,8 @@ MSC_DEV void nich_block_rows(const Src &src, int f, const float (&xv)[M], const 
       comp<C0 + 3>(acc[r]) = nich_block_finish<EST>(comp<C0 + 3>(acc[r]), p[3], c1l[3]);
     }
   };
+  // (asking for four rows' values TOGETHER -- one wait a batch instead of the load-wait-use per row the compiler makes of the
+  // rows after the first four -- left the scoring kernels where they were and cost the sweep 6 %: its registers.  r05_c3_notes.txt)
 #pragma unroll
   for (int r = 0; r < R; r++) {
     float t[NC][M], p[NC];
@@ -689,7 +691,17 @@ MSC_DEV void nich_block(const FeatDesc *__restrict__ feats, int f, const Src &sr
   }
   constexpr int NC = NCSEL;                             // (groups of the lane a part takes: MSC_NICH_NC; 4 where the registers allow)
   nich_block_part<M, R, 0, NC, EST>(feats, f, src, xv, acc);
-  if constexpr (NC <= 2) nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
+  if constexpr (NC <= 2) {
+    if constexpr (Src::kScalarX) {
+      // (the second part fetches the rows' values AGAIN -- scalar loads, the scalar cache has them --: read once for both
+      // parts they are 16 M scalar registers alive across the block, which the allocator spilled through v_writelane)
+      Src again = src;
+      asm volatile("" : "+s"(again.xwave));
+      nich_block_part<M, R, NC, NC, EST>(feats, f, again, xv, acc);
+    } else {
+      nich_block_part<M, R, NC, NC, EST>(feats, f, src, xv, acc);
+    }
+  }
   if constexpr (NC == 1) {
     nich_block_part<M, R, 2, NC, EST>(feats, f, src, xv, acc);
     nich_block_part<M, R, 3, NC, EST>(feats, f, src, xv, acc);

@@ -40,12 +40,23 @@ def kernels(co):
         def f(key, default="0"):
             m = re.search(r"\." + key + r":\s+(\S+)", blk)
             return m.group(1) if m else default
-        sym = f("symbol", "?").replace(".kd", "").strip("'\"")
+        sym = f("name", "?")
         try:
-            name = subprocess.check_output([LLVM + "/llvm-cxxfilt", sym], text=True).strip()
+            name = subprocess.check_output(["c++filt", sym], text=True).strip()
         except Exception:
             name = sym
-        name = re.sub(r"\(.*$", "", name).replace("void msc::", "").replace("void ", "")
+        # "void msc::k<...>(args)" -> "k<...>": cut the argument list at the parenthesis that closes the template list
+        name = name.replace("void ", "", 1).replace("msc::", "")
+        depth, cut = 0, len(name)
+        for i, ch in enumerate(name):
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        name = name[:cut]
         res.append((name, int(f("vgpr_count")), int(f("agpr_count")), int(f("sgpr_count")), int(f("vgpr_spill_count")),
                     int(f("sgpr_spill_count")), int(f("private_segment_fixed_size")), int(f("group_segment_fixed_size"))))
     return res
