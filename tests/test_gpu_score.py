@@ -656,3 +656,33 @@ def test_far_rows_take_the_plain_path_for_all_their_nich_features(gpu_ctx, K, la
         n = min(64, N - row0)
         assert torch.equal(st.score_value(view, row0=row0, nrows=n), plain[row0:row0 + n])
         assert torch.equal(st.score_value(view, row0=row0, nrows=n, z=zt[row0:row0 + n].contiguous(), crp_prior=True), loo[row0:row0 + n])
+
+
+def test_a_view_keeps_at_most_eight_index_matrices_and_the_ninth_plan_still_scores_right(gpu_ctx):
+    """The lookup index matrix and the x matrix of the role-split kernels are copies a view keeps per distinct feature list
+    (at most eight of each: abi.cpp kViewPackCap); a ninth list -- or a failed allocation -- plans the state onto the kernels
+    that need none.  Ten states over ten different column subsets of ONE view: every one scores its rows like the oracle,
+    and the bits of a state do not depend on whether it got its matrices (the tile kernels agree bit for bit): the ninth and
+    tenth against fresh views of their own, where they do get them.  (a copy is an optimisation, never a reason
+    for a call to fail.)"""
+    import common_amd
+    rng = np.random.default_rng(2025)
+    N, K = 40_000, 200
+    specs = [(orc.DD, 6 + i) for i in range(10)] + [(orc.GP, 0), (orc.BB, 0), (orc.NICH, 0), (orc.NICH, 0), (orc.NICH, 0)]
+    feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    rows = rng.choice(N, 200, replace=False)
+    for i in range(10):
+        cols = [i, 10, 11, 12, 13, 14]                       # a different dd column each time: a different first phase
+        st = common_amd.State(gpu_ctx, [specs[c] for c in cols], K)
+        load_state(st, [fs[c] for c in cols])
+        got = st.score_value(view, cols=cols)
+        want = oracle_scores([feats[c] for c in cols], [fs[c] for c in cols], rows=rows)
+        assert rel_err(got.cpu().numpy()[rows], want).max() <= TOL, i
+        if i >= 8:                                          # (the view's cap is spent: this plan took the kernels without a matrix)
+            own_view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of([feats[c] for c in cols]))
+            st2 = common_amd.State(gpu_ctx, [specs[c] for c in cols], K)
+            load_state(st2, [fs[c] for c in cols])
+            assert torch.equal(st2.score_value(own_view), got), i

@@ -2,7 +2,8 @@
 """Does a SPREAD store order make the C2 pass's rate independent of where the driver put the score matrix?
   Eight 1 GB matrices from torch.empty held side by side (the placement lottery: some take the
 dense write stream at ~5.5 TB/s, some at ~7), the same pass into each with the resident waves writing one dense window
-(MSC_NICH1_SPREAD=0) and S windows spread over the whole buffer (S = 4, 16, 64, 256, 1024); results are checked equal."""
+(MSC_NICH1_SPREAD=0) and S windows spread over the whole buffer (S = 4, 16, 64, 256, 1024); results are checked equal.
+(Round 5: the knobs this scan drives live in tools/microbench/r05_experiment_switches.patch, not in the product.)"""
 import json
 import os
 import sys
