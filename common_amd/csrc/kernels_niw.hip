@@ -342,6 +342,21 @@ MSC_DEV double xsum_rows_f64(double v) {
   return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
+// One step of a reduce-scatter over lane rows: the rows of a pair (ROWS = 16: rows 0|1 and 2|3; ROWS = 32: rows 0,1 | 2,3)
+// add their x's into the first of them and their y's into the second -- one swap per 32-bit half and one add.
+template <int ROWS>
+MSC_DEV double pair_rows_f64(double x, double y) {
+  u32x2 lo, hi;
+  if (ROWS == 16) {
+    lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  }
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 // log(u) for u >= 1 in double without the library routine's branches and tables: u = m 2^e with m in [1/sqrt2, sqrt2),
 // log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716, as an odd series to s^15 (next term 2 s^17 / 17 < 2e-14);
 // the quotient through v_rcp_f64 and two Newton steps.  ~30 double instructions.
@@ -373,6 +388,53 @@ MSC_DEV double log_ge1_f64(double u) {
 // the group), and 1e-7 of the term is 1e-5 of the score.  The series above costs ~2 % of the matrix work it follows; a
 // branch to the library log1p for the cancelling lanes only cost 25 % (C4 1.01 -> 1.27 ms: its registers).
 MSC_DEV double niw_score_from_q(double c0, double c1, double q) { return c0 - c1 * log_ge1_f64(1.0 + q); }
+
+// The end of a batch of 16 groups (or of the table): lane (c, kk) turns its 4 kept q's into the scores of groups
+// k0 .. k0 + 3 of its row of every block and stores them as one float4.
+template <int JB, bool LOO, bool ACCUM>
+MSC_DEV void niw64_finish_batch(const FeatDesc &fd, uint32_t k, int kk, int c, uint64_t rb, const double (&qkeep)[JB][4],
+                                const int (&gz)[JB], const bool (&msk)[JB], const bool (&live)[JB],
+                                double *__restrict__ qown, float *__restrict__ out, uint64_t ld, bool vec_ok) {
+  const uint32_t k0 = (k & ~15u) + 4 * kk;
+  float4 pend[JB];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t kg = k0 + i;
+    const bool valid = kg <= k;
+    const double *c64 = fd.niw_c64 + (size_t)(valid ? kg : 0) * 8;
+    const double c0 = c64[0], c1 = c64[1];
+#pragma unroll
+    for (int jb = 0; jb < JB; jb++) {
+      const double q = valid ? qkeep[jb][i] : 0.0;
+      double sc = niw_score_from_q(c0, c1, q);
+      if (LOO && valid && gz[jb] == (int)kg) {       // the own group: its value comes from k_niw_loo_patch
+        qown[rb + 16 * jb + c] = q;
+        sc = 0.0;
+      }
+      if (msk[jb]) sc = 0.0;
+      const float scf = (float)sc;
+      if (i == 0) pend[jb].x = scf;
+      else if (i == 1) pend[jb].y = scf;
+      else if (i == 2) pend[jb].z = scf;
+      else pend[jb].w = scf;
+    }
+  }
+#pragma unroll
+  for (int jb = 0; jb < JB; jb++) {
+    if (!live[jb] || k0 > k) continue;
+    float *p = out + (rb + 16 * jb + c) * ld + k0;
+    if (vec_ok && k0 + 3 <= k) {
+      float4 v = pend[jb];
+      if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *reinterpret_cast<float4 *>(p) = v;
+    } else {
+      const float vals[4] = {pend[jb].x, pend[jb].y, pend[jb].z, pend[jb].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (k0 + i <= k) p[i] = ACCUM ? p[i] + vals[i] : vals[i];
+    }
+  }
+}
 
 // NB = 16-blocks of the dimension (1 .. 8), JB = 16-row blocks a wave carries
 template <int NB, int JB, bool LOO, bool ACCUM>
@@ -483,48 +545,158 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
           else qkeep[jb][3] = q;
         }
       }
-      if ((k & 15) == 15 || k == K - 1) {
-        // finish the batch: lane (c, kk) turns its 4 kept q's into scores of groups k0 .. k0+3
-        const uint32_t k0 = (k & ~15u) + 4 * kk;
-        float4 pend[JB];
+      if ((k & 15) == 15 || k == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, k, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+    }
+  }
+}
+
+// 16 < dim <= 32, the same arithmetic with as few vector instructions as it takes.  On gfx950 the f64 matrix instruction
+// has no shadow: a vector instruction issued next to it (same wave or the SIMD's other wave) adds its own ~4 cycles
+// (f64), ~2.5 (f32), ~1.4 (v_mov), ~9 (v_permlane*_swap) to the 64 of the matrix instruction
+// (tools/microbench/mfma_f64_shadow.hip) -- the kernel's time is its matrix instructions PLUS its vector instructions, and
+// k_score_niw64 above spends ~216 of them a group.  Here:
+//   * the accumulators of a block start as the matrix instruction's C operand: acc = W (-x) + W mu, the features negated
+//     once per row block -- no copies of -(W mu) into four accumulator sets (64 v_mov a group), no subtraction;
+//   * the sum over the four lanes of a row is a reduce-scatter over FOUR groups: the groups of a batch of 16 are taken in
+//     the order s, 4 + s, 8 + s, 12 + s (s = 0 .. 3), and of such a set lane row kk ends with the total of group 4 kk + s --
+//     the one it finishes and stores -- after 3 swaps + 1.5 adds a group and row block where the all-to-all sum took
+//     4 swaps + 2 adds + the selects that filed it.  (The last K mod 16 groups go in their natural order with the
+//     all-to-all sum: a set of theirs may belong to one lane row.)
+//   * a unit's operands (block 0: one chunk + W mu, block 1: two chunks + W mu) are fetched into the registers its
+//     matrix instructions just read, a group ahead of their use; block 0 and block 1 accumulate in two sets and a unit's
+//     squares follow the next unit's matrix instructions.
+#ifndef MSC_NIW_LAG
+#define MSC_NIW_LAG 1
+#endif
+template <bool LOO, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                             uint32_t K, uint32_t kpad, uint64_t row0,
+                                                             uint64_t nrows, const int32_t *z,
+                                                             double *__restrict__ qown, float *__restrict__ out, uint64_t ld) {
+  constexpr int NB = 2, JB = 4, NS = 8, NCH = 3;
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim;
+  const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
+  const uint64_t nblocks = (nrows + 16 * JB - 1) / (16 * JB);
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const double *W = fd.niw_w64 + lane * 4, *B = fd.niw_mu64 + lane * 4;
+  const uint32_t Kfull = K & ~15u;
+  // the group taken at time t (clamped past the table: the last group again, into slots the batch finish skips)
+  auto group_at = [&](uint32_t t) -> size_t {
+    const uint32_t g = t < Kfull ? (t & ~15u) + 4 * (t & 3) + ((t >> 2) & 3) : t;
+    return g < K ? g : K - 1;
+  };
+  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
+    const uint64_t rb = blk * 16 * JB;
+    float xn[JB][NS];            // MINUS this lane's feature of every step, for its row of each block
+    int gz[JB];
+    bool live[JB], msk[JB];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const uint32_t kg = k0 + i;
-          const bool valid = kg <= k;
-          const double *c64 = fd.niw_c64 + (size_t)(valid ? kg : 0) * 8;
-          const double c0 = c64[0], c1 = c64[1];
+    for (int jb = 0; jb < JB; jb++) {
+      const uint64_t row = rb + 16 * jb + c;
+      live[jb] = row < nrows;
+      const float *xp = X + (row0 + (live[jb] ? row : 0)) * d;
 #pragma unroll
-          for (int jb = 0; jb < JB; jb++) {
-            const double q = valid ? qkeep[jb][i] : 0.0;
-            double sc = niw_score_from_q(c0, c1, q);
-            if (LOO && valid && gz[jb] == (int)kg) {       // the own group: its value comes from k_niw_loo_patch
-              qown[rb + 16 * jb + c] = q;
-              sc = 0.0;
-            }
-            if (msk[jb]) sc = 0.0;
-            const float scf = (float)sc;
-            if (i == 0) pend[jb].x = scf;
-            else if (i == 1) pend[jb].y = scf;
-            else if (i == 2) pend[jb].z = scf;
-            else pend[jb].w = scf;
-          }
-        }
+      for (int s = 0; s < NS; s++) {
+        const bool has = live[jb] && (uint32_t)(4 * s + kk) < d;
+        const float v = xp[has ? 4 * s + kk : 0];
+        xn[jb][s] = has ? -v : 0.0f;
+      }
+      gz[jb] = (LOO && live[jb]) ? z[row] : -1;
+      msk[jb] = false;
+      if (live[jb] && fd.mask != nullptr)
+        for (uint32_t e = 0; e < d; e++) msk[jb] |= fd.mask[(row0 + row) * d + e] != 0;
+    }
+    double qkeep[JB][4];
+    // operands: w0 = chunk (0, 0); w1, w2 = chunks (1, 0), (1, 1); m0, m1 = W mu of the two blocks, in accumulator layout
+    double2 w0[2], w1[2], w2[2], m0[2], m1[2];
+    auto load2 = [](double2 (&o)[2], const double *p) {
+      o[0] = *reinterpret_cast<const double2 *>(p);
+      o[1] = *reinterpret_cast<const double2 *>(p + 2);
+    };
+    // one chunk of a unit; the first starts every accumulator from W mu as the instruction's C operand
+    auto chunk = [&](f64x4 (&acc)[JB], const double2 (&w)[2], int s4, const double2 (*m)[2]) {
+      const double a[4] = {w[0].x, w[0].y, w[1].x, w[1].y};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
 #pragma unroll
         for (int jb = 0; jb < JB; jb++) {
-          if (!live[jb] || k0 > k) continue;
-          float *p = out + (rb + 16 * jb + c) * ld + k0;
-          if (vec_ok && k0 + 3 <= k) {
-            float4 v = pend[jb];
-            if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            *reinterpret_cast<float4 *>(p) = v;
-          } else {
-            const float vals[4] = {pend[jb].x, pend[jb].y, pend[jb].z, pend[jb].w};
+          const f64x4 from = (m != nullptr && e == 0) ? f64x4{(*m)[0].x, (*m)[0].y, (*m)[1].x, (*m)[1].y} : acc[jb];
+          acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], (double)xn[jb][4 * s4 + e], from, 0, 0, 0);
+        }
+    };
+    auto squares = [](double (&qp)[JB], const f64x4 (&acc)[JB], bool fresh) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-              if (k0 + i <= k) p[i] = ACCUM ? p[i] + vals[i] : vals[i];
+      for (int jb = 0; jb < JB; jb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) qp[jb] = (fresh && i == 0) ? acc[jb][i] * acc[jb][i] : fma(acc[jb][i], acc[jb][i], qp[jb]);
+    };
+    f64x4 accA[JB], accB[JB];
+    double qp[JB], held[JB], half[JB];
+    {
+      const size_t g0 = group_at(0), g1 = group_at(1);
+      load2(w0, W + g0 * (NCH * 256));
+      load2(m0, B + g0 * (NB * 256));
+      load2(w1, W + g0 * (NCH * 256) + 256);
+      load2(w2, W + g0 * (NCH * 256) + 512);
+      load2(m1, B + g0 * (NB * 256) + 256);
+      chunk(accA, w0, 0, &m0);                                           // unit (group_at(0), 0)
+      load2(w0, W + g1 * (NCH * 256));
+      load2(m0, B + g1 * (NB * 256));
+    }
+    for (uint32_t t4 = 0; t4 < K; t4 += 4) {        // four groups a trip
+      const bool tail = t4 >= Kfull;
+      const bool mine = (int)((t4 >> 2) & 3) == kk;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const size_t gn = group_at(t4 + i + 1), gn2 = group_at(t4 + i + 2);
+        // block 1 of this group issues, then block 0's squares; block 1's operands of the next group are fetched
+        chunk(accB, w1, 0, &m1);
+        chunk(accB, w2, 1, nullptr);
+        squares(qp, accA, true);
+        load2(w1, W + gn * (NCH * 256) + 256);
+        load2(w2, W + gn * (NCH * 256) + 512);
+        load2(m1, B + gn * (NB * 256) + 256);
+        __builtin_amdgcn_sched_barrier(0);
+        // block 0 of the next group issues, then block 1's squares
+        chunk(accA, w0, 0, &m0);
+        squares(qp, accB, false);
+        load2(w0, W + gn2 * (NCH * 256));
+        load2(m0, B + gn2 * (NB * 256));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!tail) {
+          // the reduce-scatter: times 0, 1 of a set pair up across lane rows (0,1) and (2,3), times 2, 3 likewise, the
+          // two halves across (0,2) and (1,3): row kk ends with the total of time kk's group = 4 kk + s of the batch
+          if (i == 0 || i == 2) {
+#pragma unroll
+            for (int jb = 0; jb < JB; jb++) held[jb] = qp[jb];
+          } else {
+#pragma unroll
+            for (int jb = 0; jb < JB; jb++) {
+              const double pr = pair_rows_f64<16>(held[jb], qp[jb]);
+              if (i == 1) half[jb] = pr;
+              else {
+                const double q = pair_rows_f64<32>(half[jb], pr);
+                qkeep[jb][0] = qkeep[jb][1];
+                qkeep[jb][1] = qkeep[jb][2];
+                qkeep[jb][2] = qkeep[jb][3];
+                qkeep[jb][3] = q;                     // set s lands in slot s after the four sets of a batch
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int jb = 0; jb < JB; jb++) {
+            const double q = xsum_rows_f64(qp[jb]);
+            qkeep[jb][i] = mine ? q : qkeep[jb][i];
           }
         }
       }
+      const uint32_t kl = t4 + 3 < K ? t4 + 3 : K - 1;
+      if ((kl & 15) == 15 || kl == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
     }
   }
 }
@@ -812,7 +984,9 @@ static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc 
   // peak), two beyond -- with four the wave's features, sums and epilogue take 290-512 registers and the kernel runs one
   // wave per SIMD: dim 64 4.94 ms; with two (and the operand stream pipelined, PIPE in the kernel) 3.06 ms, three
   // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).
-  if constexpr (NB > 2)
+  if constexpr (NB == 2 && MSC_NIW_LAG)
+    hipLaunchKernelGGL((k_score_niw64_lag<LOO, ACCUM>), (note_kernel(0, "k_score_niw64_lag<%s, %s>", tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  else if constexpr (NB > 2)
     hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 2, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   else
     hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 4, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
