@@ -391,7 +391,7 @@ MSC_DEV double niw_score_from_q(double c0, double c1, double q) { return c0 - c1
 
 // The end of a batch of 16 groups (or of the table): lane (c, kk) turns its 4 kept q's into the scores of groups
 // k0 .. k0 + 3 of its row of every block and stores them as one float4.
-template <int JB, bool LOO, bool ACCUM>
+template <int JB, bool LOO, bool ACCUM, bool FULL = false>
 MSC_DEV void niw64_finish_batch(const FeatDesc &fd, uint32_t k, int kk, int c, uint64_t rb, const double (&qkeep)[JB][4],
                                 const int (&gz)[JB], const bool (&msk)[JB], const bool (&live)[JB],
                                 double *__restrict__ qown, float *__restrict__ out, uint64_t ld, bool vec_ok) {
@@ -400,7 +400,7 @@ MSC_DEV void niw64_finish_batch(const FeatDesc &fd, uint32_t k, int kk, int c, u
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const uint32_t kg = k0 + i;
-    const bool valid = kg <= k;
+    const bool valid = FULL || kg <= k;       // FULL: a whole batch of 16, no lane has a slot to skip
     const double *c64 = fd.niw_c64 + (size_t)(valid ? kg : 0) * 8;
     const double c0 = c64[0], c1 = c64[1];
 #pragma unroll
@@ -421,9 +421,9 @@ MSC_DEV void niw64_finish_batch(const FeatDesc &fd, uint32_t k, int kk, int c, u
   }
 #pragma unroll
   for (int jb = 0; jb < JB; jb++) {
-    if (!live[jb] || k0 > k) continue;
+    if (!live[jb] || (!FULL && k0 > k)) continue;
     float *p = out + (rb + 16 * jb + c) * ld + k0;
-    if (vec_ok && k0 + 3 <= k) {
+    if (vec_ok && (FULL || k0 + 3 <= k)) {
       float4 v = pend[jb];
       if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *reinterpret_cast<float4 *>(p) = v;
@@ -545,12 +545,53 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
           else qkeep[jb][3] = q;
         }
       }
-      if ((k & 15) == 15 || k == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, k, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+      if ((k & 15) == 15 || k == K - 1) {
+        // finish the batch: lane (c, kk) turns its 4 kept q's into scores of groups k0 .. k0+3
+        const uint32_t k0 = (k & ~15u) + 4 * kk;
+        float4 pend[JB];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t kg = k0 + i;
+          const bool valid = kg <= k;
+          const double *c64 = fd.niw_c64 + (size_t)(valid ? kg : 0) * 8;
+          const double c0 = c64[0], c1 = c64[1];
+#pragma unroll
+          for (int jb = 0; jb < JB; jb++) {
+            const double q = valid ? qkeep[jb][i] : 0.0;
+            double sc = niw_score_from_q(c0, c1, q);
+            if (LOO && valid && gz[jb] == (int)kg) {       // the own group: its value comes from k_niw_loo_patch
+              qown[rb + 16 * jb + c] = q;
+              sc = 0.0;
+            }
+            if (msk[jb]) sc = 0.0;
+            const float scf = (float)sc;
+            if (i == 0) pend[jb].x = scf;
+            else if (i == 1) pend[jb].y = scf;
+            else if (i == 2) pend[jb].z = scf;
+            else pend[jb].w = scf;
+          }
+        }
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++) {
+          if (!live[jb] || k0 > k) continue;
+          float *p = out + (rb + 16 * jb + c) * ld + k0;
+          if (vec_ok && k0 + 3 <= k) {
+            float4 v = pend[jb];
+            if (ACCUM) { const float4 o = *reinterpret_cast<const float4 *>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4 *>(p) = v;
+          } else {
+            const float vals[4] = {pend[jb].x, pend[jb].y, pend[jb].z, pend[jb].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if (k0 + i <= k) p[i] = ACCUM ? p[i] + vals[i] : vals[i];
+          }
+        }
+      }
     }
   }
 }
 
-// 16 < dim <= 32, the same arithmetic with as few vector instructions as it takes.  On gfx950 the f64 matrix instruction
+// dim <= 32, the same arithmetic with as few vector instructions as it takes.  On gfx950 the f64 matrix instruction
 // has no shadow: a vector instruction issued next to it (same wave or the SIMD's other wave) adds its own ~4 cycles
 // (f64), ~2.5 (f32), ~1.4 (v_mov), ~9 (v_permlane*_swap) to the 64 of the matrix instruction
 // (tools/microbench/mfma_f64_shadow.hip) -- the kernel's time is its matrix instructions PLUS its vector instructions, and
@@ -562,18 +603,19 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 //     the one it finishes and stores -- after 3 swaps + 1.5 adds a group and row block where the all-to-all sum took
 //     4 swaps + 2 adds + the selects that filed it.  (The last K mod 16 groups go in their natural order with the
 //     all-to-all sum: a set of theirs may belong to one lane row.)
-//   * a unit's operands (block 0: one chunk + W mu, block 1: two chunks + W mu) are fetched into the registers its
-//     matrix instructions just read, a group ahead of their use; block 0 and block 1 accumulate in two sets and a unit's
-//     squares follow the next unit's matrix instructions.
+//   * a unit's operands (dim > 16: block 0 = one chunk + W mu, block 1 = two chunks + W mu; dim <= 16: the group) are
+//     fetched into the registers its matrix instructions just read, a group (dim <= 16: two) ahead of their use; units
+//     alternate between two accumulator sets and a unit's squares follow the next unit's matrix instructions.
 #ifndef MSC_NIW_LAG
 #define MSC_NIW_LAG 1
 #endif
-template <bool LOO, bool ACCUM>
+template <int NB, bool LOO, bool ACCUM>
 __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__restrict__ feats, uint32_t f,
                                                              uint32_t K, uint32_t kpad, uint64_t row0,
                                                              uint64_t nrows, const int32_t *z,
                                                              double *__restrict__ qown, float *__restrict__ out, uint64_t ld) {
-  constexpr int NB = 2, JB = 4, NS = 8, NCH = 3;
+  static_assert(NB == 1 || NB == 2, "dim <= 32");
+  constexpr int JB = 4, NS = 4 * NB, NCH = NB * (NB + 1) / 2;
   const FeatDesc fd = feats[f];
   const uint32_t d = fd.dim;
   const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
@@ -582,10 +624,14 @@ __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__re
   const uint64_t nwaves = (uint64_t)gridDim.x * 4;
   const float *X = reinterpret_cast<const float *>(fd.col);
   const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const double *W = fd.niw_w64 + lane * 4, *B = fd.niw_mu64 + lane * 4;
+  // the operand streams as buffers: a group's offset is a scalar, the lane's 32 bytes of a chunk a constant register
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t Wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(fd.niw_w64), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t Bb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(fd.niw_mu64), 0, 0x7fffffff, 0x00020000);
+  const uint32_t lane_off = lane * 32;
   const uint32_t Kfull = K & ~15u;
   // the group taken at time t (clamped past the table: the last group again, into slots the batch finish skips)
-  auto group_at = [&](uint32_t t) -> size_t {
+  auto group_at = [&](uint32_t t) -> uint32_t {
     const uint32_t g = t < Kfull ? (t & ~15u) + 4 * (t & 3) + ((t >> 2) & 3) : t;
     return g < K ? g : K - 1;
   };
@@ -611,11 +657,14 @@ __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__re
         for (uint32_t e = 0; e < d; e++) msk[jb] |= fd.mask[(row0 + row) * d + e] != 0;
     }
     double qkeep[JB][4];
-    // operands: w0 = chunk (0, 0); w1, w2 = chunks (1, 0), (1, 1); m0, m1 = W mu of the two blocks, in accumulator layout
+    // operands.  dim > 16: w0 = chunk (0, 0); w1, w2 = chunks (1, 0), (1, 1); m0, m1 = W mu of the two blocks, in
+    // accumulator layout.  dim <= 16: a group is one unit -- w0 / m0 serve the groups at even times, w1 / m1 at odd times.
     double2 w0[2], w1[2], w2[2], m0[2], m1[2];
-    auto load2 = [](double2 (&o)[2], const double *p) {
-      o[0] = *reinterpret_cast<const double2 *>(p);
-      o[1] = *reinterpret_cast<const double2 *>(p + 2);
+    auto load2 = [&](double2 (&o)[2], __amdgpu_buffer_rsrc_t buf, uint32_t byte) {
+      const u32x4v lo = __builtin_amdgcn_raw_buffer_load_b128(buf, lane_off, byte, 0);
+      const u32x4v hi = __builtin_amdgcn_raw_buffer_load_b128(buf, lane_off + 16, byte, 0);
+      o[0] = double2{__hiloint2double((int)lo[1], (int)lo[0]), __hiloint2double((int)lo[3], (int)lo[2])};
+      o[1] = double2{__hiloint2double((int)hi[1], (int)hi[0]), __hiloint2double((int)hi[3], (int)hi[2])};
     };
     // one chunk of a unit; the first starts every accumulator from W mu as the instruction's C operand
     auto chunk = [&](f64x4 (&acc)[JB], const double2 (&w)[2], int s4, const double2 (*m)[2]) {
@@ -636,37 +685,64 @@ __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__re
     };
     f64x4 accA[JB], accB[JB];
     double qp[JB], held[JB], half[JB];
-    {
-      const size_t g0 = group_at(0), g1 = group_at(1);
-      load2(w0, W + g0 * (NCH * 256));
-      load2(m0, B + g0 * (NB * 256));
-      load2(w1, W + g0 * (NCH * 256) + 256);
-      load2(w2, W + g0 * (NCH * 256) + 512);
-      load2(m1, B + g0 * (NB * 256) + 256);
+    if constexpr (NB == 2) {
+      const uint32_t g0 = group_at(0), g1 = group_at(1);
+      load2(w0, Wb, g0 * (NCH * 2048u));
+      load2(m0, Bb, g0 * (NB * 2048u));
+      load2(w1, Wb, g0 * (NCH * 2048u) + 2048);
+      load2(w2, Wb, g0 * (NCH * 2048u) + 4096);
+      load2(m1, Bb, g0 * (NB * 2048u) + 2048);
       chunk(accA, w0, 0, &m0);                                           // unit (group_at(0), 0)
-      load2(w0, W + g1 * (NCH * 256));
-      load2(m0, B + g1 * (NB * 256));
+      load2(w0, Wb, g1 * (NCH * 2048u));
+      load2(m0, Bb, g1 * (NB * 2048u));
+    } else {
+      const uint32_t g0 = group_at(0), g1 = group_at(1), g2 = group_at(2);
+      load2(w0, Wb, g0 * 2048u);
+      load2(m0, Bb, g0 * 2048u);
+      load2(w1, Wb, g1 * 2048u);
+      load2(m1, Bb, g1 * 2048u);
+      chunk(accA, w0, 0, &m0);                                           // the group at time 0
+      load2(w0, Wb, g2 * 2048u);
+      load2(m0, Bb, g2 * 2048u);
     }
     for (uint32_t t4 = 0; t4 < K; t4 += 4) {        // four groups a trip
       const bool tail = t4 >= Kfull;
       const bool mine = (int)((t4 >> 2) & 3) == kk;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const size_t gn = group_at(t4 + i + 1), gn2 = group_at(t4 + i + 2);
-        // block 1 of this group issues, then block 0's squares; block 1's operands of the next group are fetched
-        chunk(accB, w1, 0, &m1);
-        chunk(accB, w2, 1, nullptr);
-        squares(qp, accA, true);
-        load2(w1, W + gn * (NCH * 256) + 256);
-        load2(w2, W + gn * (NCH * 256) + 512);
-        load2(m1, B + gn * (NB * 256) + 256);
-        __builtin_amdgcn_sched_barrier(0);
-        // block 0 of the next group issues, then block 1's squares
-        chunk(accA, w0, 0, &m0);
-        squares(qp, accB, false);
-        load2(w0, W + gn2 * (NCH * 256));
-        load2(m0, B + gn2 * (NB * 256));
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NB == 2) {
+          const uint32_t gn = group_at(t4 + i + 1), gn2 = group_at(t4 + i + 2);
+          // block 1 of this group issues, then block 0's squares; block 1's operands of the next group are fetched
+          chunk(accB, w1, 0, &m1);
+          chunk(accB, w2, 1, nullptr);
+          squares(qp, accA, true);
+          load2(w1, Wb, gn * (NCH * 2048u) + 2048);
+          load2(w2, Wb, gn * (NCH * 2048u) + 4096);
+          load2(m1, Bb, gn * (NB * 2048u) + 2048);
+          __builtin_amdgcn_sched_barrier(0);
+          // block 0 of the next group issues, then block 1's squares
+          chunk(accA, w0, 0, &m0);
+          squares(qp, accB, false);
+          load2(w0, Wb, gn2 * (NCH * 2048u));
+          load2(m0, Bb, gn2 * (NB * 2048u));
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // the next group issues into the other accumulator set, then this group's squares; the operands just read are
+          // replaced by those of the group two times on
+          const uint32_t gn3 = group_at(t4 + i + 3);
+          if ((i & 1) == 0) {
+            chunk(accB, w1, 0, &m1);
+            squares(qp, accA, true);
+            load2(w1, Wb, gn3 * 2048u);
+            load2(m1, Bb, gn3 * 2048u);
+          } else {
+            chunk(accA, w0, 0, &m0);
+            squares(qp, accB, true);
+            load2(w0, Wb, gn3 * 2048u);
+            load2(m0, Bb, gn3 * 2048u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (!tail) {
           // the reduce-scatter: times 0, 1 of a set pair up across lane rows (0,1) and (2,3), times 2, 3 likewise, the
           // two halves across (0,2) and (1,3): row kk ends with the total of time kk's group = 4 kk + s of the batch
@@ -696,7 +772,8 @@ __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__re
         }
       }
       const uint32_t kl = t4 + 3 < K ? t4 + 3 : K - 1;
-      if ((kl & 15) == 15 || kl == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+      if ((kl & 15) == 15) niw64_finish_batch<JB, LOO, ACCUM, true>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+      else if (kl == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
     }
   }
 }
@@ -984,9 +1061,14 @@ static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc 
   // peak), two beyond -- with four the wave's features, sums and epilogue take 290-512 registers and the kernel runs one
   // wave per SIMD: dim 64 4.94 ms; with two (and the operand stream pipelined, PIPE in the kernel) 3.06 ms, three
   // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).
-  if constexpr (NB == 2 && MSC_NIW_LAG)
-    hipLaunchKernelGGL((k_score_niw64_lag<LOO, ACCUM>), (note_kernel(0, "k_score_niw64_lag<%s, %s>", tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else if constexpr (NB > 2)
+  // (k_score_niw64_lag reads the operand streams as buffers, 32-bit offsets: 2 or 6 KiB a group)
+  if constexpr (NB <= 2 && MSC_NIW_LAG) {
+    if ((uint64_t)K * 6144u < 0x7fffffffull) {
+      hipLaunchKernelGGL((k_score_niw64_lag<NB, LOO, ACCUM>), (note_kernel(0, "k_score_niw64_lag<%d, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+      return;
+    }
+  }
+  if constexpr (NB > 2)
     hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 2, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
   else
     hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 4, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
