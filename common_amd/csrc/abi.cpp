@@ -726,7 +726,7 @@ static void default_hp(int family, uint32_t dim, std::vector<float> &hp) {
 // kGrpRows rows per group, never across the two phases.
 // what the choice of kernels depends on, for one plan
 struct PlanFacts {
-  bool roles_ok = false, nich_only = false, lookups_only = false, tail_ok = false, tail_masked_nich = false;
+  bool roles_ok = false, nich_only = false, lookups_only = false, tail_ok = false, tail_masked_nich = false, tail_dm = false;
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;
 };
 
@@ -808,15 +808,23 @@ static PlanFacts plan_layout(std::vector<FeatDesc> &t, uint32_t split, const std
   for (uint32_t i = 0; i < n; i++) pf.lookups_only &= t[i].kind != MSC_KIND_GENERIC;
   // the lane <-> row kernel for a partly filled last tile (k_score_tail_rows): lookup features only in the first phase
   // (what it implements), whatever the second holds of plain nich features
-  pf.tail_ok = !has_dm && std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
-  // (a masked nich column among them is evaluated like the second phase's features, under the row's mask)
-  for (uint32_t i = 0; i < split; i++)
-    pf.tail_ok &= t[i].kind != MSC_KIND_GENERIC || (t[i].family == MSC_NICH && t[i].mask != nullptr && t[i].col != nullptr);
+  pf.tail_ok = std::getenv("MSC_NO_NARROW_TAIL") == nullptr;
+  // (a masked nich column among them is evaluated like the second phase's features, under the row's mask; a dm feature
+  // whose dim + 1 tables are staged whole -- small counts: no row of the bound column is beyond them -- is dim + 1 lookups
+  // of (hi, lo) pairs, round 5; the kernel has one instantiation for either, none for both)
+  for (uint32_t i = 0; i < split; i++) {
+    const bool masked_nich = t[i].family == MSC_NICH && t[i].mask != nullptr && t[i].col != nullptr;
+    const bool staged_dm = t[i].family == MSC_DM && t[i].col != nullptr && t[i].dm_meta != nullptr && t[i].grp_rows != 0;
+    pf.tail_ok &= t[i].kind != MSC_KIND_GENERIC || masked_nich || staged_dm;
+    pf.tail_masked_nich |= masked_nich;
+    pf.tail_dm |= staged_dm;
+  }
+  if (pf.tail_dm && pf.tail_masked_nich) pf.tail_ok = false;
   for (uint32_t i = split; i < n; i++) pf.tail_ok &= t[i].family == MSC_NICH && t[i].mask == nullptr && t[i].grp_rows == 6;
+  if (!pf.tail_ok) pf.tail_masked_nich = pf.tail_dm = false;
   if (pf.tail_ok)
     for (uint32_t i = 0; i < split; i++) {
-      const uint32_t rows = t[i].kind == MSC_KIND_GENERIC ? 0u : t[i].run_clamp + 1;
-      pf.tail_masked_nich |= t[i].kind == MSC_KIND_GENERIC;
+      const uint32_t rows = t[i].family == MSC_DM ? t[i].dm_rows : t[i].kind == MSC_KIND_GENERIC ? 0u : t[i].run_clamp + 1;
       pf.tail_max_rows = std::max(pf.tail_max_rows, rows);
       pf.tail_pack_rows += rows;
     }
@@ -1160,6 +1168,7 @@ static int plan_groups(msc_state *st) {
     double lookups = 0, rows = 0, nich = (double)(st->fuse_nfeat - st->fuse_split);
     for (uint32_t i = 0; i < st->fuse_split; i++) {
       if (tf[i].family == MSC_NICH) nich += 1;
+      else if (tf[i].family == MSC_DM) lookups += 2.0 * (tf[i].dim + 1), rows += tf[i].grp_rows;   // (dim + 1 stages of (hi, lo) pairs)
       else lookups += 1, rows += tf[i].grp_rows;
     }
     PlanCost pc;
@@ -1172,6 +1181,7 @@ static int plan_groups(msc_state *st) {
   }
   st->tile_narrow_tail_ok = facts.tail_ok;
   st->tail_masked_nich = facts.tail_masked_nich;
+  st->tail_dm = facts.tail_dm;
   st->tail_max_rows = facts.tail_max_rows;
   st->tail_pack_rows = facts.tail_pack_rows;
   return MSC_OK;
@@ -1810,6 +1820,7 @@ static int tail_plan(msc_state *st, TailPlan &tp) {
   }
   tp.ok = true;
   tp.masked_nich = st->tail_masked_nich;
+  tp.dm = st->tail_dm;
   tp.max_rows = st->tail_max_rows;
   tp.pack_rows = st->tail_pack_rows;
   tp.pack = st->tail_pack;
@@ -1941,7 +1952,7 @@ static int run_score(msc_state *st, uint64_t row0, uint64_t nrows, const int32_t
     const FeatDesc *descs = path == MSC_PATH_NICH1 ? st->desc_dev : st->desc_fuse_dev;
     TailPlan tail;
     tail.cost = st->plan_cost;
-    if (path != MSC_PATH_NICH1 && path != MSC_PATH_TILE_DM && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
+    if (path != MSC_PATH_NICH1 && st->K - (st->kpad - kGroupTile) <= kTailMaxGroups)
       MSC_TRY(tail_plan(st, tail));
     if (path != MSC_PATH_NICH1) MSC_TRY(refresh_fused_tables(st));
     auto launch = [&](int shape) {
@@ -2316,7 +2327,7 @@ static int sweep_assign_impl(msc_state *st, const msc_dataview *view, const uint
     else if (nl) rc = launch_narrow(s, cus, nl, narrow_rows, true, st->desc_dev, (int)st->nfeat, st->K, st->kpad, row0, nrows, z_dev,
                                     st->own, st->logpc, nullptr, 0, row_id0, z_dev, st->rng_dev, zero);
     else if (refresh_fused_tables(st)) return MSC_EHIP;    // (everything below walks the fused plan)
-    else if (!has_dm && st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr &&
+    else if (st->tile_narrow_tail_ok && st->K <= kTailMaxGroups && std::getenv("MSC_NO_SWEEP_ROWS") == nullptr &&
              sweep_rows_pays(st, st->K)) {
       // at most 128 groups on a plan of lookup + plain nich features: the lane <-> row kernel, whose cost follows the
       // groups (a tile pass costs what 256 cost).  Up to 64: scores and draw in one launch, a lane draws its own row.

@@ -1228,17 +1228,18 @@ constexpr uint32_t kTailStride = 65;                   // floats per staged tabl
 
 // table rows a first-phase feature brings to the slot: a lookup feature's selectable rows; none for a masked nich column
 // (the one generic kind the plan admits there: evaluated like the second phase's, under the row's mask)
-__host__ __device__ inline uint32_t tail_table_rows(uint32_t kind, uint32_t run_clamp) {
-  return kind == MSC_KIND_GENERIC ? 0u : run_clamp + 1;
+// ... and all dim + 1 (hi, lo) tables of a dm feature (the plan admits it only when they are staged whole: small counts)
+__host__ __device__ inline uint32_t tail_table_rows(uint32_t family, uint32_t kind, uint32_t run_clamp, uint32_t dm_rows) {
+  return family == MSC_DM ? dm_rows : kind == MSC_KIND_GENERIC ? 0u : run_clamp + 1;
 }
 
 __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ feats, uint32_t kpad, uint32_t k0,
                                                     float *__restrict__ pack) {
   const int f = blockIdx.x;
   uint32_t off = 0;
-  for (int i = 0; i < f; i++) off += tail_table_rows(feats[i].kind, feats[i].run_clamp);
+  for (int i = 0; i < f; i++) off += tail_table_rows(feats[i].family, feats[i].kind, feats[i].run_clamp, feats[i].dm_rows);
   const FeatDesc &fd = feats[f];
-  const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u, rows = tail_table_rows(fd.kind, fd.run_clamp);
+  const uint32_t first_row = is_count_family(fd.family) ? (uint32_t)GP_T0 : 0u, rows = tail_table_rows(fd.family, fd.kind, fd.run_clamp, fd.dm_rows);
   for (uint32_t e = threadIdx.x; e < rows * 64u; e += 256u) {
     const uint32_t r = e >> 6, g = e & 63u;
     pack[(size_t)(off + r) * 64 + g] = fd.tab[(size_t)(first_row + r) * kpad + k0 + g];      // (k0 + 63 < kpad)
@@ -1250,8 +1251,12 @@ __global__ __launch_bounds__(256) void k_tail_pack(const FeatDesc *__restrict__ 
 // order, no cross-lane step) and writes it to z; (seed, sweep) from `rng`, the uniform of global row row_id0 + r.
 // MNICH: the first phase may hold masked nich columns (an instantiation of its own: the branch costs the others registers)
 // EST: the sweeps' nich form (family_math.hpp nich_accum<true>)
-template <int TGP, bool SPLIT, bool DRAW = false, bool MNICH = false, bool EST = false>
-__global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_tail_rows(
+// DMF: the first phase may hold dm features (an instantiation of its own, like MNICH's): dim + 1 count lookups a row, each a
+// (hi, lo) pair of staged table rows, summed apart sixteen groups at a time and added to the score once (score_block.hpp
+// score_dm_feature_staged: the same sums in the same order); a masked row, or one whose total is beyond the tables, reads
+// entry 0 of every table, which is exactly zero
+template <int TGP, bool SPLIT, bool DRAW = false, bool MNICH = false, bool EST = false, bool DMF = false>
+__global__ __launch_bounds__(kTailRowsWaves * 64, (MNICH || DMF) ? 2 : 4) void k_score_tail_rows(
     const FeatDesc *__restrict__ feats_g, int nfeat, int nsplit, uint32_t K, uint32_t kpad, uint32_t k0, uint64_t row0,
     uint64_t nrows, int32_t *z, const float *__restrict__ own, const float *__restrict__ crp,
     float *__restrict__ out, uint64_t ld, const float *__restrict__ pack, uint32_t cap_rows, uint32_t kend,
@@ -1339,7 +1344,7 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
           off = 0;
           uint32_t rows = 0;
           while (stage_end < nsplit) {
-            const uint32_t rw = tail_table_rows(feats[stage_end].kind, feats[stage_end].run_clamp);
+            const uint32_t rw = tail_table_rows(feats[stage_end].family, feats[stage_end].kind, feats[stage_end].run_clamp, feats[stage_end].dm_rows);
             if (rows + rw > cap_rows && rows > 0) break;       // (the launcher sizes the slot for the largest table)
             rows += rw;
             stage_end++;
@@ -1352,7 +1357,36 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
           }
           __syncthreads();
         }
-        if (MNICH && feats[f].kind == MSC_KIND_GENERIC) {
+        if (DMF && feats[f].family == MSC_DM) {
+          const uint32_t dim = feats[f].dim;
+          const uint32_t *xr = reinterpret_cast<const uint32_t *>(feats[f].col) + rr * dim;
+          const uint32_t *meta = feats[f].dm_meta;
+          const uint32_t tot = has_row ? feats[f].dm_tot[rr] : 0u;
+          bool dead = !has_row || tot >= kGpMaxTable;
+          if (feats[f].mask != nullptr)
+            for (uint32_t e = 0; e < dim; e++) dead |= feats[f].mask[rr * dim + e] != 0;
+#pragma unroll
+          for (int gb = 0; gb < TGP; gb += 16) {
+            float hi[16], lo[16];
+#pragma unroll
+            for (int g = 0; g < 16; g++) hi[g] = lo[g] = 0.f;
+#pragma unroll 1
+            for (uint32_t st = 0; st <= dim; st++) {
+              const uint32_t first_row = meta[2 * st], vcap = meta[2 * st + 1];
+              uint32_t v = st < dim ? xr[st] : tot;
+              v = (dead || v >= vcap) ? 0u : v;
+              const float *b = tl + (size_t)(off + first_row + 2u * v) * kTailStride + gb;
+#pragma unroll
+              for (int g = 0; g < 16; g++) {
+                hi[g] += b[g];
+                lo[g] += b[kTailStride + g];
+              }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[gb + g] += hi[g] + lo[g];
+          }
+          off += feats[f].dm_rows;
+        } else if (MNICH && feats[f].kind == MSC_KIND_GENERIC) {
           // a masked nich column, in the caller's place among the lookups: acc += nich_eval(...) unless the row's value is
           // masked (add_feature's generic branch, the same bits); constants as scalar operands, four groups at a time
           const bool masked = feats[f].mask[rr] != 0;
@@ -1532,23 +1566,25 @@ __global__ __launch_bounds__(kTailRowsWaves * 64, MNICH ? 2 : 4) void k_score_ta
   }
 }
 
-template <int TGP, bool SPLIT, bool DRAW, bool MNICH, bool EST>
+template <int TGP, bool SPLIT, bool DRAW, bool MNICH, bool EST, bool DMF = false>
 static void launch_tail_rows_m(hipStream_t stream, unsigned grid, size_t lds, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
                                const uint64_t *rng, uint64_t row_id0, ZeroSpans zero) {
   static unsigned long long attr_devices = 0;
   if (first_use_on_device(attr_devices))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST>), dim3(grid), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST, DMF>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((k_score_tail_rows<TGP, SPLIT, DRAW, MNICH, EST, DMF>), (note_kernel(DRAW ? 1 : 0, "k_score_tail_rows<%d, %s, %s, %s, %s, %s>", TGP, tf(SPLIT), tf(DRAW), tf(MNICH), tf(EST), tf(DMF)), dim3(grid)), dim3(kTailRowsWaves * 64), lds, stream, feats_dev, nfeat, nsplit, K, kpad, k0,
                      row0, nrows, const_cast<int32_t *>(z), own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
 }
 template <int TGP, bool SPLIT, bool DRAW = false, bool EST = false>
-static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, bool mnich, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
+static void launch_tail_rows_t(hipStream_t stream, unsigned grid, size_t lds, int mnich, const FeatDesc *feats_dev, int nfeat, int nsplit, uint32_t K,
                                uint32_t kpad, uint32_t k0, uint64_t row0, uint64_t nrows, const int32_t *z, const float *own,
                                const float *crp, float *out, uint64_t ld, const float *pack, uint32_t cap_rows, uint32_t kend,
                                const uint64_t *rng = nullptr, uint64_t row_id0 = 0, ZeroSpans zero = ZeroSpans()) {
-  if (mnich) launch_tail_rows_m<TGP, SPLIT, DRAW, true, EST>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  // (mnich: 0 plain, 1 masked nich columns in the first phase, 2 dm features there -- TailPlan::masked_nich / dm)
+  if (mnich == 2) launch_tail_rows_m<TGP, SPLIT, DRAW, false, EST, true>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
+  else if (mnich) launch_tail_rows_m<TGP, SPLIT, DRAW, true, EST>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
   else launch_tail_rows_m<TGP, SPLIT, DRAW, false, EST>(stream, grid, lds, feats_dev, nfeat, nsplit, K, kpad, k0, row0, nrows, z, own, crp, out, ld, pack, cap_rows, kend, rng, row_id0, zero);
 }
 
@@ -1580,10 +1616,10 @@ int launch_sweep_rows(hipStream_t stream, int num_cus, const TailPlan &tp, const
   if (K > 64 || crp == nullptr || !tail_rows_geometry(tp, num_cus, nfeat, nsplit, nrows, cap_rows, lds, grid)) return 1;
   if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, 0u, tp.pack);
   const uint32_t tgp = (K + 15u) / 16u * 16u;
-#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
+#define MSC_SWEEP_ROWS(T) launch_tail_rows_t<T, false, true, true>(stream, grid, lds, tp.dm ? 2 : tp.masked_nich ? 1 : 0, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero)
   if (tgp == 16) MSC_SWEEP_ROWS(16);
   else if (tgp == 32)        // (two sums per group here: the one-sum instantiation of 32 spills -- the register allocator's quirk)
-    launch_tail_rows_t<32, true, true, true>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero);
+    launch_tail_rows_t<32, true, true, true>(stream, grid, lds, tp.dm ? 2 : tp.masked_nich ? 1 : 0, feats_dev, nfeat, nsplit, K, kpad, 0u, row0, nrows, z, own, crp, nullptr, 0, tp.pack, cap_rows, K, rng, row_id0, zero);
   else if (tgp == 48) MSC_SWEEP_ROWS(48);
   else MSC_SWEEP_ROWS(64);
 #undef MSC_SWEEP_ROWS
@@ -1610,7 +1646,7 @@ int launch_score_tail(hipStream_t stream, int num_cus, const TailPlan &tp, const
     const uint32_t kend = std::min<uint32_t>(K, kb + blk), tgp = (kend - kb + 15u) / 16u * 16u;
     // (the packed tables are this launch's: the stream orders the next block's k_tail_pack behind it)
     if (nsplit > 0) hipLaunchKernelGGL(k_tail_pack, dim3((unsigned)nsplit), dim3(256), 0, stream, feats_dev, kpad, kb, tp.pack);
-#define MSC_TAIL_ROWS(T, S, E) launch_tail_rows_t<T, S, false, E>(stream, grid, lds, tp.masked_nich, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
+#define MSC_TAIL_ROWS(T, S, E) launch_tail_rows_t<T, S, false, E>(stream, grid, lds, tp.dm ? 2 : tp.masked_nich ? 1 : 0, feats_dev, nfeat, nsplit, K, kpad, kb, row0, nrows, z, own, crp, out, ld, tp.pack, cap_rows, kend)
     if (tp.exact) {
       if (tgp == 16) MSC_TAIL_ROWS(16, true, false);
       else if (tgp == 32) MSC_TAIL_ROWS(32, true, false);

@@ -97,6 +97,7 @@ struct TailPlan {
   bool exact = true;          // the tile kernels' bits (two sums per group: score passes, where the row count picks the kernel);
                               // false: one sum per group, faster (sweeps: the choice of kernel follows the bound view's row count, not the call's)
   bool masked_nich = false;   // the first phase holds masked nich columns (the kernel's instantiation that evaluates them)
+  bool dm = false;            // ... or dm features with their tables staged whole (the instantiation that looks them up)
   uint32_t max_rows = 0;      // the largest lookup table (rows a value may select)
   uint32_t pack_rows = 0;     // all lookup tables together
   float *pack = nullptr;      // scratch of pack_rows x 64 floats (the tail groups' tables, k_tail_pack), owned by the state

@@ -466,6 +466,7 @@ struct msc_state {
   bool tile_narrow_tail_ok = false;   // plan_groups: a partly filled last tile may take k_score_tail_rows
   uint32_t tail_max_rows = 0, tail_pack_rows = 0;   // the lookup tables of the tile plan's first phase: the largest, all together
   bool tail_masked_nich = false;      // ... and masked nich columns among them (evaluated in place, under the row's mask)
+  bool tail_dm = false;               // ... or dm features with their tables staged whole
   float *tail_pack = nullptr;         // k_tail_pack's output: tail_pack_rows x 64 floats (grown on demand)
   size_t tail_pack_floats = 0;
   uint32_t loo_staged = 0;        // plan_groups: features whose leave-one-out block k_loo_own_lds stages in LDS

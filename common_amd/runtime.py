@@ -247,7 +247,10 @@ class DataView(object):
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx.lib.msc_dataview_destroy(self._h)
+            # (a view that outlives its context -- kept alive by a traceback, say -- must not hand the library a handle whose
+            # context is gone: the context's destruction already released the device)
+            if getattr(self.ctx, "_h", None):
+                self.ctx.lib.msc_dataview_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -483,7 +486,8 @@ class State(object):
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx.lib.msc_state_destroy(self._h)
+            if getattr(self.ctx, "_h", None):           # (see DataView.close)
+                self.ctx.lib.msc_state_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -176,3 +176,93 @@ def test_masked_dm_rows_contribute_nothing(gpu_ctx):
     dm_part[hide] = 0.0
     want = dm_part + fs_all[0][0].score_matrix(fs_all[0][1], feats[1]["values"])
     assert rel_err(got, want).max() <= TOL
+
+
+def _small_counts(feat):
+    """the same feature with counts small enough that all dim + 1 tables fit the LDS slot (row totals of at most ~10)"""
+    return dict(feat, values=(feat["values"] // 5).astype(np.int32))
+
+
+DM_ROWS_PLANS = {
+    "four_dm4": [(orc.DM, 4)] * 4,
+    "mixed": [(orc.BB, 0), (orc.DM, 4), (orc.NICH, 0), (orc.DM, 3), (orc.GP, 0), (orc.NICH, 0)],
+}
+
+
+@pytest.mark.parametrize("plan", sorted(DM_ROWS_PLANS))
+@pytest.mark.parametrize("K", [5, 32, 50, 64])
+def test_dm_states_of_few_groups_score_on_the_lane_row_kernel(gpu_ctx, plan, K, monkeypatch):
+    """Round 5: a state of at most 64 groups whose dm features have small counts (tables staged whole) takes the lane <-> row
+    kernel (k_score_tail_rows<..., DMF = true>): dim + 1 (hi, lo) lookups per row and feature, the cost following the groups.
+    Plain, leave-one-out and leave-one-out + prior against the oracle (the per-feature tolerances add: a sum of D features is
+    gated at 1e-6 sum_f max(1, |score_f|), tests/test_gpu_score.py _gate_on_sum); src/models/dm.cpp:39-76."""
+    import common_amd
+    from tests.test_gpu_score import _gate_on_sum
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")       # (the library's own mark grows with the groups: ~1000 rows a group)
+    N = 20_000
+    rng = np.random.default_rng(K * 7 + len(plan))
+    feats = [make_feature(f, N, K, rng, d) for f, d in DM_ROWS_PLANS[plan]]
+    feats = [_small_counts(f) if f["family"] == orc.DM else f for f in feats]
+    z = rng.integers(0, K, N).astype(np.int32)
+    fs = state_from_assignment(feats, K, z)
+    view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
+    st = common_amd.State(gpu_ctx, [(f["family"], f["dim"]) for f in feats], K)
+    load_state(st, fs)
+    st.set_group_counts(np.bincount(z, minlength=K).astype(np.uint32))
+    got = st.score_value(view).cpu().numpy()
+    assert gpu_ctx.last_kernel("score").startswith("k_score_tail_rows<") and gpu_ctx.last_kernel("score").endswith("true>")
+    rows = np.arange(N)
+    audit("dm_lane_row.plain", _gate_on_sum(got, feats, fs, rows), TOL)
+    zt = torch.from_numpy(z).to(gpu_ctx.torch_device)
+    loo = st.score_value(view, z=zt).cpu().numpy()
+    audit("dm_lane_row.loo", _gate_on_sum(loo, feats, fs, rows, z=z), TOL)
+    st.set_alpha(0.7)
+    both = st.score_value(view, z=zt, crp_prior=True).cpu().numpy()
+    audit("dm_lane_row.loo_prior", _gate_on_sum(both, feats, fs, rows, z=z, prior=crp_prior_matrix(np.bincount(z, minlength=K), 0.7, z)), TOL)
+    # the same rows in three shards (few enough rows each that the library picks the tile kernel for them): the same bits,
+    # as the choice between the two kernels by the call's row count requires
+    parts = torch.empty((N, K), dtype=torch.float32, device=gpu_ctx.torch_device)
+    for lo, n in (common_amd.dist.shard_rows(N, 3, r) for r in range(3)):
+        parts[lo:lo + n] = st.score_value(view, z=zt[lo:lo + n].contiguous(), crp_prior=True, row0=lo, nrows=n)
+    assert gpu_ctx.last_kernel("score").startswith("k_score_tile<")
+    assert np.array_equal(parts.cpu().numpy(), both)
+
+
+def test_masked_dm_rows_contribute_nothing_on_the_lane_row_kernel(gpu_ctx, monkeypatch):
+    """(a masked view hands every column a mask: the bool column beside the dm feature becomes a lookup with a zero row; a
+    masked nich column AND a dm feature in one plan stay with the tile kernel -- the lane <-> row kernel has an instantiation
+    for either, none for both)"""
+    import common_amd
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "16384")
+    rng = np.random.default_rng(14)
+    N, K, C = 20_000, 21, 4
+    feats = [_small_counts(make_feature(orc.DM, N, K, rng, C)), make_feature(orc.BB, N, K, rng)]
+    z = rng.integers(0, K, N).astype(np.int32)
+    rec = recarray_of(feats)
+    mask = np.zeros(N, dtype=[("f0", np.bool_, (C,)), ("f1", np.bool_)])
+    hide = rng.random(N) < 0.2
+    mask["f0"][hide, rng.integers(0, C, hide.sum())] = True        # one masked element hides the whole vector
+    view = common_amd.DataView.from_recarray(gpu_ctx, np.ma.masked_array(rec, mask=mask))
+    keep = ~hide
+    fs_keep = state_from_assignment([dict(feats[0], values=feats[0]["values"][keep])], K, z[keep])
+    fs_all = state_from_assignment(feats[1:], K, z)
+    st = common_amd.State(gpu_ctx, [(orc.DM, C), (orc.BB, 0)], K)
+    load_state(st, [fs_keep[0]] + fs_all)
+    got = st.score_value(view).cpu().numpy()
+    assert gpu_ctx.last_kernel("score").startswith("k_score_tail_rows<")
+    dm_part = fs_keep[0][0].score_matrix(fs_keep[0][1], feats[0]["values"])
+    dm_part[hide] = 0.0
+    want = dm_part + sum(f[0].score_matrix(f[1], feats[1 + i]["values"]) for i, f in enumerate(fs_all))
+    assert rel_err(got, want).max() <= TOL
+
+
+@pytest.mark.parametrize("K,empty", [(7, 1), (32, 0), (64, 5)])
+def test_sweep_of_a_dm_state_on_the_lane_row_kernel_matches_the_oracle(gpu_ctx, K, empty, monkeypatch):
+    """... and the fused sweep of such a state (scores + draw in one launch, a lane draws its own row) against the oracle's
+    sweep, every disagreeing draw on a CDF step"""
+    from tests.test_gpu_sweep import _check_agreement, _run
+    monkeypatch.setenv("MSC_TAIL_MIN_ROWS", "1")
+    specs = [(orc.DM, 4), (orc.BB, 0), (orc.DM, 3), (orc.NICH, 0)]
+    got, want, scores, _ = _run(gpu_ctx, specs, 3000, K, seed=60 + K, sweep_idx=2, alpha=0.8, empty=empty, small_dm=True)
+    assert gpu_ctx.last_kernel("sweep").startswith("k_score_tail_rows<")
+    _check_agreement(got, want, scores, 60 + K, 2, 0.995)

@@ -11,10 +11,12 @@ from tests.gpu_helpers import load_state, make_feature, recarray_of, state_from_
 pytestmark = pytest.mark.gpu
 
 
-def _run(gpu_ctx, specs, N, K, seed, sweep_idx, alpha=1.3, empty=2, row_id0=0):
+def _run(gpu_ctx, specs, N, K, seed, sweep_idx, alpha=1.3, empty=2, row_id0=0, small_dm=False):
     import common_amd
     rng = np.random.default_rng(seed)
     feats = [make_feature(f, N, K, rng, d) for f, d in specs]
+    if small_dm:      # dm counts small enough that the feature's tables are staged whole (row totals of at most ~10)
+        feats = [dict(f, values=(f["values"] // 5).astype(np.int32)) if f["family"] == orc.DM else f for f in feats]
     z = rng.integers(0, max(1, K - empty), N).astype(np.int32)
     fs = state_from_assignment(feats, K, z)
     view = common_amd.DataView.from_recarray(gpu_ctx, recarray_of(feats))
