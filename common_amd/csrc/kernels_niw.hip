@@ -20,6 +20,9 @@
 //                   In float the score error is c1 * eps(q) with c1 >= dim/2, which breaks the 1e-6 gate for
 //                   small groups at dim 32; the f32 kernel (dim <= 32) stays available behind MSC_SCORE_NIW_F32
 //                   at twice the matrix rate.
+//   k_score_niw64_lag   dim <= 32 since round 5: the same contraction with as few vector instructions as it takes --
+//                   on gfx950 a vector instruction beside the f64 matrix instruction costs its full issue time
+//                   (tools/microbench/mfma_f64_shadow.hip); k_score_niw64 keeps dims 33 .. 128
 //   k_niw_bucket_*, k_niw_group_sums   sum_x, sum_xxT by group: rows bucketed by group, summed in registers
 //
 // Leave-one-out needs no second factorisation: with u = x - mu_n, t = u^T Psi_n^-1 u,
@@ -606,9 +609,6 @@ __global__ __launch_bounds__(256) void k_score_niw64(const FeatDesc *__restrict_
 //   * a unit's operands (dim > 16: block 0 = one chunk + W mu, block 1 = two chunks + W mu; dim <= 16: the group) are
 //     fetched into the registers its matrix instructions just read, a group (dim <= 16: two) ahead of their use; units
 //     alternate between two accumulator sets and a unit's squares follow the next unit's matrix instructions.
-#ifndef MSC_NIW_LAG
-#define MSC_NIW_LAG 1
-#endif
 template <int NB, bool LOO, bool ACCUM>
 __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__restrict__ feats, uint32_t f,
                                                              uint32_t K, uint32_t kpad, uint64_t row0,
@@ -1062,7 +1062,7 @@ static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc 
   // wave per SIMD: dim 64 4.94 ms; with two (and the operand stream pipelined, PIPE in the kernel) 3.06 ms, three
   // waves per SIMD; dim 128 17.2 -> 11.4 ms (profiles/r03_niw_dims.txt).
   // (k_score_niw64_lag reads the operand streams as buffers, 32-bit offsets: 2 or 6 KiB a group)
-  if constexpr (NB <= 2 && MSC_NIW_LAG) {
+  if constexpr (NB <= 2) {
     if ((uint64_t)K * 6144u < 0x7fffffffull) {
       hipLaunchKernelGGL((k_score_niw64_lag<NB, LOO, ACCUM>), (note_kernel(0, "k_score_niw64_lag<%d, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
       return;

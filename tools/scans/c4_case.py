@@ -22,6 +22,8 @@ for d in [int(a) for a in sys.argv[1:]] or [32]:
     r = {"dim": d}
     r["score_f64_ms"] = timed(lambda: st.score_value(view, out=out), 20, warmup=5)[1]
     r["kernel"] = ctx.last_kernel("score")
+    r["score_f64_loo_ms"] = timed(lambda: st.score_value(view, z=z, out=out), 20, warmup=5)[1]     # (+ k_niw_loo_patch)
+    r["kernel_loo"] = ctx.last_kernel("score")
     if d <= 32:
         r["score_f32_ms"] = timed(lambda: st.score_value(view, out=out, niw_f32=True), 20, warmup=5)[1]
     print(json.dumps(r), flush=True)
