@@ -22,7 +22,8 @@
 //                   at twice the matrix rate.
 //   k_score_niw64_lag   dim <= 32 since round 5: the same contraction with as few vector instructions as it takes --
 //                   on gfx950 a vector instruction beside the f64 matrix instruction costs its full issue time
-//                   (tools/microbench/mfma_f64_shadow.hip); k_score_niw64 keeps dims 33 .. 128
+//                   (tools/microbench/mfma_f64_shadow.hip); k_score_niw64_wide: dims 33 .. 128 likewise (k_score_niw64
+//                   stays for operand streams beyond 2 GiB, where the buffer loads' 32-bit offsets end)
 //   k_niw_bucket_*, k_niw_group_sums   sum_x, sum_xxT by group: rows bucketed by group, summed in registers
 //
 // Leave-one-out needs no second factorisation: with u = x - mu_n, t = u^T Psi_n^-1 u,
@@ -778,6 +779,147 @@ __global__ __launch_bounds__(256, 2) void k_score_niw64_lag(const FeatDesc *__re
   }
 }
 
+// 32 < dim <= 128 with the same cuts (round 5): two row blocks a wave and the operand stream pipelined by chunk as in
+// k_score_niw64<NB, 2> (a chunk's successor -- the next group's first included -- is fetched when the chunk starts to
+// multiply: two chunks of operands live whatever the dimension), buffer loads, accumulators started from W mu as the
+// C operand against negated features (kept as floats: the conversion stays next to its matrix instruction, the widened
+// copies of NB = 8 would be 256 registers), the reduce-scatter lane sums over the groups in k_score_niw64_lag's order and
+// its batch finish.  The occupancy is asked for -- three waves a SIMD up to dim 80, two beyond: left to itself the compiler
+// took 208 .. 292 registers where 155 .. 203 do without a spill -- and with it N = 256k, K = 128 goes from 1.94 / 3.08 / 4.94 /
+// 6.86 / 9.03 / 11.5 ms at dim 48 / 64 / 80 / 96 / 112 / 128 (k_score_niw64<NB, 2>) to 1.75 / 2.80 / 4.11 / 5.94 / 7.83 / 9.95,
+// leave-one-out at dim 128 from 17.5 to 9.96.
+template <int NB, bool LOO, bool ACCUM>
+__global__ __launch_bounds__(256, NB <= 5 ? 3 : 2) void k_score_niw64_wide(const FeatDesc *__restrict__ feats, uint32_t f,
+                                                           uint32_t K, uint32_t kpad, uint64_t row0,
+                                                           uint64_t nrows, const int32_t *z,
+                                                           double *__restrict__ qown, float *__restrict__ out, uint64_t ld) {
+  static_assert(NB > 2 && NB <= 8, "32 < dim <= 128");
+  constexpr int JB = 2, NS = 4 * NB, NCH = NB * (NB + 1) / 2;
+  const FeatDesc fd = feats[f];
+  const uint32_t d = fd.dim;
+  const int lane = threadIdx.x & 63, c = lane & 15, kk = lane >> 4;
+  const uint64_t nblocks = (nrows + 16 * JB - 1) / (16 * JB);
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+  const float *X = reinterpret_cast<const float *>(fd.col);
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t Wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(fd.niw_w64), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t Bb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(fd.niw_mu64), 0, 0x7fffffff, 0x00020000);
+  const uint32_t lane_off = lane * 32;
+  const uint32_t Kfull = K & ~15u;
+  auto group_at = [&](uint32_t t) -> uint32_t {
+    const uint32_t g = t < Kfull ? (t & ~15u) + 4 * (t & 3) + ((t >> 2) & 3) : t;
+    return g < K ? g : K - 1;
+  };
+  auto load2 = [&](double2 (&o)[2], __amdgpu_buffer_rsrc_t buf, uint32_t byte) {
+    const u32x4v lo = __builtin_amdgcn_raw_buffer_load_b128(buf, lane_off, byte, 0);
+    const u32x4v hi = __builtin_amdgcn_raw_buffer_load_b128(buf, lane_off + 16, byte, 0);
+    o[0] = double2{__hiloint2double((int)lo[1], (int)lo[0]), __hiloint2double((int)lo[3], (int)lo[2])};
+    o[1] = double2{__hiloint2double((int)hi[1], (int)hi[0]), __hiloint2double((int)hi[3], (int)hi[2])};
+  };
+  for (uint64_t blk = wave_id; blk < nblocks; blk += nwaves) {
+    const uint64_t rb = blk * 16 * JB;
+    float xn[JB][NS];            // MINUS this lane's feature of every step, for its row of each block
+    int gz[JB];
+    bool live[JB], msk[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; jb++) {
+      const uint64_t row = rb + 16 * jb + c;
+      live[jb] = row < nrows;
+      const float *xp = X + (row0 + (live[jb] ? row : 0)) * d;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        const bool has = live[jb] && (uint32_t)(4 * s + kk) < d;
+        const float v = xp[has ? 4 * s + kk : 0];
+        xn[jb][s] = has ? -v : 0.0f;
+      }
+      gz[jb] = (LOO && live[jb]) ? z[row] : -1;
+      msk[jb] = false;
+      if (live[jb] && fd.mask != nullptr)
+        for (uint32_t e = 0; e < d; e++) msk[jb] |= fd.mask[(row0 + row) * d + e] != 0;
+    }
+    double qkeep[JB][4], held[JB], half[JB];
+    double2 nxt[2];                                         // the chunk after the one that multiplies
+    load2(nxt, Wb, group_at(0) * (NCH * 2048u));
+    const uint32_t Kt = (K + 3u) & ~3u;                     // times: whole sets of four (past the table: the last group again)
+    for (uint32_t t = 0; t < Kt; t++) {
+      const uint32_t g = group_at(t), gn = group_at(t + 1);
+      const int i = (int)(t & 3u);
+      const bool tail = t >= Kfull;
+      double qp[JB];
+#pragma unroll
+      for (int jb = 0; jb < JB; jb++) qp[jb] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        double2 m[2];
+        load2(m, Bb, g * (NB * 2048u) + b * 2048u);
+        const f64x4 mv = {m[0].x, m[0].y, m[1].x, m[1].y};
+        f64x4 acc[JB];
+#pragma unroll
+        for (int s4 = 0; s4 <= b; s4++) {
+          constexpr int kLast = NCH - 1;
+          const int ch = b * (b + 1) / 2 + s4;
+          const double a[4] = {nxt[0].x, nxt[0].y, nxt[1].x, nxt[1].y};
+          if (ch < kLast) load2(nxt, Wb, g * (NCH * 2048u) + (ch + 1) * 2048u);
+          else load2(nxt, Wb, gn * (NCH * 2048u));
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int jb = 0; jb < JB; jb++) {
+              float xv = xn[jb][4 * s4 + e];
+              asm volatile("" : "+v"(xv));                  // (the conversion stays next to its matrix instruction)
+              acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], (double)xv, (s4 == 0 && e == 0) ? mv : acc[jb], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) qp[jb] = fma(acc[jb][q], acc[jb][q], qp[jb]);
+      }
+      // lane sums: k_score_niw64_lag's reduce-scatter over the four groups of a set (wave-uniform branches on the time
+      // within the set); the last K mod 16 groups all-to-all into the slot their time names
+      if (!tail) {
+        if (i == 0 || i == 2) {
+#pragma unroll
+          for (int jb = 0; jb < JB; jb++) held[jb] = qp[jb];
+        } else {
+#pragma unroll
+          for (int jb = 0; jb < JB; jb++) {
+            const double pr = pair_rows_f64<16>(held[jb], qp[jb]);
+            if (i == 1) half[jb] = pr;
+            else {
+              const double q = pair_rows_f64<32>(half[jb], pr);
+              qkeep[jb][0] = qkeep[jb][1];
+              qkeep[jb][1] = qkeep[jb][2];
+              qkeep[jb][2] = qkeep[jb][3];
+              qkeep[jb][3] = q;
+            }
+          }
+        }
+      } else {
+        const bool mine = (int)((t >> 2) & 3) == kk;
+#pragma unroll
+        for (int jb = 0; jb < JB; jb++) {
+          const double q = xsum_rows_f64(qp[jb]);
+          if (mine) {
+            if (i == 0) qkeep[jb][0] = q;
+            else if (i == 1) qkeep[jb][1] = q;
+            else if (i == 2) qkeep[jb][2] = q;
+            else qkeep[jb][3] = q;
+          }
+        }
+      }
+      if (i == 3) {
+        const uint32_t kl = t < K ? t : K - 1;
+        if ((kl & 15) == 15) niw64_finish_batch<JB, LOO, ACCUM, true>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+        else if (kl == K - 1) niw64_finish_batch<JB, LOO, ACCUM>(fd, kl, kk, c, rb, qkeep, gz, msk, live, qown, out, ld, vec_ok);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // dim <= 8: the padded 32 x 32 contraction above would spend 16 .. 256 times the arithmetic the problem has (a
 // 3-d niw feature scored at the rate of a 32-d one: 2.7e10 evals/s whatever the dimension).  Here a lane keeps one
@@ -1068,9 +1210,12 @@ static void launch_niw64_nb(hipStream_t stream, const dim3 grid, const FeatDesc 
       return;
     }
   }
-  if constexpr (NB > 2)
-    hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 2, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
-  else
+  if constexpr (NB > 2) {
+    if ((uint64_t)K * (NB * (NB + 1) / 2) * 2048u < 0x7fffffffull)        // (buffer loads: 32-bit offsets into the operand stream)
+      hipLaunchKernelGGL((k_score_niw64_wide<NB, LOO, ACCUM>), (note_kernel(0, "k_score_niw64_wide<%d, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+    else
+      hipLaunchKernelGGL((k_score_niw64<NB, 2, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 2, %s, %s>", NB, tf(LOO), tf(ACCUM)), dim3(grid.x * 2)), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
+  } else
     hipLaunchKernelGGL((k_score_niw64<NB, 4, LOO, ACCUM>), (note_kernel(0, "k_score_niw64<%d, 4, %s, %s>", NB, tf(LOO), tf(ACCUM)), grid), dim3(256), 0, stream, feats_dev, f, K, kpad, row0, nrows, z, qown, out, ld);
 }
 template <bool LOO, bool ACCUM>
