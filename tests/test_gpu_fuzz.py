@@ -25,7 +25,8 @@ def _random_spec(rng):
         if fam == orc.DD:
             dim = int(rng.choice([2, 3, 17, 64, 65, 100, 128]))   # 65+: more categories than a feature may stage
         elif fam == orc.NIW:
-            dim = int(rng.integers(1, 6))
+            # (1 .. 5: the register kernel; now and then the f64 matrix kernels of dim <= 16, <= 32 and beyond)
+            dim = int(rng.integers(1, 6)) if rng.random() < 0.7 else int(rng.choice([9, 16, 17, 32, 33, 48]))
         elif fam == orc.DM:
             dim = int(rng.integers(2, 9))
         spec.append((fam, dim))
@@ -141,13 +142,19 @@ def test_random_scalar_feature_lists_on_many_rows(gpu_ctx, seed):
         if kind == 2 or (kind == 3 and i >= 2):
             fam = orc.NICH
         spec.append((fam, int(rng.choice([2, 9, 33, 100, 128])) if fam == orc.DD else 0))
+    # (round 5: now and then dm features with small counts -- tables staged whole: the lane <-> row kernel's dm instantiation
+    # up to 128 groups, the 8-wave tile kernel beyond and for the slices of a few hundred rows, which must agree bit for bit)
+    n_dm = int(rng.integers(1, 3)) if kind in (0, 1) and seed % 3 == 0 else 0
+    for _ in range(n_dm):
+        spec.insert(int(rng.integers(0, len(spec) + 1)), (orc.DM, int(rng.integers(2, 6))))
     N = int(rng.choice([33_000, 50_000, 70_000])) + int(rng.integers(0, 700))
     K = int(rng.choice([40, 64, 100, 128, 200, 256, 300, 384])) - int(rng.integers(0, 3))
     feats = [make_feature(f, N, K, rng, d) for f, d in spec]
+    feats = [dict(f, values=(f["values"] // 5).astype(np.int32)) if f["family"] == orc.DM else f for f in feats]
     z = rng.integers(0, K, N).astype(np.int32)
     z[7] = -1
     # (masked lookup columns keep the fast kernels; now and then a masked nich column: the one-phase-after-the-other kernels)
-    masked = [kind == 0 and (f["family"] != orc.NICH or seed % 16 == 0) and rng.random() < 0.2 for f in feats]
+    masked = [kind == 0 and f["family"] != orc.DM and (f["family"] != orc.NICH or seed % 16 == 0) and rng.random() < 0.2 for f in feats]
     dev = gpu_ctx.torch_device
     cols = [torch.from_numpy(np.ascontiguousarray(f["values"])).to(dev) for f in feats]
     rowmask = [(rng.random(N) < 0.2) if m else np.zeros(N, dtype=bool) for m in masked]
