@@ -32,6 +32,24 @@ MFMA_F64_PEAK_TF = 78.6      # dense f64 matrix peak (MI355X spec; the table's d
 # instruction per SIMD every 4 cycles (v_fma_f32 "one wave alone: 4", MI355X_MICROARCH.md per-instruction table),
 # 256 CUs x 4 SIMDs at the 2.4 GHz the guide's constants are quoted at = 6.14e11 wave-instructions/s
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
+# ... which is what ONE wave on a SIMD sustains.  With two or more waves on it a SIMD issues a plain f32 / integer vector
+# instruction every 2 cycles (it is 32 lanes wide), a transcendental every 8, an f64 or packed-f32 one every 4
+# (tools/microbench/valu_rate.hip, profiles/r05_valu_rate.txt: 2.0 / 8.1 / 4.1-4.3 cycles at the clock the run held).  So the
+# lines also carry the kernel's instructions priced at those costs against the SIMD-cycles it had: frac_weighted.
+VALU_PLAIN_CYCLES, VALU_TRANS_CYCLES = 2.0, 8.0
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+
+
+def valu_weighted(insts, busy_slots, ms):
+    """SQ_ACTIVE_INST_VALU counts one slot a plain instruction and two a transcendental: busy - insts = transcendentals"""
+    trans = max(0.0, busy_slots - insts)
+    plain = max(0.0, insts - trans)
+    cyc = plain * VALU_PLAIN_CYCLES + trans * VALU_TRANS_CYCLES
+    return {"frac_weighted": cyc / (ms * 1e-3 * SIMD_CYCLES_PER_S), "weighted_simd_cycles_per_launch": cyc,
+            "issue_cost_cycles": {"plain": VALU_PLAIN_CYCLES, "transcendental": VALU_TRANS_CYCLES,
+                                  "source": "tools/microbench/valu_rate.hip, two or more waves a SIMD (profiles/r05_valu_rate.txt)"},
+            "note": "frac / busy_frac are against ONE wave's issue rate (an instruction per 4 cycles); frac_weighted prices "
+                    "plain instructions at the SIMD's 2 cycles and transcendentals at 8, f64 / packed ones (4) counted as plain"}
 C5_ROWS_PER_RANK = 12_500_000
 C5_GROUPS = 1024
 
@@ -319,6 +337,7 @@ def sweep_roofline(nrows, K, kern_ms, kernel):
         if busy is not None:
             r["valu_issue"]["busy_slots_per_launch"] = busy
             r["valu_issue"]["busy_frac"] = busy / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
+            r["valu_issue"].update(valu_weighted(insts, busy, kern_ms))
     return r
 
 
@@ -586,6 +605,7 @@ def extra_c3(a, torch, common_amd, ctx):
         if busy is not None:
             v["busy_slots_per_launch"] = busy
             v["busy_frac"] = busy / (ms * 1e-3) / VALU_ISSUE_PEAK
+            v.update(valu_weighted(insts, busy, ms))
         return v
     r = {"workload": "C3 mixed bb+gp+dd32+nich x16, N=1M, K=256, D=64, scoring pass", "ms": avg, "ms_min": mn,
          "evals_per_s": float(N) * K * len(spec) / (avg * 1e-3), "kernel": kern,
