@@ -44,3 +44,15 @@ def test_traffic_ratio_is_counter_bytes_over_algorithmic_bytes():
     t = bench.traffic_of("k_score_nich1<false, false, 4, false>", 1.028e9)
     assert t["traffic"] is not None and abs(t["traffic_ratio"] - t["traffic"] / 1.028e9) < 1e-12
     assert bench.traffic_of("k_no_such_kernel<1>", 1.0)["traffic"] is None
+
+
+def test_weighted_vector_issue_prices_transcendentals_apart():
+    """bench.valu_weighted: SQ_ACTIVE_INST_VALU counts a transcendental twice, so busy - insts of them at 8 cycles and the
+    rest at the SIMD's 2 (tools/microbench/valu_rate.hip), against 256 x 4 SIMDs x 2.4 GHz"""
+    import bench
+    w = bench.valu_weighted(insts=1.0e9, busy_slots=1.2e9, ms=2.0)
+    cyc = 0.8e9 * 2.0 + 0.2e9 * 8.0
+    assert abs(w["weighted_simd_cycles_per_launch"] - cyc) < 1.0
+    assert abs(w["frac_weighted"] - cyc / (2.0e-3 * 256 * 4 * 2.4e9)) < 1e-12
+    # no transcendental at all: busy == insts
+    assert abs(bench.valu_weighted(1.0e9, 1.0e9, 1.0)["frac_weighted"] - 2.0e9 / (1.0e-3 * 256 * 4 * 2.4e9)) < 1e-12
